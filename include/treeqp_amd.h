@@ -1,0 +1,103 @@
+/*
+ * treeqp_amd.h -- C-ABI of the MI355X (gfx950) device path of the tdunes hot path.
+ *
+ * This is the drop-in boundary: plain `extern "C"`, pointers and sizes only, no C++/torch types.
+ * The reference has no FFI for this path (it is a static C library, Makefile:55-63); the entry
+ * points below are what its own solver front end binds, one per reference interface:
+ *
+ *   tqgpu_create / tqgpu_destroy    <- treeqp_tdunes_calculate_size + treeqp_tdunes_create
+ *                                      (dual_Newton_tree.c:1291-1407, 1411-1648): workspace sizing,
+ *                                      setup_npar/setup_idxpos (:166-194) become device tables
+ *   tqgpu_set_dynamics / _objective_diag / _bounds
+ *                                   <- the QP values the solver reads from tree_qp_in every solve
+ *                                      (tree_qp_common.h:85-115) + stage_qp_clipping_init
+ *                                      (dual_Newton_tree_clipping.c:149-184: Qinv = 1/diag(Q))
+ *   tqgpu_set_lambda                <- treeqp_tdunes_set_dual_initialization (dual_Newton_tree.c:1654-1663)
+ *   tqgpu_solve                     <- the Newton loop of treeqp_tdunes_solve (dual_Newton_tree.c:1166-1228):
+ *                                      solve_stage_problems, build_dual_problem, calculate_delta_lambda,
+ *                                      line_search, all as HIP kernels
+ *   tqgpu_get_solution              <- the export block of treeqp_tdunes_solve (:1235-1247) + export_mu
+ *                                      (dual_Newton_tree_clipping.c:386-399)
+ *
+ * Flat data layout ("ltv" order of tree_qp_common.c:1952-2090):
+ *   per node k: Qd,q,xmin,xmax (nx[k] doubles each, nodes concatenated); Rd,r,umin,umax (nu[k])
+ *   per edge e=k-1: A (nx[k] x nx[dad(k)], column major), B (nx[k] x nu[dad(k)]), b (nx[k])
+ *   lambda / lam / dlam: concatenation over k=1..Nn-1 of nx[k] doubles
+ *
+ * All functions return 0 on success, a negative TQGPU_E* code otherwise; tqgpu_last_error()
+ * returns a human-readable message for the calling thread.  Nothing here falls back to the CPU.
+ */
+#ifndef TREEQP_AMD_H_
+#define TREEQP_AMD_H_
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TQGPU_OK 0
+#define TQGPU_ENODEVICE (-1)     /* no usable HIP device / HIP runtime error */
+#define TQGPU_EINVAL (-2)        /* inconsistent tree / dimensions / options */
+#define TQGPU_ENOMEM (-3)
+#define TQGPU_EUNSUPPORTED (-4)  /* e.g. dual block too large for the LDS-resident kernels */
+#define TQGPU_ECOMM (-5)         /* RCCL failure */
+
+typedef struct tqgpu_solver tqgpu_solver;
+
+typedef struct tqgpu_opts {
+    int maxIter;
+    int termCondition;           /* termination_t value */
+    double stationarityTolerance;
+    int regType;                 /* regType_t value */
+    double regTol, regValue;
+    int lineSearchMaxIter;
+    double lineSearchGamma, lineSearchBeta;
+    int lineSearchRestartTrigger;
+    int profile;                 /* 0: total device time only; 1: per-iteration event timing */
+} tqgpu_opts;
+
+typedef struct tqgpu_result {
+    int status;                  /* return_t value: 0 optimal, 1 max iterations, 2 not a descent direction */
+    int iter;                    /* Newton iterations */
+    int ls_total;                /* total line-search trials */
+    int ls_last;                 /* trials of the last iteration */
+    int n_launches;              /* kernels launched during the solve */
+    double device_time;          /* seconds between the first and last kernel (HIP events) */
+    double last_error_norm;      /* termination norm at exit */
+    double last_fval;            /* dual function value at the last accepted point */
+} tqgpu_result;
+
+int tqgpu_device_count(void);
+const char *tqgpu_last_error(void);
+const char *tqgpu_version(void);
+
+int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *nk, const int *nx, const int *nu);
+void tqgpu_destroy(tqgpu_solver *s);
+
+int tqgpu_set_dynamics(tqgpu_solver *s, const double *A, const double *B, const double *b);
+int tqgpu_set_objective_diag(tqgpu_solver *s, const double *Qd, const double *Rd, const double *q, const double *r);
+int tqgpu_set_bounds(tqgpu_solver *s, const double *xmin, const double *xmax, const double *umin, const double *umax);
+int tqgpu_set_lambda(tqgpu_solver *s, const double *lambda);   /* NULL = zeros */
+
+int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *opts, tqgpu_result *res);
+
+/* any output pointer may be NULL */
+int tqgpu_get_solution(tqgpu_solver *s, double *x, double *u, double *lam, double *mu_x, double *mu_u, double *dlam);
+
+/* sizes of the flat arrays, for callers that did not keep them */
+int tqgpu_dims(const tqgpu_solver *s, int *sum_nx, int *sum_nu, int *sum_lam, int *sum_A, int *sum_B);
+
+/* per-iteration line-search counts and event times (seconds) of the last solve; arrays of
+ * length >= iter; times are NaN unless opts.profile != 0 */
+int tqgpu_get_iteration_log(const tqgpu_solver *s, int *ls_iters, double *iter_times, int cap);
+
+/* roofline support: algorithmic bytes and flops of ONE Newton iteration with n_ls line-search
+ * trials (closed form of SURVEY.md §8(d) generalised to per-node dimensions) */
+int tqgpu_iteration_cost(const tqgpu_solver *s, int n_ls, double *bytes, double *flops);
+
+/* sizeof() of the public structs (0 dmat, 1 dvec, 2 node, 3 tree_qp_in, 4 tree_qp_out,
+ * 5 tdunes opts, 6 tdunes workspace, 7 profiling record, 8 qp_internal_t) for FFI self-checks */
+int treeqp_amd_sizeof(int which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* TREEQP_AMD_H_ */

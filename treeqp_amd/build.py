@@ -1,0 +1,136 @@
+"""Build the native pieces of treeqp_amd, in-tree.
+
+* ``libtreeqp_amd.so``  -- the product: host C layer (gcc) + HIP device path for gfx950 (hipcc),
+  one C-ABI shared library (include/treeqp_amd.h + the reference-compatible treeqp headers).
+* ``oracle/liboracle.so`` -- the CPU oracle (test infrastructure only, never linked into the product).
+* ``oracle/_ref/*``      -- only when /root/reference is present: the reference's own example
+  drivers, compiled UNCHANGED from where they lie and linked against libtreeqp_amd.so (drop-in
+  proof for the boundary; the binaries travel to the GPU box, the sources do not).
+
+hipcc cross-compiles gfx950 without a GPU, so this runs on the CPU-only build container.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+CSRC = ROOT / "treeqp_amd" / "csrc"
+LIBDIR = ROOT / "treeqp_amd" / "lib"
+OBJDIR = ROOT / "build" / "obj"
+INCLUDE = ROOT / "include"
+REFERENCE = Path("/root/reference")
+
+HOST_SOURCES = ["blasfeo_compat.c", "tree_topology.c", "host_utils.c", "qp_container.c", "tdunes_host.c"]
+DEVICE_SOURCES = ["tdunes_device.hip"]
+
+HOST_CFLAGS = ["-O2", "-g", "-fPIC", "-std=gnu99", "-Wall", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+
+
+def _run(cmd, **kw):
+    print("[build]", " ".join(str(c) for c in cmd), flush=True)
+    subprocess.run([str(c) for c in cmd], check=True, **kw)
+
+
+def _newer(target: Path, sources) -> bool:
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(Path(s).stat().st_mtime > t for s in sources)
+
+
+def hipcc_path() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found: the treeqp_amd device path cannot be built")
+
+
+def product_library() -> Path:
+    return LIBDIR / "libtreeqp_amd.so"
+
+
+def build_product(force: bool = False) -> Path:
+    LIBDIR.mkdir(parents=True, exist_ok=True)
+    OBJDIR.mkdir(parents=True, exist_ok=True)
+    headers = list(INCLUDE.rglob("*.h"))
+    objs = []
+    for name in HOST_SOURCES:
+        src = CSRC / "host" / name
+        obj = OBJDIR / (name + ".o")
+        if force or _newer(obj, [src] + headers):
+            _run(["gcc", *HOST_CFLAGS, f"-I{INCLUDE}", "-c", src, "-o", obj])
+        objs.append(obj)
+    hipcc = hipcc_path()
+    for name in DEVICE_SOURCES:
+        src = CSRC / "device" / name
+        obj = OBJDIR / (name + ".o")
+        extra = list((CSRC / "device").glob("*.h")) + list((CSRC / "device").glob("*.hpp"))
+        if force or _newer(obj, [src] + headers + extra):
+            _run([hipcc, *HIP_FLAGS, f"-I{INCLUDE}", f"-I{CSRC / 'device'}", "-c", src, "-o", obj])
+        objs.append(obj)
+    lib = product_library()
+    if force or _newer(lib, objs):
+        _run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", *objs, "-o", lib, "-lm"])
+    return lib
+
+
+def oracle_library() -> Path:
+    return ROOT / "oracle" / "liboracle.so"
+
+
+def build_oracle(force: bool = False, native: bool = False) -> Path:
+    src = ROOT / "oracle" / "tdunes_oracle.c"
+    hdr = ROOT / "oracle" / "tdunes_oracle.h"
+    lib = oracle_library()
+    if force or _newer(lib, [src, hdr]):
+        # portable flags: the .so built here travels to the GPU box (different host CPU)
+        arch = ["-march=native"] if native else ["-mavx2", "-mfma"]
+        _run(["gcc", "-O3", *arch, "-fopenmp", "-fPIC", "-std=gnu99", "-Wall", "-Wno-unused-function",
+              "-shared", "-o", lib, src, "-lm"])
+    return lib
+
+
+REF_EXAMPLES = {
+    # output name -> (source relative to the reference root, extra defines)
+    "spring_mass_tdunes": ("examples/spring_mass_dual_newton_tree.c", ["-DNREP=20", "-DPRINT_LEVEL=1", "-DPROFILE=0"]),
+    "thesis_example": ("examples/thesis_example.c", ["-DNREP=1", "-DPRINT_LEVEL=1", "-DPROFILE=0"]),
+}
+
+
+def build_reference_dropins(force: bool = False):
+    """Compile the reference's UNCHANGED example drivers against our headers + library."""
+    if not REFERENCE.exists():
+        return []
+    outdir = ROOT / "oracle" / "_ref"
+    outdir.mkdir(parents=True, exist_ok=True)
+    lib = product_library()
+    built = []
+    for name, (rel, defs) in REF_EXAMPLES.items():
+        src = REFERENCE / rel
+        exe = outdir / name
+        if not src.exists():
+            continue
+        if force or _newer(exe, [src, lib]):
+            # -I<reference> is needed only for the driver's `#include "examples/.../data.c"`;
+            # our include dir comes first so every treeqp/blasfeo header resolves to ours.
+            _run(["gcc", "-O2", "-std=gnu99", *defs, f"-I{INCLUDE}", f"-I{REFERENCE}", src, "-o", exe,
+                  f"-L{LIBDIR}", "-ltreeqp_amd", f"-Wl,-rpath,$ORIGIN/../../treeqp_amd/lib", "-lm"])
+        built.append(exe)
+    return built
+
+
+def build_all(force: bool = False):
+    lib = build_product(force)
+    orc = build_oracle(force)
+    refs = build_reference_dropins(force)
+    return lib, orc, refs
+
+
+if __name__ == "__main__":
+    out = build_all(force="--force" in sys.argv)
+    print("[build] done:", *out[:2], *out[2])

@@ -1,0 +1,964 @@
+/*
+ * tdunes_device.hip -- MI355X (gfx950) device path of the tdunes hot path + its C-ABI.
+ *
+ * Replaces, as hand-written HIP kernels, the reference call sequences:
+ *   k_stage   <- solve_stage_problems (dual_Newton_tree.c:218-330) + clipping solve_extended
+ *                (dual_Newton_tree_clipping.c:188-227) fused with evaluate_dual_function
+ *                (:823-918) + eval_dual_term (clipping.c:359-382) and the multiplier update of
+ *                line_search (:964-968)
+ *   k_grad    <- dual gradient loop of build_dual_problem (:519-539) + per-node norm partials
+ *   k_check   <- calculate_error_in_residuals (:412-442) + termination test (:542-546)
+ *   k_hess    <- dual Hessian loop (:551-615) with set_CmPnCmT / add_EPmE / add_CmPnCkT
+ *                (clipping.c:264-355) as ONE C*P*C' product per parent block
+ *   k_factor  <- backward sweep of calculate_delta_lambda (:668-752) with
+ *                treeqp_dpotrf_l_with_reg_opts (dual_Newton_common.c:36-78): potrf, trsv_lnn and
+ *                trsm_rltn done as one "tall" Cholesky of [W; resMod'; Ut], then dsyrk/dgemv Schur
+ *                updates into the parent block
+ *   k_forward <- forward sweep (:756-775) + partial of gradient_trans_times_direction (:808-820)
+ *   k_ls_*    <- line_search control flow (:922-1019), decided on the device
+ *
+ * Design: one 64-lane wavefront owns one tree node (k_stage, k_grad) or one dual-Hessian block
+ * (k_hess, k_factor, k_forward); the block lives in LDS while it is worked on; nodes/blocks of
+ * one tree level form one grid.  All indices come from flat prefix-sum tables, so per-node
+ * dimensions nx[k], nu[k], nk[k] are free (nx[0] = 0 after x0 elimination included).  The active
+ * set bookkeeping of the reference (checkLastActiveSet) is not needed: every iteration rebuilds
+ * every block, which yields bit-identical factors (DESIGN.md "checkLastActiveSet").
+ *
+ * Control flow lives in a device control block (struct Ctrl): every kernel first looks at it and
+ * returns if its phase is not due, so the host may enqueue ahead without reading back.
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "treeqp_amd.h"
+
+#define WAVE 64
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(TQGPU_ENODEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+    } while (0)
+
+/* ------------------------------------------------------------------------------------------ */
+/* device-side tables                                                                         */
+/* ------------------------------------------------------------------------------------------ */
+
+struct Tree {            /* device pointers, passed by value */
+    int Nn, Np, Nh, nx0;
+    const int *dad, *nk, *kid0, *nx, *nu, *xoff, *uoff, *aoff, *boff, *pos, *bdim, *woff, *utoff;
+};
+
+struct Ctrl {
+    int done;            /* all work finished (converged / max iterations / failure)        */
+    int status;          /* return_t value                                                   */
+    int iter;            /* completed Newton iterations                                      */
+    int cur;             /* which lambda buffer holds the current point                      */
+    int ls_pending;      /* line search wants another trial                                  */
+    int ls_iter;         /* trial counter of the running line search                         */
+    int ls_total;
+    int ls_last;
+    int restart_counter; /* work->lineSearchRestartCounter                                   */
+    int n_reg;           /* blocks regularised (diagnostic)                                  */
+    int pad0, pad1;
+    double tau, tauPrev, fval0, fval, dot, err;
+};
+
+struct Data {            /* device pointers, passed by value */
+    const double *A, *B, *b, *Qd, *Rd, *q, *r, *xmin, *xmax, *umin, *umax;
+    double *Qinv, *Rinv;
+    double *qmod, *rmod, *x, *u, *xUnc, *uUnc, *QinvCal, *RinvCal;
+    double *lam0, *lam1, *dlam, *res, *resMod;
+    double *W, *CholW, *invd, *Ut, *CholUt;
+    double *fval, *part_err, *part_dot;
+    Ctrl *ctrl;
+    int *ls_log;
+    int ls_log_cap;
+};
+
+struct Opts {
+    int maxIter, termCondition, regType, lsMaxIter, lsRestartTrigger;
+    double tol, regTol, regValue, gamma, beta;
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, WAVE));
+    return v;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* k_init: Qinv = 1/Qd, Rinv = 1/Rd  (stage_qp_clipping_init, clipping.c:163-170)             */
+/* ------------------------------------------------------------------------------------------ */
+__global__ void k_init(int n_x, int n_u, Data D) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_x) D.Qinv[i] = 1.0 / D.Qd[i];
+    if (i < n_u) D.Rinv[i] = 1.0 / D.Rd[i];
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* k_stage: one wave per node.  mode 0: evaluate at lam[cur] (first sweep of a solve);         */
+/* mode 1: line-search trial, lam_next = lam_cur + (tau - tauPrev) * dlam, evaluate there.     */
+/* Produces qmod,rmod,x,u,xUnc,uUnc,QinvCal,RinvCal and the node's dual-function term.         */
+/* ------------------------------------------------------------------------------------------ */
+__global__ void __launch_bounds__(WAVE) k_stage(Tree T, Data D, int mode) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const Ctrl *c = D.ctrl;
+    if (c->done) return;
+    if (mode == 1 && !c->ls_pending) return;
+
+    const int k = blockIdx.x, lane = threadIdx.x;
+    const int nxk = T.nx[k], nuk = T.nu[k], xo = T.xoff[k], uo = T.uoff[k];
+    const int nkid = T.nk[k], d = T.bdim[k];
+    const double *lamc = c->cur ? D.lam1 : D.lam0;
+    double *lamn = c->cur ? D.lam0 : D.lam1;
+    const double step = c->tau - c->tauPrev;
+
+    /* lambda of the children = dual block of node k, contiguous at xoff[kid0] */
+    double *lk = lds;                   /* d doubles  */
+    double *lown = lds + d;             /* nxk doubles */
+    const int ko = nkid > 0 ? T.xoff[T.kid0[k]] : 0;
+    for (int t = lane; t < d; t += WAVE) {
+        double v = lamc[ko + t];
+        if (mode == 1) v = fma(step, D.dlam[ko + t], v);
+        lk[t] = v;
+    }
+    for (int t = lane; t < nxk; t += WAVE) {
+        double v = 0.0;
+        if (k > 0) {
+            v = lamc[xo + t];
+            if (mode == 1) { v = fma(step, D.dlam[xo + t], v); lamn[xo + t] = v; }
+        }
+        lown[t] = v;
+    }
+    __syncthreads();
+
+    double p_qx = 0.0, p_hx = 0.0, p_ru = 0.0, p_hu = 0.0;   /* partial dots for the dual term */
+    for (int t = lane; t < nxk + nuk; t += WAVE) {
+        const bool isx = t < nxk;
+        const int j = isx ? t : t - nxk;
+        double v = isx ? fma(-1.0, D.q[xo + j], lown[j]) : -1.0 * D.r[uo + j];
+        int rowoff = 0;
+        for (int cc = 0; cc < nkid; cc++) {
+            const int kid = T.kid0[k] + cc, nxc = T.nx[kid];
+            const double *col = isx ? D.A + T.aoff[kid] + (size_t)j * nxc : D.B + T.boff[kid] + (size_t)j * nxc;
+            double acc = 0.0;
+            for (int i = 0; i < nxc; i++) acc = fma(col[i], lk[rowoff + i], acc);
+            v = fma(-1.0, acc, v);
+            rowoff += nxc;
+        }
+        if (isx) {
+            D.qmod[xo + j] = v;
+            const double qi = D.Qinv[xo + j];
+            const double unc = qi * v, lo = D.xmin[xo + j], hi = D.xmax[xo + j];
+            double xv, cal;
+            if (unc >= hi) { xv = hi; cal = 0.0; } else if (unc <= lo) { xv = lo; cal = 0.0; } else { xv = unc; cal = qi; }
+            D.xUnc[xo + j] = unc; D.x[xo + j] = xv; D.QinvCal[xo + j] = cal;
+            p_qx = fma(D.Qd[xo + j] * xv, xv, p_qx);
+            p_hx = fma(v, xv, p_hx);
+        } else {
+            D.rmod[uo + j] = v;
+            const double ri = D.Rinv[uo + j];
+            const double unc = ri * v, lo = D.umin[uo + j], hi = D.umax[uo + j];
+            double uv, cal;
+            if (unc >= hi) { uv = hi; cal = 0.0; } else if (unc <= lo) { uv = lo; cal = 0.0; } else { uv = unc; cal = ri; }
+            D.uUnc[uo + j] = unc; D.u[uo + j] = uv; D.RinvCal[uo + j] = cal;
+            p_ru = fma(D.Rd[uo + j] * uv, uv, p_ru);
+            p_hu = fma(v, uv, p_hu);
+        }
+    }
+    /* cmod = sum_kids b_kid' lambda_kid */
+    double p_c = 0.0;
+    for (int t = lane; t < d; t += WAVE) p_c = fma(D.b[ko + t], lk[t], p_c);
+    p_qx = wave_sum(p_qx); p_hx = wave_sum(p_hx); p_ru = wave_sum(p_ru); p_hu = wave_sum(p_hu); p_c = wave_sum(p_c);
+    if (lane == 0) {
+        double f = -0.5 * p_qx - p_c;       /* clipping.c:375 */
+        f += p_hx;                          /* :376 */
+        f -= 0.5 * p_ru;                    /* :380 */
+        f += p_hu;                          /* :381 */
+        D.fval[k] = f;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* block reductions (one workgroup of 256 threads, fixed pairwise order => deterministic)      */
+/* ------------------------------------------------------------------------------------------ */
+template <bool IS_MAX>
+__device__ double block_reduce(const double *v, int n, double *sh) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) acc = IS_MAX ? fmax(acc, v[i]) : acc + v[i];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] = IS_MAX ? fmax(sh[threadIdx.x], sh[threadIdx.x + s]) : sh[threadIdx.x] + sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    return sh[0];
+}
+
+/* first sweep of a solve: fval0 = sum of the node terms */
+__global__ void __launch_bounds__(256) k_fval_init(Tree T, Data D) {
+    __shared__ double sh[256];
+    const double f = block_reduce<false>(D.fval, T.Nn, sh);
+    if (threadIdx.x == 0) { D.ctrl->fval0 = f; D.ctrl->fval = f; }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* k_grad: one wave per node k >= 1:  res_k = b_k - x_k + A_k x_dad + B_k u_dad                */
+/* ------------------------------------------------------------------------------------------ */
+__global__ void __launch_bounds__(WAVE) k_grad(Tree T, Data D, int termCondition) {
+    const Ctrl *c = D.ctrl;
+    if (c->done || c->ls_pending) return;
+    const int k = blockIdx.x + 1, lane = threadIdx.x;
+    const int p = T.dad[k], nxk = T.nx[k], nxp = T.nx[p], nup = T.nu[p];
+    const int xo = T.xoff[k], xp = T.xoff[p], up = T.uoff[p];
+    const double *A = D.A + T.aoff[k], *B = D.B + T.boff[k];
+    double part = 0.0;
+    for (int i = lane; i < nxk; i += WAVE) {
+        double rv = fma(-1.0, D.x[xo + i], D.b[xo + i]);
+        double acc = 0.0;
+        for (int j = 0; j < nxp; j++) acc = fma(A[i + (size_t)j * nxk], D.x[xp + j], acc);
+        rv += acc;
+        acc = 0.0;
+        for (int j = 0; j < nup; j++) acc = fma(B[i + (size_t)j * nxk], D.u[up + j], acc);
+        rv += acc;
+        D.res[xo + i] = rv;
+        D.resMod[xo + i] = rv;
+        part = (termCondition == 2) ? fmax(part, fabs(rv)) : fma(rv, rv, part);
+    }
+    part = (termCondition == 2) ? wave_max(part) : wave_sum(part);
+    if (lane == 0) D.part_err[k] = part;
+}
+
+/* termination test; also the top-of-loop bookkeeping of the Newton iteration */
+__global__ void __launch_bounds__(256) k_check(Tree T, Data D, Opts O) {
+    __shared__ double sh[256];
+    Ctrl *c = D.ctrl;
+    if (c->done || c->ls_pending) return;
+    double err = (O.termCondition == 2) ? block_reduce<true>(D.part_err + 1, T.Nn - 1, sh)
+                                        : block_reduce<false>(D.part_err + 1, T.Nn - 1, sh);
+    if (threadIdx.x == 0) {
+        if (O.termCondition == 1) err = sqrt(err);
+        c->err = err;
+        if (err < O.tol) { c->done = 1; c->status = 0; }      /* TREEQP_OPTIMAL_SOLUTION_FOUND */
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* k_hess: one wave per parent block p.                                                        */
+/*   W_p = C P C' + blockdiag(QinvCal_kids),  C = [A_c B_c] stacked over the children,         */
+/*   P = diag(QinvCal_p, RinvCal_p);   Ut_p = -(C[:, :nx_p] P)'                                */
+/* ------------------------------------------------------------------------------------------ */
+__global__ void __launch_bounds__(WAVE) k_hess(Tree T, Data D) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const Ctrl *c = D.ctrl;
+    if (c->done || c->ls_pending) return;
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const int d = T.bdim[p], nxp = T.nx[p], nup = T.nu[p], nz = nxp + nup;
+    double *Cs = lds;                 /* d x nz, column major, ld = d */
+    double *CP = lds + (size_t)d * nz;
+    const int k0 = T.kid0[p], ko = T.xoff[k0];
+    const double *Qc = D.QinvCal + T.xoff[p], *Rc = D.RinvCal + T.uoff[p];
+    /* stage the children's [A B] rows */
+    int rowoff = 0;
+    for (int cc = 0; cc < T.nk[p]; cc++) {
+        const int kid = k0 + cc, nxc = T.nx[kid];
+        const double *A = D.A + T.aoff[kid], *B = D.B + T.boff[kid];
+        for (int e = lane; e < nxc * nz; e += WAVE) {
+            const int i = e % nxc, col = e / nxc;
+            const double a = col < nxp ? A[i + (size_t)col * nxc] : B[i + (size_t)(col - nxp) * nxc];
+            const double pc = col < nxp ? Qc[col] : Rc[col - nxp];
+            Cs[rowoff + i + (size_t)col * d] = a;
+            CP[rowoff + i + (size_t)col * d] = a * pc;
+        }
+        rowoff += nxc;
+    }
+    __syncthreads();
+    double *W = D.W + T.woff[p];
+    for (int e = lane; e < d * d; e += WAVE) {
+        const int i = e % d, j = e / d;
+        if (i < j) continue;
+        double acc = 0.0, acc2 = 0.0;
+        for (int cidx = 0; cidx < nxp; cidx++) acc = fma(Cs[i + (size_t)cidx * d], CP[j + (size_t)cidx * d], acc);
+        for (int cidx = nxp; cidx < nz; cidx++) acc2 = fma(Cs[i + (size_t)cidx * d], CP[j + (size_t)cidx * d], acc2);
+        double w = acc + acc2;
+        if (i == j) w += D.QinvCal[ko + i];
+        W[i + (size_t)j * d] = w;
+    }
+    if (p > 0) {
+        double *Ut = D.Ut + T.utoff[p];
+        for (int e = lane; e < nxp * d; e += WAVE) {
+            const int i = e % nxp, rr = e / nxp;
+            Ut[i + (size_t)rr * nxp] = -1.0 * CP[rr + (size_t)i * d];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* k_factor: one wave per block of one tree level (blocks first .. first+count-1).             */
+/* Tall Cholesky of T = [W ; resMod' ; Ut] (R = d + 1 + nx_ii rows, d columns), left-looking,   */
+/* one lane per row:  rows 0..d-1 -> L,  row d -> (L^-1 resMod)',  rows d+1.. -> Ut L^-T.       */
+/* Root block (ii == 0): no Ut rows; followed by the backward solve L^-T.                       */
+/* ------------------------------------------------------------------------------------------ */
+__device__ __forceinline__ void tall_potrf(double *Tm, double *invd, int R, int d, int ld, int lane) {
+    for (int j = 0; j < d; j++) {
+        /* every row i >= j : s_i = T[i,j] - sum_{k<j} T[i,k] T[j,k] */
+        for (int i = j + lane; i < R; i += WAVE) {
+            double s = Tm[i + (size_t)j * ld];
+            for (int k = 0; k < j; k++) s = fma(-Tm[i + (size_t)k * ld], Tm[j + (size_t)k * ld], s);
+            Tm[i + (size_t)j * ld] = s;
+        }
+        __syncthreads();
+        const double cjj = Tm[j + (size_t)j * ld];
+        const double finv = cjj > 0.0 ? 1.0 / sqrt(cjj) : 0.0;      /* pivot <= 0 -> zero column */
+        for (int i = j + lane; i < R; i += WAVE) Tm[i + (size_t)j * ld] *= finv;
+        if (lane == 0) invd[j] = finv;
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(WAVE) k_factor(Tree T, Data D, Opts O, int first) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    Ctrl *c = D.ctrl;
+    if (c->done || c->ls_pending) return;
+    const int ii = first + blockIdx.x, lane = threadIdx.x;
+    const int d = T.bdim[ii], nxi = ii > 0 ? T.nx[ii] : 0;
+    const int R = d + 1 + nxi, ld = R | 1;
+    double *Tm = lds;                         /* ld x d */
+    double *invd = lds + (size_t)ld * d;      /* d */
+    const double *W = D.W + T.woff[ii];
+    const int bo = T.xoff[T.kid0[ii]];        /* offset of the block vector */
+    const double *Ut = D.Ut + T.utoff[ii];
+
+    for (int pass = 0; pass < 2; pass++) {
+        for (int e = lane; e < d * d; e += WAVE) {
+            const int i = e % d, j = e / d;
+            double w = W[i + (size_t)j * d];
+            if (i == j && (O.regType == 1 || pass == 1)) w += O.regValue;   /* ddiare */
+            Tm[i + (size_t)j * ld] = w;
+        }
+        for (int j = lane; j < d; j += WAVE) Tm[d + (size_t)j * ld] = D.resMod[bo + j];
+        for (int e = lane; e < nxi * d; e += WAVE) {
+            const int i = e % nxi, j = e / nxi;
+            Tm[d + 1 + i + (size_t)j * ld] = Ut[i + (size_t)j * nxi];
+        }
+        __syncthreads();
+        tall_potrf(Tm, invd, R, d, ld, lane);
+        if (O.regType != 2 || pass == 1) break;
+        /* on-the-fly Levenberg-Marquardt: any diagonal entry <= regTol -> shift and refactorize */
+        int small = 0;
+        for (int j = lane; j < d; j += WAVE) small |= (Tm[j + (size_t)j * ld] <= O.regTol);
+        if (!__any(small)) break;
+        if (lane == 0) atomicAdd(&c->n_reg, 1);
+        __syncthreads();
+    }
+
+    /* outputs: factor, reciprocal diagonal */
+    double *L = D.CholW + T.woff[ii];
+    for (int e = lane; e < d * d; e += WAVE) {
+        const int i = e % d, j = e / d;
+        if (i >= j) L[i + (size_t)j * d] = Tm[i + (size_t)j * ld];
+    }
+    for (int j = lane; j < d; j += WAVE) D.invd[bo + j] = invd[j];
+
+    if (ii > 0) {
+        for (int j = lane; j < d; j += WAVE) D.dlam[bo + j] = Tm[d + (size_t)j * ld];
+        double *CUt = D.CholUt + T.utoff[ii];
+        for (int e = lane; e < nxi * d; e += WAVE) {
+            const int i = e % nxi, j = e / nxi;
+            CUt[i + (size_t)j * nxi] = Tm[d + 1 + i + (size_t)j * ld];
+        }
+        /* Schur complement into the parent's diagonal sub-block and right-hand side */
+        const int dd = T.dad[ii], pos = T.pos[ii], ddim = T.bdim[dd];
+        double *Wd = D.W + T.woff[dd];
+        for (int e = lane; e < nxi * nxi; e += WAVE) {
+            const int i = e % nxi, j = e / nxi;
+            if (i < j) continue;
+            double acc = 0.0;
+            for (int cidx = 0; cidx < d; cidx++) acc = fma(Tm[d + 1 + i + (size_t)cidx * ld], Tm[d + 1 + j + (size_t)cidx * ld], acc);
+            Wd[(pos + i) + (size_t)(pos + j) * ddim] -= acc;
+        }
+        const int xo = T.xoff[ii];
+        for (int i = lane; i < nxi; i += WAVE) {
+            double acc = 0.0;
+            for (int cidx = 0; cidx < d; cidx++) acc = fma(Tm[d + 1 + i + (size_t)cidx * ld], Tm[d + (size_t)cidx * ld], acc);
+            D.resMod[xo + i] -= acc;
+        }
+    } else {
+        /* root: dlam_0 = L^-T (L^-1 resMod_0); column-oriented back substitution, k descending */
+        double *z = Tm + d;                 /* row d, stride ld */
+        double pd = 0.0;
+        for (int k = d - 1; k >= 0; k--) {
+            __syncthreads();
+            const double zk = z[(size_t)k * ld] * invd[k];
+            for (int i = lane; i < k; i += WAVE) z[(size_t)i * ld] = fma(-Tm[k + (size_t)i * ld], zk, z[(size_t)i * ld]);
+            __syncthreads();
+            if (lane == 0) z[(size_t)k * ld] = zk;
+        }
+        __syncthreads();
+        for (int j = lane; j < d; j += WAVE) {
+            const double v = z[(size_t)j * ld];
+            D.dlam[bo + j] = v;
+            pd = fma(D.res[bo + j], v, pd);
+        }
+        pd = wave_sum(pd);
+        if (lane == 0) D.part_dot[0] = pd;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* k_forward: one wave per block of one level:                                                 */
+/*   dlam_ii = L^-T ( y_ii - CholUt_ii' * dlam_dad[pos..] )                                    */
+/* ------------------------------------------------------------------------------------------ */
+__global__ void __launch_bounds__(WAVE) k_forward(Tree T, Data D, int first) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const Ctrl *c = D.ctrl;
+    if (c->done || c->ls_pending) return;
+    const int ii = first + blockIdx.x, lane = threadIdx.x;
+    const int d = T.bdim[ii], nxi = T.nx[ii], ld = d | 1;
+    double *L = lds;                      /* ld x d */
+    double *z = lds + (size_t)ld * d;     /* d */
+    double *dl = z + d;                   /* nxi : dlam of node ii (inside the parent's block) */
+    const int bo = T.xoff[T.kid0[ii]], xo = T.xoff[ii];
+    const double *Lg = D.CholW + T.woff[ii];
+    for (int e = lane; e < d * d; e += WAVE) {
+        const int i = e % d, j = e / d;
+        if (i >= j) L[i + (size_t)j * ld] = Lg[i + (size_t)j * d];
+    }
+    for (int i = lane; i < nxi; i += WAVE) dl[i] = D.dlam[xo + i];
+    __syncthreads();
+    const double *CUt = D.CholUt + T.utoff[ii];
+    for (int j = lane; j < d; j += WAVE) {
+        double acc = 0.0;
+        for (int i = 0; i < nxi; i++) acc = fma(CUt[i + (size_t)j * nxi], dl[i], acc);
+        z[j] = fma(-1.0, acc, D.dlam[bo + j]);
+    }
+    const double *invd = D.invd + bo;
+    for (int k = d - 1; k >= 0; k--) {
+        __syncthreads();
+        const double zk = z[k] * invd[k];
+        for (int i = lane; i < k; i += WAVE) z[i] = fma(-L[k + (size_t)i * ld], zk, z[i]);
+        __syncthreads();
+        if (lane == 0) z[k] = zk;
+    }
+    __syncthreads();
+    double pd = 0.0;
+    for (int j = lane; j < d; j += WAVE) {
+        D.dlam[bo + j] = z[j];
+        pd = fma(D.res[bo + j], z[j], pd);
+    }
+    pd = wave_sum(pd);
+    if (lane == 0) D.part_dot[ii] = pd;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* line-search control (line_search, dual_Newton_tree.c:922-1019)                              */
+/* ------------------------------------------------------------------------------------------ */
+__global__ void __launch_bounds__(256) k_ls_begin(Tree T, Data D) {
+    __shared__ double sh[256];
+    Ctrl *c = D.ctrl;
+    if (c->done || c->ls_pending) return;
+    const double s = block_reduce<false>(D.part_dot, T.Np, sh);
+    if (threadIdx.x == 0) {
+        const double dotp = -s;                                     /* :819 */
+        c->dot = dotp;
+        if (dotp > 1e-10 || !((dotp > 1e-10) || (dotp < 1e-10))) {  /* :951, NaN included */
+            c->done = 1; c->status = 2;                             /* TREEQP_DN_NOT_DESCENT_DIRECTION */
+        } else {
+            c->tau = 1.0; c->tauPrev = 0.0; c->ls_iter = 1; c->ls_pending = 1;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_ls_decide(Tree T, Data D, Opts O) {
+    __shared__ double sh[256];
+    Ctrl *c = D.ctrl;
+    if (c->done || !c->ls_pending) return;
+    const double f = block_reduce<false>(D.fval, T.Nn, sh);
+    if (threadIdx.x == 0) {
+        c->cur ^= 1;                       /* the trial point is now the current point */
+        c->fval = f;
+        int finished = 0, lsIter = c->ls_iter;
+        if (c->restart_counter == O.lsRestartTrigger) finished = 1;                        /* :973 */
+        else if (f <= c->fval0 + O.gamma * c->tau * c->dot) finished = 1;                  /* :982 */
+        else {
+            c->tauPrev = c->tau;
+            c->tau = O.beta * c->tauPrev;
+            if (lsIter + 1 > O.lsMaxIter) { finished = 1; lsIter = lsIter + 1; }           /* loop exhausted */
+            else c->ls_iter = lsIter + 1;
+        }
+        if (finished) {
+            if (lsIter >= O.lsMaxIter) c->restart_counter++; else c->restart_counter = 0;  /* :993-1000 */
+            c->ls_pending = 0;
+            c->ls_last = lsIter;
+            c->ls_total += lsIter;
+            if (c->iter < D.ls_log_cap) D.ls_log[c->iter] = lsIter;
+            c->iter += 1;
+            c->fval0 = f;                  /* same point, same sweep => identical to a re-evaluation */
+            if (c->iter >= O.maxIter) { c->done = 1; c->status = 1; }                      /* MAXIMUM_ITERATIONS */
+        }
+    }
+}
+
+/* export_mu (clipping.c:386-399): mu = Q .* (xUnc - x) */
+__global__ void k_export_mu(int n_x, int n_u, Data D, double *mu_x, double *mu_u) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_x) mu_x[i] = D.Qd[i] * fma(-1.0, D.x[i], D.xUnc[i]);
+    if (i < n_u) mu_u[i] = D.Rd[i] * fma(-1.0, D.u[i], D.uUnc[i]);
+}
+
+}  // namespace
+
+/* ============================================================================================ */
+/* host side of the C-ABI                                                                       */
+/* ============================================================================================ */
+
+struct tqgpu_solver {
+    int device = 0;
+    int Nn = 0, Np = 0, Nh = 0;
+    std::vector<int> nk, nx, nu, dad, stage, kid0, xoff, uoff, aoff, boff, pos, bdim, woff, utoff, lvl_first;
+    int sum_nx = 0, sum_nu = 0, sum_lam = 0, sum_A = 0, sum_B = 0, sum_W = 0, sum_Ut = 0, nx0 = 0;
+    size_t lds_stage = 0, lds_hess = 0, lds_factor = 0, lds_forward = 0;
+    void *slab = nullptr;
+    size_t slab_bytes = 0;
+    Tree T{};
+    Data D{};
+    double *d_mu_x = nullptr, *d_mu_u = nullptr;
+    /* writable aliases of the const inputs */
+    double *A = nullptr, *B = nullptr, *b = nullptr, *Qd = nullptr, *Rd = nullptr, *q = nullptr, *r = nullptr;
+    double *xmin = nullptr, *xmax = nullptr, *umin = nullptr, *umax = nullptr;
+    Ctrl *h_ctrl = nullptr;      /* pinned */
+    int *h_ls_log = nullptr;     /* pinned */
+    int ls_log_cap = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> iter_ev;
+    std::vector<double> iter_times;
+    int last_iter = 0;
+    bool need_init = true;
+};
+
+extern "C" const char *tqgpu_last_error(void) { return g_err.c_str(); }
+extern "C" const char *tqgpu_version(void) { return "treeqp_amd tdunes device path r1 (gfx950, generic wave-per-block kernels)"; }
+
+extern "C" int tqgpu_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+namespace {
+
+struct Carver {
+    size_t off = 0;
+    size_t take(size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; }
+};
+
+template <typename T>
+T *at(void *base, size_t off) { return reinterpret_cast<T *>(static_cast<char *>(base) + off); }
+
+int build_tables(tqgpu_solver *s) {
+    const int Nn = s->Nn;
+    s->dad.assign(Nn, -1); s->stage.assign(Nn, 0); s->kid0.assign(Nn, -1);
+    int cursor = 1;
+    for (int i = 0; i < Nn; i++) {
+        if (s->nk[i] < 0) return fail(TQGPU_EINVAL, "negative number of children");
+        if (s->nk[i] > 0) s->kid0[i] = cursor;
+        for (int c = 0; c < s->nk[i]; c++) {
+            if (cursor + c >= Nn) return fail(TQGPU_EINVAL, "children counts exceed the number of nodes");
+            s->dad[cursor + c] = i;
+            s->stage[cursor + c] = s->stage[i] + 1;
+        }
+        cursor += s->nk[i];
+    }
+    if (cursor != Nn) return fail(TQGPU_EINVAL, "children counts do not add up to Nn - 1");
+    s->Np = 0;
+    for (int i = 0; i < Nn; i++) s->Np += s->nk[i] > 0;
+    for (int i = 0; i < Nn; i++)
+        if ((s->nk[i] > 0) != (i < s->Np)) return fail(TQGPU_EINVAL, "tdunes needs all leaves at the same depth");
+    s->Nh = s->stage[Nn - 1];
+    s->lvl_first.assign(s->Nh + 2, Nn);
+    for (int i = Nn - 1; i >= 0; i--) s->lvl_first[s->stage[i]] = i;
+    s->lvl_first[s->Nh + 1] = Nn;
+
+    s->xoff.assign(Nn + 1, 0); s->uoff.assign(Nn + 1, 0); s->aoff.assign(Nn + 1, 0); s->boff.assign(Nn + 1, 0);
+    s->pos.assign(Nn, 0); s->bdim.assign(Nn, 0); s->woff.assign(Nn + 1, 0); s->utoff.assign(Nn + 1, 0);
+    for (int k = 0; k < Nn; k++) {
+        if (s->nx[k] < 0 || s->nu[k] < 0) return fail(TQGPU_EINVAL, "negative dimension");
+        s->xoff[k + 1] = s->xoff[k] + s->nx[k];
+        s->uoff[k + 1] = s->uoff[k] + s->nu[k];
+        if (k > 0) {
+            s->aoff[k + 1] = s->aoff[k] + s->nx[k] * s->nx[s->dad[k]];
+            s->boff[k + 1] = s->boff[k] + s->nx[k] * s->nu[s->dad[k]];
+            int first = s->kid0[s->dad[k]];
+            for (int j = first; j < k; j++) s->pos[k] += s->nx[j];     /* dual_Newton_tree.c:177-194 */
+        }
+        int d = 0;
+        for (int c = 0; c < s->nk[k]; c++) d += s->nx[s->kid0[k] + c];
+        s->bdim[k] = d;
+        s->woff[k + 1] = s->woff[k] + d * d;
+        s->utoff[k + 1] = s->utoff[k] + (k > 0 ? s->nx[k] * d : 0);
+    }
+    s->nx0 = s->nx[0];
+    s->sum_nx = s->xoff[Nn]; s->sum_nu = s->uoff[Nn]; s->sum_lam = s->sum_nx - s->nx0;
+    s->sum_A = s->aoff[Nn]; s->sum_B = s->boff[Nn]; s->sum_W = s->woff[Nn]; s->sum_Ut = s->utoff[Nn];
+
+    /* LDS budgets of the wave-per-block kernels */
+    s->lds_stage = s->lds_hess = s->lds_factor = s->lds_forward = 0;
+    for (int k = 0; k < Nn; k++) {
+        const size_t d = s->bdim[k], nz = s->nx[k] + s->nu[k];
+        s->lds_stage = std::max(s->lds_stage, (d + s->nx[k] + 2) * sizeof(double));
+        if (k < s->Np) {
+            s->lds_hess = std::max(s->lds_hess, (2 * d * nz + 2) * sizeof(double));
+            const size_t R = d + 1 + (k > 0 ? s->nx[k] : 0), ld = R | 1;
+            s->lds_factor = std::max(s->lds_factor, (ld * d + d + 2) * sizeof(double));
+            s->lds_forward = std::max(s->lds_forward, ((d | 1) * d + d + s->nx[k] + 2) * sizeof(double));
+        }
+    }
+    const size_t lim = 160 * 1024;
+    if (s->lds_factor > lim || s->lds_hess > lim)
+        return fail(TQGPU_EUNSUPPORTED, "dual Hessian block too large for the LDS-resident kernels (160 KiB per workgroup)");
+    return TQGPU_OK;
+}
+
+template <typename K>
+int allow_lds(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return TQGPU_OK;
+}
+
+}  // namespace
+
+extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *nk, const int *nx, const int *nu) {
+    if (!out || Nn < 2 || !nk || !nx || !nu) return fail(TQGPU_EINVAL, "tqgpu_create: bad arguments");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(TQGPU_ENODEVICE, std::string("no HIP device available (") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0") + "); the tdunes hot path has no CPU fallback");
+    if (device < 0) HIP_TRY(hipGetDevice(&device));
+    if (device >= ndev) return fail(TQGPU_EINVAL, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+
+    tqgpu_solver *s = new tqgpu_solver();
+    s->device = device; s->Nn = Nn;
+    s->nk.assign(nk, nk + Nn); s->nx.assign(nx, nx + Nn); s->nu.assign(nu, nu + Nn);
+    int rc = build_tables(s);
+    if (rc != TQGPU_OK) { delete s; return rc; }
+
+    /* one slab for everything */
+    Carver cv;
+    const size_t I = sizeof(int), Dbl = sizeof(double);
+    const size_t o_dad = cv.take(Nn * I), o_nk = cv.take(Nn * I), o_kid0 = cv.take(Nn * I), o_nx = cv.take(Nn * I), o_nu = cv.take(Nn * I);
+    const size_t o_xoff = cv.take((Nn + 1) * I), o_uoff = cv.take((Nn + 1) * I), o_aoff = cv.take((Nn + 1) * I), o_boff = cv.take((Nn + 1) * I);
+    const size_t o_pos = cv.take(Nn * I), o_bdim = cv.take(Nn * I), o_woff = cv.take((Nn + 1) * I), o_utoff = cv.take((Nn + 1) * I);
+    const size_t SX = s->sum_nx, SU = s->sum_nu;
+    const size_t o_A = cv.take(s->sum_A * Dbl), o_B = cv.take(s->sum_B * Dbl), o_b = cv.take(SX * Dbl);
+    const size_t o_Qd = cv.take(SX * Dbl), o_q = cv.take(SX * Dbl), o_xmin = cv.take(SX * Dbl), o_xmax = cv.take(SX * Dbl);
+    const size_t o_Rd = cv.take(SU * Dbl), o_r = cv.take(SU * Dbl), o_umin = cv.take(SU * Dbl), o_umax = cv.take(SU * Dbl);
+    const size_t o_Qinv = cv.take(SX * Dbl), o_Rinv = cv.take(SU * Dbl);
+    const size_t o_qmod = cv.take(SX * Dbl), o_x = cv.take(SX * Dbl), o_xUnc = cv.take(SX * Dbl), o_Qcal = cv.take(SX * Dbl);
+    const size_t o_rmod = cv.take(SU * Dbl), o_u = cv.take(SU * Dbl), o_uUnc = cv.take(SU * Dbl), o_Rcal = cv.take(SU * Dbl);
+    const size_t o_lam0 = cv.take(SX * Dbl), o_lam1 = cv.take(SX * Dbl), o_dlam = cv.take(SX * Dbl), o_res = cv.take(SX * Dbl), o_resMod = cv.take(SX * Dbl);
+    const size_t o_invd = cv.take(SX * Dbl);
+    const size_t o_W = cv.take(s->sum_W * Dbl), o_CW = cv.take(s->sum_W * Dbl), o_Ut = cv.take(s->sum_Ut * Dbl), o_CUt = cv.take(s->sum_Ut * Dbl);
+    const size_t o_fval = cv.take(Nn * Dbl), o_perr = cv.take(Nn * Dbl), o_pdot = cv.take(Nn * Dbl);
+    const size_t o_mux = cv.take(SX * Dbl), o_muu = cv.take(SU * Dbl);
+    const size_t o_ctrl = cv.take(sizeof(Ctrl));
+    s->ls_log_cap = 4096;
+    const size_t o_log = cv.take(s->ls_log_cap * I);
+    s->slab_bytes = cv.off + 256;
+
+    auto cleanup_fail = [&](int code) { tqgpu_destroy(s); return code; };
+    if (hipMalloc(&s->slab, s->slab_bytes) != hipSuccess) { delete s; return fail(TQGPU_ENOMEM, "hipMalloc failed for the device mirror"); }
+    if (hipMemset(s->slab, 0, s->slab_bytes) != hipSuccess) return cleanup_fail(fail(TQGPU_ENODEVICE, "hipMemset failed"));
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) return cleanup_fail(fail(TQGPU_ENODEVICE, "hipStreamCreate failed"));
+    if (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) return cleanup_fail(fail(TQGPU_ENODEVICE, "hipEventCreate failed"));
+    if (hipHostMalloc((void **)&s->h_ctrl, sizeof(Ctrl), hipHostMallocDefault) != hipSuccess) return cleanup_fail(fail(TQGPU_ENOMEM, "hipHostMalloc failed"));
+    if (hipHostMalloc((void **)&s->h_ls_log, s->ls_log_cap * I, hipHostMallocDefault) != hipSuccess) return cleanup_fail(fail(TQGPU_ENOMEM, "hipHostMalloc failed"));
+
+    void *base = s->slab;
+#define UP(off, vec) if (hipMemcpy(at<int>(base, off), (vec).data(), (vec).size() * I, hipMemcpyHostToDevice) != hipSuccess) return cleanup_fail(fail(TQGPU_ENODEVICE, "table upload failed"))
+    UP(o_dad, s->dad); UP(o_nk, s->nk); UP(o_kid0, s->kid0); UP(o_nx, s->nx); UP(o_nu, s->nu);
+    UP(o_xoff, s->xoff); UP(o_uoff, s->uoff); UP(o_aoff, s->aoff); UP(o_boff, s->boff);
+    UP(o_pos, s->pos); UP(o_bdim, s->bdim); UP(o_woff, s->woff); UP(o_utoff, s->utoff);
+#undef UP
+    Tree &T = s->T;
+    T.Nn = Nn; T.Np = s->Np; T.Nh = s->Nh; T.nx0 = s->nx0;
+    T.dad = at<int>(base, o_dad); T.nk = at<int>(base, o_nk); T.kid0 = at<int>(base, o_kid0);
+    T.nx = at<int>(base, o_nx); T.nu = at<int>(base, o_nu); T.xoff = at<int>(base, o_xoff); T.uoff = at<int>(base, o_uoff);
+    T.aoff = at<int>(base, o_aoff); T.boff = at<int>(base, o_boff); T.pos = at<int>(base, o_pos);
+    T.bdim = at<int>(base, o_bdim); T.woff = at<int>(base, o_woff); T.utoff = at<int>(base, o_utoff);
+    Data &D = s->D;
+    s->A = at<double>(base, o_A); s->B = at<double>(base, o_B); s->b = at<double>(base, o_b);
+    s->Qd = at<double>(base, o_Qd); s->Rd = at<double>(base, o_Rd); s->q = at<double>(base, o_q); s->r = at<double>(base, o_r);
+    s->xmin = at<double>(base, o_xmin); s->xmax = at<double>(base, o_xmax); s->umin = at<double>(base, o_umin); s->umax = at<double>(base, o_umax);
+    D.A = s->A; D.B = s->B; D.b = s->b; D.Qd = s->Qd; D.Rd = s->Rd; D.q = s->q; D.r = s->r;
+    D.xmin = s->xmin; D.xmax = s->xmax; D.umin = s->umin; D.umax = s->umax;
+    D.Qinv = at<double>(base, o_Qinv); D.Rinv = at<double>(base, o_Rinv);
+    D.qmod = at<double>(base, o_qmod); D.rmod = at<double>(base, o_rmod); D.x = at<double>(base, o_x); D.u = at<double>(base, o_u);
+    D.xUnc = at<double>(base, o_xUnc); D.uUnc = at<double>(base, o_uUnc); D.QinvCal = at<double>(base, o_Qcal); D.RinvCal = at<double>(base, o_Rcal);
+    D.lam0 = at<double>(base, o_lam0); D.lam1 = at<double>(base, o_lam1); D.dlam = at<double>(base, o_dlam);
+    D.res = at<double>(base, o_res); D.resMod = at<double>(base, o_resMod); D.invd = at<double>(base, o_invd);
+    D.W = at<double>(base, o_W); D.CholW = at<double>(base, o_CW); D.Ut = at<double>(base, o_Ut); D.CholUt = at<double>(base, o_CUt);
+    D.fval = at<double>(base, o_fval); D.part_err = at<double>(base, o_perr); D.part_dot = at<double>(base, o_pdot);
+    D.ctrl = at<Ctrl>(base, o_ctrl); D.ls_log = at<int>(base, o_log); D.ls_log_cap = s->ls_log_cap;
+    s->d_mu_x = at<double>(base, o_mux); s->d_mu_u = at<double>(base, o_muu);
+
+    if ((rc = allow_lds(k_stage, s->lds_stage)) || (rc = allow_lds(k_hess, s->lds_hess)) ||
+        (rc = allow_lds(k_factor, s->lds_factor)) || (rc = allow_lds(k_forward, s->lds_forward)))
+        return cleanup_fail(rc);
+    *out = s;
+    return TQGPU_OK;
+}
+
+extern "C" void tqgpu_destroy(tqgpu_solver *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    for (auto &ev : s->iter_ev) (void)hipEventDestroy(ev);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    if (s->h_ctrl) (void)hipHostFree(s->h_ctrl);
+    if (s->h_ls_log) (void)hipHostFree(s->h_ls_log);
+    if (s->slab) (void)hipFree(s->slab);
+    delete s;
+}
+
+extern "C" int tqgpu_dims(const tqgpu_solver *s, int *sum_nx, int *sum_nu, int *sum_lam, int *sum_A, int *sum_B) {
+    if (!s) return fail(TQGPU_EINVAL, "null solver");
+    if (sum_nx) *sum_nx = s->sum_nx;
+    if (sum_nu) *sum_nu = s->sum_nu;
+    if (sum_lam) *sum_lam = s->sum_lam;
+    if (sum_A) *sum_A = s->sum_A;
+    if (sum_B) *sum_B = s->sum_B;
+    return TQGPU_OK;
+}
+
+#define H2D(dst, src, count)                                                                                   \
+    do {                                                                                                       \
+        if ((src) && (count) > 0)                                                                              \
+            HIP_TRY(hipMemcpyAsync((dst), (src), sizeof(double) * (size_t)(count), hipMemcpyHostToDevice, s->stream)); \
+    } while (0)
+
+extern "C" int tqgpu_set_dynamics(tqgpu_solver *s, const double *A, const double *B, const double *b) {
+    if (!s) return fail(TQGPU_EINVAL, "null solver");
+    HIP_TRY(hipSetDevice(s->device));
+    H2D(s->A, A, s->sum_A); H2D(s->B, B, s->sum_B);
+    H2D(s->b + s->nx0, b, s->sum_lam);              /* node-indexed on the device: root slot unused */
+    HIP_TRY(hipStreamSynchronize(s->stream));       /* the caller may reuse its buffers */
+    return TQGPU_OK;
+}
+
+extern "C" int tqgpu_set_objective_diag(tqgpu_solver *s, const double *Qd, const double *Rd, const double *q, const double *r) {
+    if (!s) return fail(TQGPU_EINVAL, "null solver");
+    HIP_TRY(hipSetDevice(s->device));
+    H2D(s->Qd, Qd, s->sum_nx); H2D(s->Rd, Rd, s->sum_nu); H2D(s->q, q, s->sum_nx); H2D(s->r, r, s->sum_nu);
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    s->need_init = true;
+    return TQGPU_OK;
+}
+
+extern "C" int tqgpu_set_bounds(tqgpu_solver *s, const double *xmin, const double *xmax, const double *umin, const double *umax) {
+    if (!s) return fail(TQGPU_EINVAL, "null solver");
+    HIP_TRY(hipSetDevice(s->device));
+    H2D(s->xmin, xmin, s->sum_nx); H2D(s->xmax, xmax, s->sum_nx); H2D(s->umin, umin, s->sum_nu); H2D(s->umax, umax, s->sum_nu);
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return TQGPU_OK;
+}
+
+extern "C" int tqgpu_set_lambda(tqgpu_solver *s, const double *lambda) {
+    if (!s) return fail(TQGPU_EINVAL, "null solver");
+    HIP_TRY(hipSetDevice(s->device));
+    /* the current buffer is lam0 at the start of every solve */
+    if (lambda) { H2D(s->D.lam0 + s->nx0, lambda, s->sum_lam); }
+    else HIP_TRY(hipMemsetAsync(s->D.lam0, 0, sizeof(double) * (size_t)s->sum_nx, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return TQGPU_OK;
+}
+#undef H2D
+
+namespace {
+
+int read_ctrl(tqgpu_solver *s) {
+    HIP_TRY(hipMemcpyAsync(s->h_ctrl, s->D.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return TQGPU_OK;
+}
+
+}  // namespace
+
+extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *res) {
+    if (!s || !o || !res) return fail(TQGPU_EINVAL, "tqgpu_solve: bad arguments");
+    HIP_TRY(hipSetDevice(s->device));
+    Opts O;
+    O.maxIter = o->maxIter; O.termCondition = o->termCondition; O.regType = o->regType;
+    O.lsMaxIter = o->lineSearchMaxIter; O.lsRestartTrigger = o->lineSearchRestartTrigger;
+    O.tol = o->stationarityTolerance; O.regTol = o->regTol; O.regValue = o->regValue;
+    O.gamma = o->lineSearchGamma; O.beta = o->lineSearchBeta;
+    if (O.termCondition < 0 || O.termCondition > 2 || O.regType < 0 || O.regType > 2 || O.regValue < 0)
+        return fail(TQGPU_EINVAL, "invalid option value");
+
+    const Tree &T = s->T; const Data &D = s->D;
+    hipStream_t st = s->stream;
+    int launches = 0;
+    const int nxu = std::max(s->sum_nx, s->sum_nu);
+
+    Ctrl init;
+    memset(&init, 0, sizeof(init));
+    HIP_TRY(hipMemcpyAsync(D.ctrl, &init, sizeof(Ctrl), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(D.ls_log, 0, sizeof(int) * (size_t)s->ls_log_cap, st));
+    HIP_TRY(hipStreamSynchronize(st));     /* `init` lives on this stack frame */
+
+    if (o->profile) {
+        while ((int)s->iter_ev.size() < o->maxIter + 1) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); s->iter_ev.push_back(ev); }
+    }
+    s->iter_times.assign((size_t)std::max(o->maxIter, 1), NAN);
+
+    HIP_TRY(hipEventRecord(s->ev0, st));
+    if (s->need_init) {
+        hipLaunchKernelGGL(k_init, dim3((nxu + 255) / 256), dim3(256), 0, st, s->sum_nx, s->sum_nu, D); launches++;
+        s->need_init = false;
+    }
+    /* first sweep at lambda0 (phase S of iteration 0 + fval0) */
+    hipLaunchKernelGGL(k_stage, dim3(T.Nn), dim3(WAVE), s->lds_stage, st, T, D, 0); launches++;
+    hipLaunchKernelGGL(k_fval_init, dim3(1), dim3(256), 0, st, T, D); launches++;
+
+    int host_iter = 0;
+    bool finished = o->maxIter <= 0;       /* nothing to iterate: reported as "maximum iterations" */
+    if (finished) { HIP_TRY(hipStreamSynchronize(st)); memset(s->h_ctrl, 0, sizeof(Ctrl)); s->h_ctrl->status = 1; }
+    if (o->profile) HIP_TRY(hipEventRecord(s->iter_ev[0], st));
+    while (!finished) {
+        /* ---- one Newton iteration (dual_Newton_tree.c:1166-1228) ---- */
+        hipLaunchKernelGGL(k_grad, dim3(T.Nn - 1), dim3(WAVE), 0, st, T, D, O.termCondition); launches++;
+        hipLaunchKernelGGL(k_check, dim3(1), dim3(256), 0, st, T, D, O); launches++;
+        hipLaunchKernelGGL(k_hess, dim3(T.Np), dim3(WAVE), s->lds_hess, st, T, D); launches++;
+        for (int lvl = T.Nh - 1; lvl >= 0; lvl--) {
+            const int first = s->lvl_first[lvl], count = s->lvl_first[lvl + 1] - first;
+            hipLaunchKernelGGL(k_factor, dim3(count), dim3(WAVE), s->lds_factor, st, T, D, O, first); launches++;
+        }
+        for (int lvl = 1; lvl < T.Nh; lvl++) {
+            const int first = s->lvl_first[lvl], count = s->lvl_first[lvl + 1] - first;
+            hipLaunchKernelGGL(k_forward, dim3(count), dim3(WAVE), s->lds_forward, st, T, D, first); launches++;
+        }
+        hipLaunchKernelGGL(k_ls_begin, dim3(1), dim3(256), 0, st, T, D); launches++;
+        hipLaunchKernelGGL(k_stage, dim3(T.Nn), dim3(WAVE), s->lds_stage, st, T, D, 1); launches++;
+        hipLaunchKernelGGL(k_ls_decide, dim3(1), dim3(256), 0, st, T, D, O); launches++;
+        int rc = read_ctrl(s);
+        if (rc != TQGPU_OK) return rc;
+        while (!s->h_ctrl->done && s->h_ctrl->ls_pending) {
+            hipLaunchKernelGGL(k_stage, dim3(T.Nn), dim3(WAVE), s->lds_stage, st, T, D, 1); launches++;
+            hipLaunchKernelGGL(k_ls_decide, dim3(1), dim3(256), 0, st, T, D, O); launches++;
+            if ((rc = read_ctrl(s)) != TQGPU_OK) return rc;
+        }
+        host_iter++;
+        if (o->profile && host_iter < (int)s->iter_ev.size()) HIP_TRY(hipEventRecord(s->iter_ev[host_iter], st));
+        finished = s->h_ctrl->done != 0;
+    }
+    HIP_TRY(hipEventRecord(s->ev1, st));
+    HIP_TRY(hipMemcpyAsync(s->h_ls_log, D.ls_log, sizeof(int) * (size_t)s->ls_log_cap, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return fail(TQGPU_ENODEVICE, std::string("kernel launch failed: ") + hipGetErrorString(le));
+
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    if (o->profile) {
+        for (int i = 0; i < host_iter && i + 1 < (int)s->iter_ev.size() && i < (int)s->iter_times.size(); i++) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, s->iter_ev[i], s->iter_ev[i + 1]) == hipSuccess) s->iter_times[i] = 1e-3 * t;
+        }
+    }
+    const Ctrl &c = *s->h_ctrl;
+    res->status = c.status; res->iter = c.iter; res->ls_total = c.ls_total; res->ls_last = c.ls_last;
+    res->n_launches = launches; res->device_time = 1e-3 * ms; res->last_error_norm = c.err; res->last_fval = c.fval;
+    s->last_iter = c.iter;
+    return TQGPU_OK;
+}
+
+extern "C" int tqgpu_get_solution(tqgpu_solver *s, double *x, double *u, double *lam, double *mu_x, double *mu_u, double *dlam) {
+    if (!s) return fail(TQGPU_EINVAL, "null solver");
+    HIP_TRY(hipSetDevice(s->device));
+    hipStream_t st = s->stream;
+    const Data &D = s->D;
+    const double *lamc = s->h_ctrl->cur ? D.lam1 : D.lam0;
+    if (mu_x || mu_u) {
+        const int n = std::max(s->sum_nx, s->sum_nu);
+        hipLaunchKernelGGL(k_export_mu, dim3((n + 255) / 256), dim3(256), 0, st, s->sum_nx, s->sum_nu, D, s->d_mu_x, s->d_mu_u);
+    }
+#define D2H(dst, src, count) do { if ((dst) && (count) > 0) HIP_TRY(hipMemcpyAsync((dst), (src), sizeof(double) * (size_t)(count), hipMemcpyDeviceToHost, st)); } while (0)
+    D2H(x, D.x, s->sum_nx); D2H(u, D.u, s->sum_nu);
+    D2H(lam, lamc + s->nx0, s->sum_lam); D2H(dlam, D.dlam + s->nx0, s->sum_lam);
+    D2H(mu_x, s->d_mu_x, s->sum_nx); D2H(mu_u, s->d_mu_u, s->sum_nu);
+#undef D2H
+    HIP_TRY(hipStreamSynchronize(st));
+    return TQGPU_OK;
+}
+
+extern "C" int tqgpu_get_iteration_log(const tqgpu_solver *s, int *ls_iters, double *iter_times, int cap) {
+    if (!s) return fail(TQGPU_EINVAL, "null solver");
+    const int n = std::min(std::min(cap, s->last_iter), s->ls_log_cap);
+    for (int i = 0; i < n; i++) {
+        if (ls_iters) ls_iters[i] = s->h_ls_log[i];
+        if (iter_times) iter_times[i] = i < (int)s->iter_times.size() ? s->iter_times[i] : NAN;
+    }
+    return TQGPU_OK;
+}
+
+/* Algorithmic bytes / flops of one Newton iteration (every input read once, every output written
+ * once per phase; SURVEY.md §8(d) generalised to per-node dimensions; n_ls line-search trials,
+ * each counted as the reference does: one dual-function sweep, plus the fval0 sweep). */
+extern "C" int tqgpu_iteration_cost(const tqgpu_solver *s, int n_ls, double *bytes, double *flops) {
+    if (!s) return fail(TQGPU_EINVAL, "null solver");
+    double Sb = 0, Gb = 0, Hb = 0, Fb = 0, Lb = 0, Sf = 0, Gf = 0, Hf = 0, Ff = 0, Lf = 0;
+    const int Nn = s->Nn;
+    for (int k = 0; k < Nn; k++) {
+        const double nx = s->nx[k], nu = s->nu[k], d = s->bdim[k];
+        Sb += 9 * nx + 9 * nu; Lb += 6 * nx + 1 + 6 * nu;
+        if (k > 0) {
+            const int p = s->dad[k];
+            const double AB = nx * (s->nx[p] + s->nu[p]);
+            Sb += AB + 2 * nx; Gb += AB + 4 * nx; Hb += AB + nx; Lb += AB + 3 * nx;
+            Sf += 2 * AB; Gf += 2 * AB; Lf += 2 * AB;
+            Hf += AB + nx * (nx + 1) * (s->nx[p] + s->nu[p]);
+        }
+        if (k < s->Np) {
+            Gb += nx + nu; Hb += nx + nu + d * (d + 1) / 2; Lb += 1.5 * d;
+            Fb += 3 * d * (d + 1) / 2 + 5 * d;
+            Ff += d * d * d / 3 + 2 * d * d;
+            /* off-diagonal sibling blocks */
+            for (int a = 0; a < s->nk[k]; a++) for (int c = 0; c < a; c++) {
+                const double na = s->nx[s->kid0[k] + a], nc = s->nx[s->kid0[k] + c];
+                Hf += nc * (nx + nu) + 2 * na * nc * (nx + nu);
+            }
+            if (k > 0) {
+                Hb += nx * d; Fb += 3 * nx * d + nx * (nx + 1) + 3 * nx;
+                Ff += nx * d * d + nx * (nx + 1) * d + 4 * nx * d;
+            }
+        }
+    }
+    const double sweeps = 1 + n_ls;       /* fval0 + trials */
+    if (bytes) *bytes = 8.0 * (Sb + Gb + Hb + Fb + sweeps * Lb);
+    if (flops) *flops = Sf + Gf + Hf + Ff + sweeps * Lf;
+    return TQGPU_OK;
+}

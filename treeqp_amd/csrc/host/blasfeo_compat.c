@@ -1,0 +1,189 @@
+/*
+ * blasfeo_compat.c -- from-scratch, column-major implementation of the BLASFEO-named routines
+ * the treeqp_amd HOST layer uses (containers, marshalling, level-1/2 algebra for the KKT check
+ * and x0 elimination).  Not a port of BLASFEO: no panel-major storage, no kernels, no level-3
+ * and no factorizations (those exist only as HIP device code in this build).
+ */
+#include <blasfeo_common.h>
+#include <blasfeo_d_aux.h>
+#include <blasfeo_d_aux_ext_dep.h>
+#include <blasfeo_d_blas.h>
+#include <blasfeo_v_aux_ext_dep.h>
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define EL(s, i, j) ((s)->pA[(i) + (size_t)(j) * (s)->m])
+
+/* ---- containers ---- */
+int blasfeo_memsize_dmat(int m, int n) { return (int)sizeof(double) * m * n; }
+int blasfeo_memsize_dvec(int m) { return (int)sizeof(double) * m; }
+
+void blasfeo_create_dmat(int m, int n, struct blasfeo_dmat *sA, void *memory) {
+    sA->pA = (double *)memory; sA->m = m; sA->n = n; sA->memsize = blasfeo_memsize_dmat(m, n);
+}
+void blasfeo_create_dvec(int m, struct blasfeo_dvec *sa, void *memory) {
+    sa->pa = (double *)memory; sa->m = m; sa->memsize = blasfeo_memsize_dvec(m);
+}
+void blasfeo_allocate_dmat(int m, int n, struct blasfeo_dmat *sA) {
+    blasfeo_create_dmat(m, n, sA, calloc((size_t)(m * n > 0 ? m * n : 1), sizeof(double)));
+}
+void blasfeo_allocate_dvec(int m, struct blasfeo_dvec *sa) {
+    blasfeo_create_dvec(m, sa, calloc((size_t)(m > 0 ? m : 1), sizeof(double)));
+}
+void blasfeo_free_dmat(struct blasfeo_dmat *sA) { free(sA->pA); sA->pA = NULL; }
+void blasfeo_free_dvec(struct blasfeo_dvec *sa) { free(sa->pa); sa->pa = NULL; }
+
+void v_zeros(void **p, int size) { *p = calloc((size_t)(size > 0 ? size : 1), 1); }
+void v_zeros_align(void **p, int size) {
+    if (posix_memalign(p, 64, (size_t)(size > 0 ? size : 64))) { *p = NULL; return; }
+    memset(*p, 0, (size_t)(size > 0 ? size : 64));
+}
+void v_free(void *p) { free(p); }
+void v_free_align(void *p) { free(p); }
+void d_zeros(double **pA, int row, int col) { *pA = calloc((size_t)(row * col > 0 ? row * col : 1), sizeof(double)); }
+void d_free(double *pA) { free(pA); }
+
+/* ---- marshalling ---- */
+void blasfeo_pack_dmat(int m, int n, double *A, int lda, struct blasfeo_dmat *sA, int ai, int aj) {
+    for (int j = 0; j < n; j++) for (int i = 0; i < m; i++) EL(sA, ai + i, aj + j) = A[i + (size_t)j * lda];
+}
+void blasfeo_pack_tran_dmat(int m, int n, double *A, int lda, struct blasfeo_dmat *sA, int ai, int aj) {
+    for (int j = 0; j < n; j++) for (int i = 0; i < m; i++) EL(sA, ai + j, aj + i) = A[i + (size_t)j * lda];
+}
+void blasfeo_pack_dvec(int m, double *a, struct blasfeo_dvec *sa, int ai) {
+    for (int i = 0; i < m; i++) sa->pa[ai + i] = a[i];
+}
+void blasfeo_unpack_dmat(int m, int n, struct blasfeo_dmat *sA, int ai, int aj, double *A, int lda) {
+    for (int j = 0; j < n; j++) for (int i = 0; i < m; i++) A[i + (size_t)j * lda] = EL(sA, ai + i, aj + j);
+}
+void blasfeo_unpack_tran_dmat(int m, int n, struct blasfeo_dmat *sA, int ai, int aj, double *A, int lda) {
+    for (int j = 0; j < n; j++) for (int i = 0; i < m; i++) A[j + (size_t)i * lda] = EL(sA, ai + i, aj + j);
+}
+void blasfeo_unpack_dvec(int m, struct blasfeo_dvec *sa, int ai, double *a) {
+    for (int i = 0; i < m; i++) a[i] = sa->pa[ai + i];
+}
+
+/* ---- element-wise ---- */
+void blasfeo_dgese(int m, int n, double alpha, struct blasfeo_dmat *sA, int ai, int aj) {
+    for (int j = 0; j < n; j++) for (int i = 0; i < m; i++) EL(sA, ai + i, aj + j) = alpha;
+}
+void blasfeo_dvecse(int m, double alpha, struct blasfeo_dvec *sx, int xi) {
+    for (int i = 0; i < m; i++) sx->pa[xi + i] = alpha;
+}
+void blasfeo_dgecp(int m, int n, struct blasfeo_dmat *sA, int ai, int aj, struct blasfeo_dmat *sB, int bi, int bj) {
+    for (int j = 0; j < n; j++) for (int i = 0; i < m; i++) EL(sB, bi + i, bj + j) = EL(sA, ai + i, aj + j);
+}
+void blasfeo_dgesc(int m, int n, double alpha, struct blasfeo_dmat *sA, int ai, int aj) {
+    for (int j = 0; j < n; j++) for (int i = 0; i < m; i++) EL(sA, ai + i, aj + j) *= alpha;
+}
+void blasfeo_dgead(int m, int n, double alpha, struct blasfeo_dmat *sA, int ai, int aj, struct blasfeo_dmat *sB, int bi, int bj) {
+    for (int j = 0; j < n; j++) for (int i = 0; i < m; i++) EL(sB, bi + i, bj + j) += alpha * EL(sA, ai + i, aj + j);
+}
+void blasfeo_dgetr(int m, int n, struct blasfeo_dmat *sA, int ai, int aj, struct blasfeo_dmat *sC, int ci, int cj) {
+    for (int j = 0; j < n; j++) for (int i = 0; i < m; i++) EL(sC, ci + j, cj + i) = EL(sA, ai + i, aj + j);
+}
+void blasfeo_dveccp(int m, struct blasfeo_dvec *sa, int ai, struct blasfeo_dvec *sc, int ci) {
+    for (int i = 0; i < m; i++) sc->pa[ci + i] = sa->pa[ai + i];
+}
+void blasfeo_dvecsc(int m, double alpha, struct blasfeo_dvec *sa, int ai) {
+    for (int i = 0; i < m; i++) sa->pa[ai + i] *= alpha;
+}
+void blasfeo_dveccpsc(int m, double alpha, struct blasfeo_dvec *sa, int ai, struct blasfeo_dvec *sc, int ci) {
+    for (int i = 0; i < m; i++) sc->pa[ci + i] = alpha * sa->pa[ai + i];
+}
+void blasfeo_ddiaex(int kmax, double alpha, struct blasfeo_dmat *sA, int ai, int aj, struct blasfeo_dvec *sx, int xi) {
+    for (int k = 0; k < kmax; k++) sx->pa[xi + k] = alpha * EL(sA, ai + k, aj + k);
+}
+void blasfeo_ddiain(int kmax, double alpha, struct blasfeo_dvec *sx, int xi, struct blasfeo_dmat *sA, int ai, int aj) {
+    for (int k = 0; k < kmax; k++) EL(sA, ai + k, aj + k) = alpha * sx->pa[xi + k];
+}
+void blasfeo_ddiaad(int kmax, double alpha, struct blasfeo_dvec *sx, int xi, struct blasfeo_dmat *sA, int ai, int aj) {
+    for (int k = 0; k < kmax; k++) EL(sA, ai + k, aj + k) += alpha * sx->pa[xi + k];
+}
+void blasfeo_ddiare(int kmax, double alpha, struct blasfeo_dmat *sA, int ai, int aj) {
+    for (int k = 0; k < kmax; k++) EL(sA, ai + k, aj + k) += alpha;
+}
+void blasfeo_drowin(int kmax, double alpha, struct blasfeo_dvec *sx, int xi, struct blasfeo_dmat *sA, int ai, int aj) {
+    for (int k = 0; k < kmax; k++) EL(sA, ai, aj + k) = alpha * sx->pa[xi + k];
+}
+void blasfeo_drowex(int kmax, double alpha, struct blasfeo_dmat *sA, int ai, int aj, struct blasfeo_dvec *sx, int xi) {
+    for (int k = 0; k < kmax; k++) sx->pa[xi + k] = alpha * EL(sA, ai, aj + k);
+}
+void blasfeo_dvecmuldot(int m, struct blasfeo_dvec *sx, int xi, struct blasfeo_dvec *sy, int yi, struct blasfeo_dvec *sz, int zi) {
+    for (int i = 0; i < m; i++) sz->pa[zi + i] = sx->pa[xi + i] * sy->pa[yi + i];
+}
+void blasfeo_dveccl(int m, struct blasfeo_dvec *sxm, int xim, struct blasfeo_dvec *sx, int xi, struct blasfeo_dvec *sxp, int xip, struct blasfeo_dvec *sz, int zi) {
+    for (int i = 0; i < m; i++) {
+        double v = sx->pa[xi + i], lo = sxm->pa[xim + i], hi = sxp->pa[xip + i];
+        sz->pa[zi + i] = (v >= hi) ? hi : ((v <= lo) ? lo : v);
+    }
+}
+void blasfeo_dveccl_mask(int m, struct blasfeo_dvec *sxm, int xim, struct blasfeo_dvec *sx, int xi, struct blasfeo_dvec *sxp, int xip, struct blasfeo_dvec *sz, int zi, struct blasfeo_dvec *sm, int mi) {
+    for (int i = 0; i < m; i++) {
+        double v = sx->pa[xi + i], lo = sxm->pa[xim + i], hi = sxp->pa[xip + i];
+        if (v >= hi) { sz->pa[zi + i] = hi; sm->pa[mi + i] = 1.0; }
+        else if (v <= lo) { sz->pa[zi + i] = lo; sm->pa[mi + i] = -1.0; }
+        else { sz->pa[zi + i] = v; sm->pa[mi + i] = 0.0; }
+    }
+}
+void blasfeo_dvecze(int m, struct blasfeo_dvec *sm, int mi, struct blasfeo_dvec *sv, int vi, struct blasfeo_dvec *se, int ei) {
+    for (int i = 0; i < m; i++) se->pa[ei + i] = (sm->pa[mi + i] == 0.0) ? sv->pa[vi + i] : 0.0;
+}
+
+/* ---- level 1 / 2 ---- */
+void blasfeo_daxpy(int m, double alpha, struct blasfeo_dvec *sx, int xi, struct blasfeo_dvec *sy, int yi, struct blasfeo_dvec *sz, int zi) {
+    for (int i = 0; i < m; i++) sz->pa[zi + i] = sy->pa[yi + i] + alpha * sx->pa[xi + i];
+}
+double blasfeo_ddot(int m, struct blasfeo_dvec *sx, int xi, struct blasfeo_dvec *sy, int yi) {
+    double acc = 0.0;
+    for (int i = 0; i < m; i++) acc += sx->pa[xi + i] * sy->pa[yi + i];
+    return acc;
+}
+void blasfeo_dgemv_n(int m, int n, double alpha, struct blasfeo_dmat *sA, int ai, int aj, struct blasfeo_dvec *sx, int xi, double beta, struct blasfeo_dvec *sy, int yi, struct blasfeo_dvec *sz, int zi) {
+    for (int i = 0; i < m; i++) {
+        double acc = 0.0;
+        for (int j = 0; j < n; j++) acc += EL(sA, ai + i, aj + j) * sx->pa[xi + j];
+        sz->pa[zi + i] = beta * sy->pa[yi + i] + alpha * acc;
+    }
+}
+void blasfeo_dgemv_t(int m, int n, double alpha, struct blasfeo_dmat *sA, int ai, int aj, struct blasfeo_dvec *sx, int xi, double beta, struct blasfeo_dvec *sy, int yi, struct blasfeo_dvec *sz, int zi) {
+    for (int j = 0; j < n; j++) {
+        double acc = 0.0;
+        for (int i = 0; i < m; i++) acc += EL(sA, ai + i, aj + j) * sx->pa[xi + i];
+        sz->pa[zi + j] = beta * sy->pa[yi + j] + alpha * acc;
+    }
+}
+void blasfeo_dsymv_l(int m, int n, double alpha, struct blasfeo_dmat *sA, int ai, int aj, struct blasfeo_dvec *sx, int xi, double beta, struct blasfeo_dvec *sy, int yi, struct blasfeo_dvec *sz, int zi) {
+    for (int i = 0; i < m; i++) {
+        double acc = 0.0;
+        for (int j = 0; j < n; j++) {
+            double a = (i >= j) ? EL(sA, ai + i, aj + j) : EL(sA, ai + j, aj + i);
+            acc += a * sx->pa[xi + j];
+        }
+        sz->pa[zi + i] = beta * sy->pa[yi + i] + alpha * acc;
+    }
+}
+
+/* ---- printing ---- */
+static void print_mat(int m, int n, const double *A, int lda, const char *fmt) {
+    for (int i = 0; i < m; i++) {
+        for (int j = 0; j < n; j++) printf(fmt, A[i + (size_t)j * lda]);
+        printf("\n");
+    }
+    printf("\n");
+}
+void d_print_mat(int m, int n, double *A, int lda) { print_mat(m, n, A, lda, "%9.5f "); }
+void d_print_e_mat(int m, int n, double *A, int lda) { print_mat(m, n, A, lda, "%1.15e\t"); }
+void d_print_exp_mat(int m, int n, double *A, int lda) { print_mat(m, n, A, lda, "%9.5e\t"); }
+void blasfeo_print_dmat(int m, int n, struct blasfeo_dmat *sA, int ai, int aj) {
+    if (m > 0 && n > 0) print_mat(m, n, &EL(sA, ai, aj), sA->m, "%9.5f "); else printf("\n");
+}
+void blasfeo_print_exp_dmat(int m, int n, struct blasfeo_dmat *sA, int ai, int aj) {
+    if (m > 0 && n > 0) print_mat(m, n, &EL(sA, ai, aj), sA->m, "%9.5e\t"); else printf("\n");
+}
+void blasfeo_print_dvec(int m, struct blasfeo_dvec *sa, int ai) { print_mat(m, 1, sa->pa + ai, m > 0 ? m : 1, "%9.5f "); }
+void blasfeo_print_exp_dvec(int m, struct blasfeo_dvec *sa, int ai) { print_mat(m, 1, sa->pa + ai, m > 0 ? m : 1, "%9.5e\t"); }
+void blasfeo_print_tran_dvec(int m, struct blasfeo_dvec *sa, int ai) { print_mat(1, m, sa->pa + ai, 1, "%9.5f "); }
+void blasfeo_print_exp_tran_dvec(int m, struct blasfeo_dvec *sa, int ai) { print_mat(1, m, sa->pa + ai, 1, "%9.5e\t"); }
