@@ -36,6 +36,9 @@ def main():
     sm["lambda0_tree"] = [float(v) for v in (REF / "examples/spring_mass_utils/lambda0_tree.txt").read_text().split()]
     sm["_source"] = "examples/spring_mass_utils/{data.c,x0.txt,lambda0_tree.txt} (numeric data only)"
     (OUT / "spring_mass_data.json").write_text(json.dumps(sm, indent=0))
+    # the two text inputs the unchanged spring-mass driver reads at run time (plain data files)
+    for name in ("x0.txt", "lambda0_tree.txt"):
+        (OUT / name).write_text((REF / "examples/spring_mass_utils" / name).read_text())
     for i in range(6):
         d = json.loads((REF / f"examples/random_qp_utils/data0{i}.json").read_text())
         d["_source"] = f"examples/random_qp_utils/data0{i}.json (reference unit-test fixture incl. golden xopt/uopt)"

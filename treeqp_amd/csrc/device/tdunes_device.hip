@@ -543,6 +543,7 @@ struct tqgpu_solver {
     Tree T{};
     Data D{};
     double *d_mu_x = nullptr, *d_mu_u = nullptr;
+    double *d_lam_init = nullptr;   /* starting point of every solve (tqgpu_set_lambda) */
     /* writable aliases of the const inputs */
     double *A = nullptr, *B = nullptr, *b = nullptr, *Qd = nullptr, *Rd = nullptr, *q = nullptr, *r = nullptr;
     double *xmin = nullptr, *xmax = nullptr, *umin = nullptr, *umax = nullptr;
@@ -683,6 +684,7 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
     const size_t o_W = cv.take(s->sum_W * Dbl), o_CW = cv.take(s->sum_W * Dbl), o_Ut = cv.take(s->sum_Ut * Dbl), o_CUt = cv.take(s->sum_Ut * Dbl);
     const size_t o_fval = cv.take(Nn * Dbl), o_perr = cv.take(Nn * Dbl), o_pdot = cv.take(Nn * Dbl);
     const size_t o_mux = cv.take(SX * Dbl), o_muu = cv.take(SU * Dbl);
+    const size_t o_lami = cv.take(SX * Dbl);
     const size_t o_ctrl = cv.take(sizeof(Ctrl));
     s->ls_log_cap = 4096;
     const size_t o_log = cv.take(s->ls_log_cap * I);
@@ -723,6 +725,7 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
     D.fval = at<double>(base, o_fval); D.part_err = at<double>(base, o_perr); D.part_dot = at<double>(base, o_pdot);
     D.ctrl = at<Ctrl>(base, o_ctrl); D.ls_log = at<int>(base, o_log); D.ls_log_cap = s->ls_log_cap;
     s->d_mu_x = at<double>(base, o_mux); s->d_mu_u = at<double>(base, o_muu);
+    s->d_lam_init = at<double>(base, o_lami);
 
     if ((rc = allow_lds(k_stage, s->lds_stage)) || (rc = allow_lds(k_hess, s->lds_hess)) ||
         (rc = allow_lds(k_factor, s->lds_factor)) || (rc = allow_lds(k_forward, s->lds_forward)))
@@ -790,9 +793,9 @@ extern "C" int tqgpu_set_bounds(tqgpu_solver *s, const double *xmin, const doubl
 extern "C" int tqgpu_set_lambda(tqgpu_solver *s, const double *lambda) {
     if (!s) return fail(TQGPU_EINVAL, "null solver");
     HIP_TRY(hipSetDevice(s->device));
-    /* the current buffer is lam0 at the start of every solve */
-    if (lambda) { H2D(s->D.lam0 + s->nx0, lambda, s->sum_lam); }
-    else HIP_TRY(hipMemsetAsync(s->D.lam0, 0, sizeof(double) * (size_t)s->sum_nx, s->stream));
+    /* kept in a resident buffer: every tqgpu_solve starts from it (device-to-device copy) */
+    if (lambda) { H2D(s->d_lam_init + s->nx0, lambda, s->sum_lam); }
+    else HIP_TRY(hipMemsetAsync(s->d_lam_init, 0, sizeof(double) * (size_t)s->sum_nx, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     return TQGPU_OK;
 }
@@ -836,6 +839,8 @@ extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *r
     s->iter_times.assign((size_t)std::max(o->maxIter, 1), NAN);
 
     HIP_TRY(hipEventRecord(s->ev0, st));
+    /* the current buffer is lam0 at the start of every solve */
+    HIP_TRY(hipMemcpyAsync(D.lam0, s->d_lam_init, sizeof(double) * (size_t)s->sum_nx, hipMemcpyDeviceToDevice, st));
     if (s->need_init) {
         hipLaunchKernelGGL(k_init, dim3((nxu + 255) / 256), dim3(256), 0, st, s->sum_nx, s->sum_nu, D); launches++;
         s->need_init = false;
