@@ -279,8 +279,8 @@ def pruned_chain_qp(Nh: int = 10, seed: int = 7, nm: int = 4, nu: int = 2, n_rea
     xlo = np.concatenate([-3.0 * np.ones(nm), -8.0 * np.ones(nm)])
     xhi = np.concatenate([2.5 * np.ones(nm), 8.0 * np.ones(nm)])
     x0 = np.zeros(nx)
-    x0[0] = 2.0
-    x0[nm - 1] = -2.5
+    x0[0] = 1.5
+    x0[nm - 1] = -1.0
     xmin = np.tile(xlo, Nn)
     xmax = np.tile(xhi, Nn)
     xmin[:nx] = x0
@@ -290,7 +290,7 @@ def pruned_chain_qp(Nh: int = 10, seed: int = 7, nm: int = 4, nu: int = 2, n_rea
         A=np.concatenate(A), B=np.concatenate(B), b=np.zeros((Nn - 1) * nx),
         Qd=np.tile(np.concatenate([10.0 * np.ones(nm), np.ones(nm)]), Nn), Rd=0.1 * np.ones(su),
         q=np.zeros(Nn * nx), r=np.zeros(su), xmin=xmin, xmax=xmax,
-        umin=-1.0 * np.ones(su), umax=1.0 * np.ones(su),
+        umin=-0.4 * np.ones(su), umax=0.4 * np.ones(su),
         opts=dict(maxIter=200, stationarityTolerance=1e-8, lineSearchMaxIter=100, lineSearchGamma=0.1,
                   lineSearchBeta=0.8, regType=1, regValue=1e-10))
 
