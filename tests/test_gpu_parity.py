@@ -239,3 +239,75 @@ def test_dropin_thesis_driver(gpu, tmp_path):
     out, _ = _run_dropin("thesis_example", tmp_path)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "Solver status: 0" in out.stdout and "Number of iterations: 3" in out.stdout
+
+
+# --- fused uniform-tree path (tdunes_fast.hpp) ---------------------------------------------------
+
+FUSED_CASES = [
+    ("chain_8_3_2_h4", lambda: P.linear_chain(2, 4, 4)),
+    ("chain_8_3_2_h6", lambda: P.linear_chain(2, 6, 6)),
+    ("chain_8_3_2_h7_tight", lambda: P.linear_chain(2, 7, 7, ubound=0.2)),
+    ("chain_6_2_2_h5", lambda: P.linear_chain(2, 5, 5, nm=3)),
+    ("spring_4_1_2_h5", lambda: P.spring_mass(md=2, Nr=5, Nh=5)),
+    ("spring_4_1_3_h3", lambda: P.spring_mass(md=3, Nr=3, Nh=3)),
+    ("chain_8_3_2_h6_tighter", lambda: P.linear_chain(2, 6, 6, ubound=0.05)),
+]
+
+
+def _solve_flat_tq(gpu, flat, lambda0, path, **opts):
+    os.environ["TREEQP_AMD_PATH"] = path
+    try:
+        g = gpu.TqGpu(flat["nk"], flat["nx"], flat["nu"]).upload(flat, lambda0)
+    finally:
+        os.environ.pop("TREEQP_AMD_PATH", None)
+    r = g.solve(**opts)
+    sol = g.solution()
+    fused = g.fused
+    g.close()
+    return r, sol, fused
+
+
+@pytest.mark.parametrize("name,make", FUSED_CASES, ids=[c[0] for c in FUSED_CASES])
+def test_fused_path_matches_oracle_and_generic(gpu, orc, name, make):
+    p = make()
+    flat = oracle_flat_from_lti(orc, p)
+    ref = orc.solve(flat, lambda0=p.lambda0)
+    rf, sf, fused = _solve_flat_tq(gpu, flat, p.lambda0, "auto")
+    rg, sg, fused_g = _solve_flat_tq(gpu, flat, p.lambda0, "generic")
+    assert fused and not fused_g
+    assert rf["status"] == rg["status"] == ref["status"] == 0
+    assert rf["iter"] == rg["iter"] == ref["iter"]
+    assert rf["ls_total"] == rg["ls_total"] == ref["ls_total"]
+    assert_solution_close(sf, ref, TOL)
+    assert_solution_close(sg, ref, TOL)
+    assert_solution_close(sf, sg, TOL)
+    assert orc.max_kkt(flat, sf) < 1e-8
+    # far fewer launches: 4 per Newton iteration instead of ~3 + 2*levels + 3
+    assert rf["n_launches"] < rg["n_launches"]
+
+
+@pytest.mark.parametrize("opts", [dict(regType=0), dict(regType=1, regValue=1e-8), dict(termCondition=0),
+                                  dict(termCondition=1), dict(maxIter=2), dict(stationarityTolerance=1e-5)])
+def test_fused_path_options(gpu, orc, opts):
+    p = P.linear_chain(2, 5, 5)
+    flat = oracle_flat_from_lti(orc, p)
+    ref = orc.solve(flat, orc.default_opts(**opts), p.lambda0)
+    rf, sf, fused = _solve_flat_tq(gpu, flat, p.lambda0, "auto", **opts)
+    assert fused
+    assert rf["status"] == ref["status"] and rf["iter"] == ref["iter"]
+    assert_solution_close(sf, ref, 1e-9, keys=("x", "u", "lam"))
+
+
+def test_fused_path_multi_trial_line_search(gpu, orc):
+    """A start far from the solution forces Armijo backtracking: the extra trials run through the
+    generic trial kernels while the iteration itself is fused."""
+    p = P.linear_chain(2, 6, 6, ubound=0.1)
+    flat = oracle_flat_from_lti(orc, p)
+    rng = np.random.Generator(np.random.PCG64(2))
+    lam0 = 10.0 * rng.standard_normal(len(p.lambda0))
+    ref = orc.solve(flat, lambda0=lam0)
+    assert ref["status"] == 0 and ref["ls_total"] > ref["iter"], "fixture should need backtracking"
+    rf, sf, fused = _solve_flat_tq(gpu, flat, lam0, "auto")
+    assert fused and rf["status"] == 0
+    assert rf["iter"] == ref["iter"] and rf["ls_total"] == ref["ls_total"]
+    assert_solution_close(sf, ref, 1e-9)

@@ -406,6 +406,10 @@ class TqGpu:
         L.tqgpu_dims(self.h, *[C.byref(v) for v in d])
         self.sum_nx, self.sum_nu, self.sum_lam, self.sum_A, self.sum_B = [v.value for v in d]
 
+    @property
+    def fused(self) -> bool:
+        return bool(lib().tqgpu_uses_fused_path(self.h))
+
     def _chk(self, rc):
         if rc != 0:
             raise RuntimeError(f"tqgpu call failed ({rc}): {lib().tqgpu_last_error().decode()}")

@@ -85,6 +85,7 @@ struct Data {            /* device pointers, passed by value */
     double *lam0, *lam1, *dlam, *res, *resMod;
     double *W, *CholW, *invd, *Ut, *CholUt;
     double *fval, *part_err, *part_dot;
+    double *Sbuf, *vbuf;     /* fused path: per-block Schur complement hand-off (NX x NX, NX) */
     Ctrl *ctrl;
     int *ls_log;
     int ls_log_cap;
@@ -94,6 +95,13 @@ struct Opts {
     int maxIter, termCondition, regType, lsMaxIter, lsRestartTrigger;
     double tol, regTol, regValue, gamma, beta;
 };
+
+/* Phase guards.  The host enqueues kernels ahead of the device's decisions and tags every launch
+ * with the Newton iteration `h` (and line-search trial `t`) it belongs to; a kernel whose tag does
+ * not match the device state is a no-op.  This keeps the host out of the loop: it only reads the
+ * control block once per enqueued chunk. */
+__device__ __forceinline__ bool phase_main(const Ctrl *c, int h) { return !c->done && c->iter == h && !c->ls_pending; }
+__device__ __forceinline__ bool phase_trial(const Ctrl *c, int h, int t) { return !c->done && c->iter == h && c->ls_pending && c->ls_iter == t; }
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -120,11 +128,10 @@ __global__ void k_init(int n_x, int n_u, Data D) {
 /* mode 1: line-search trial, lam_next = lam_cur + (tau - tauPrev) * dlam, evaluate there.     */
 /* Produces qmod,rmod,x,u,xUnc,uUnc,QinvCal,RinvCal and the node's dual-function term.         */
 /* ------------------------------------------------------------------------------------------ */
-__global__ void __launch_bounds__(WAVE) k_stage(Tree T, Data D, int mode) {
+__global__ void __launch_bounds__(WAVE) k_stage(Tree T, Data D, int mode, int h, int t) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const Ctrl *c = D.ctrl;
-    if (c->done) return;
-    if (mode == 1 && !c->ls_pending) return;
+    if (mode == 1 && !phase_trial(c, h, t)) return;
 
     const int k = blockIdx.x, lane = threadIdx.x;
     const int nxk = T.nx[k], nuk = T.nu[k], xo = T.xoff[k], uo = T.uoff[k];
@@ -225,9 +232,9 @@ __global__ void __launch_bounds__(256) k_fval_init(Tree T, Data D) {
 /* ------------------------------------------------------------------------------------------ */
 /* k_grad: one wave per node k >= 1:  res_k = b_k - x_k + A_k x_dad + B_k u_dad                */
 /* ------------------------------------------------------------------------------------------ */
-__global__ void __launch_bounds__(WAVE) k_grad(Tree T, Data D, int termCondition) {
+__global__ void __launch_bounds__(WAVE) k_grad(Tree T, Data D, int termCondition, int h) {
     const Ctrl *c = D.ctrl;
-    if (c->done || c->ls_pending) return;
+    if (!phase_main(c, h)) return;
     const int k = blockIdx.x + 1, lane = threadIdx.x;
     const int p = T.dad[k], nxk = T.nx[k], nxp = T.nx[p], nup = T.nu[p];
     const int xo = T.xoff[k], xp = T.xoff[p], up = T.uoff[p];
@@ -250,10 +257,10 @@ __global__ void __launch_bounds__(WAVE) k_grad(Tree T, Data D, int termCondition
 }
 
 /* termination test; also the top-of-loop bookkeeping of the Newton iteration */
-__global__ void __launch_bounds__(256) k_check(Tree T, Data D, Opts O) {
+__global__ void __launch_bounds__(256) k_check(Tree T, Data D, Opts O, int h) {
     __shared__ double sh[256];
     Ctrl *c = D.ctrl;
-    if (c->done || c->ls_pending) return;
+    if (!phase_main(c, h)) return;
     double err = (O.termCondition == 2) ? block_reduce<true>(D.part_err + 1, T.Nn - 1, sh)
                                         : block_reduce<false>(D.part_err + 1, T.Nn - 1, sh);
     if (threadIdx.x == 0) {
@@ -268,10 +275,10 @@ __global__ void __launch_bounds__(256) k_check(Tree T, Data D, Opts O) {
 /*   W_p = C P C' + blockdiag(QinvCal_kids),  C = [A_c B_c] stacked over the children,         */
 /*   P = diag(QinvCal_p, RinvCal_p);   Ut_p = -(C[:, :nx_p] P)'                                */
 /* ------------------------------------------------------------------------------------------ */
-__global__ void __launch_bounds__(WAVE) k_hess(Tree T, Data D) {
+__global__ void __launch_bounds__(WAVE) k_hess(Tree T, Data D, int h) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const Ctrl *c = D.ctrl;
-    if (c->done || c->ls_pending) return;
+    if (!phase_main(c, h)) return;
     const int p = blockIdx.x, lane = threadIdx.x;
     const int d = T.bdim[p], nxp = T.nx[p], nup = T.nu[p], nz = nxp + nup;
     double *Cs = lds;                 /* d x nz, column major, ld = d */
@@ -336,10 +343,10 @@ __device__ __forceinline__ void tall_potrf(double *Tm, double *invd, int R, int 
     }
 }
 
-__global__ void __launch_bounds__(WAVE) k_factor(Tree T, Data D, Opts O, int first) {
+__global__ void __launch_bounds__(WAVE) k_factor(Tree T, Data D, Opts O, int first, int h) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     Ctrl *c = D.ctrl;
-    if (c->done || c->ls_pending) return;
+    if (!phase_main(c, h)) return;
     const int ii = first + blockIdx.x, lane = threadIdx.x;
     const int d = T.bdim[ii], nxi = ii > 0 ? T.nx[ii] : 0;
     const int R = d + 1 + nxi, ld = R | 1;
@@ -429,10 +436,10 @@ __global__ void __launch_bounds__(WAVE) k_factor(Tree T, Data D, Opts O, int fir
 /* k_forward: one wave per block of one level:                                                 */
 /*   dlam_ii = L^-T ( y_ii - CholUt_ii' * dlam_dad[pos..] )                                    */
 /* ------------------------------------------------------------------------------------------ */
-__global__ void __launch_bounds__(WAVE) k_forward(Tree T, Data D, int first) {
+__global__ void __launch_bounds__(WAVE) k_forward(Tree T, Data D, int first, int h) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const Ctrl *c = D.ctrl;
-    if (c->done || c->ls_pending) return;
+    if (!phase_main(c, h)) return;
     const int ii = first + blockIdx.x, lane = threadIdx.x;
     const int d = T.bdim[ii], nxi = T.nx[ii], ld = d | 1;
     double *L = lds;                      /* ld x d */
@@ -473,10 +480,10 @@ __global__ void __launch_bounds__(WAVE) k_forward(Tree T, Data D, int first) {
 /* ------------------------------------------------------------------------------------------ */
 /* line-search control (line_search, dual_Newton_tree.c:922-1019)                              */
 /* ------------------------------------------------------------------------------------------ */
-__global__ void __launch_bounds__(256) k_ls_begin(Tree T, Data D) {
+__global__ void __launch_bounds__(256) k_ls_begin(Tree T, Data D, int h) {
     __shared__ double sh[256];
     Ctrl *c = D.ctrl;
-    if (c->done || c->ls_pending) return;
+    if (!phase_main(c, h)) return;
     const double s = block_reduce<false>(D.part_dot, T.Np, sh);
     if (threadIdx.x == 0) {
         const double dotp = -s;                                     /* :819 */
@@ -489,10 +496,23 @@ __global__ void __launch_bounds__(256) k_ls_begin(Tree T, Data D) {
     }
 }
 
-__global__ void __launch_bounds__(256) k_ls_decide(Tree T, Data D, Opts O) {
+__global__ void __launch_bounds__(256) k_ls_decide(Tree T, Data D, Opts O, int h, int t, int with_descent_check) {
     __shared__ double sh[256];
+    __shared__ int bail;
     Ctrl *c = D.ctrl;
-    if (c->done || !c->ls_pending) return;
+    if (!phase_trial(c, h, t)) return;
+    if (with_descent_check) {
+        /* fused path: the first trial was evaluated speculatively; test the direction now (:944-954) */
+        const double s = block_reduce<false>(D.part_dot, T.Np, sh);
+        if (threadIdx.x == 0) {
+            const double dotp = -s;
+            c->dot = dotp;
+            bail = (dotp > 1e-10 || !((dotp > 1e-10) || (dotp < 1e-10)));
+            if (bail) { c->done = 1; c->status = 2; c->ls_pending = 0; }
+        }
+        __syncthreads();
+        if (bail) return;
+    }
     const double f = block_reduce<false>(D.fval, T.Nn, sh);
     if (threadIdx.x == 0) {
         c->cur ^= 1;                       /* the trial point is now the current point */
@@ -518,6 +538,8 @@ __global__ void __launch_bounds__(256) k_ls_decide(Tree T, Data D, Opts O) {
         }
     }
 }
+
+#include "tdunes_fast.hpp"
 
 /* export_mu (clipping.c:386-399): mu = Q .* (xUnc - x) */
 __global__ void k_export_mu(int n_x, int n_u, Data D, double *mu_x, double *mu_u) {
@@ -556,6 +578,12 @@ struct tqgpu_solver {
     std::vector<double> iter_times;
     int last_iter = 0;
     bool need_init = true;
+    /* fused path for uniform complete trees */
+    int fast = -1;            /* index into the instantiation table, -1: generic path only */
+    int fNX = 0, fNU = 0, fMD = 0, lcut = 0, nsub = 0;
+    size_t lds_fast = 0;
+    int use_fast = 1;         /* can be switched off (TREEQP_AMD_PATH=generic) */
+    int chunk = 4;            /* Newton iterations enqueued per status read-back */
 };
 
 extern "C" const char *tqgpu_last_error(void) { return g_err.c_str(); }
@@ -647,6 +675,83 @@ int allow_lds(K kernel, size_t bytes) {
     return TQGPU_OK;
 }
 
+
+/* (NX, NU, MD) instantiations of the fused path */
+#define FAST_TABLE(X) X(0, 8, 3, 2) X(1, 4, 1, 2) X(2, 4, 1, 3) X(3, 2, 1, 2) X(4, 8, 2, 2) X(5, 6, 2, 2)
+
+int fast_index(int NX, int NU, int MD) {
+#define X(idx, nx, nu, md) if (NX == nx && NU == nu && MD == md) return idx;
+    FAST_TABLE(X)
+#undef X
+    return -1;
+}
+
+size_t fast_wave_lds(int idx) {
+#define X(i, nx, nu, md) if (idx == i) return Uni<nx, nu, md>::WAVE_LDS * sizeof(double);
+    FAST_TABLE(X)
+#undef X
+    return 0;
+}
+
+/* uniform complete tree? (every node nx, every parent nu + md children, one leaf depth) */
+void detect_fast(tqgpu_solver *s) {
+    s->fast = -1;
+    const int Nn = s->Nn, NX = s->nx[0], NU = s->nu[0], MD = s->nk[0];
+    if (s->Nh < 2 || MD < 2) return;
+    for (int k = 0; k < Nn; k++) {
+        if (s->nx[k] != NX) return;
+        if (k < s->Np) { if (s->nu[k] != NU || s->nk[k] != MD) return; }
+        else if (s->nu[k] != 0) return;
+    }
+    const int idx = fast_index(NX, NU, MD);
+    if (idx < 0) return;
+    s->fast = idx; s->fNX = NX; s->fNU = NU; s->fMD = MD;
+    /* cut level: the widest level handled by the single top workgroup has <= FAST_WAVES blocks */
+    int lcut = 1, w = 1;
+    while (lcut < s->Nh - 1 && w * MD <= FAST_WAVES) { w *= MD; lcut++; }
+    s->lcut = lcut;
+    int nsub = 1;
+    for (int l = 0; l < lcut; l++) nsub *= MD;
+    s->nsub = nsub;
+    s->lds_fast = FAST_WAVES * fast_wave_lds(idx);
+}
+
+void launch_fast_iteration(tqgpu_solver *s, const Opts &O, int h, int &launches) {
+    const Tree &T = s->T; const Data &D = s->D; hipStream_t st = s->stream;
+    const dim3 blk(FAST_WAVES * WAVE);
+    switch (s->fast) {
+#define X(idx, nx, nu, md)                                                                              \
+    case idx:                                                                                           \
+        hipLaunchKernelGGL((f_up<nx, nu, md>), dim3(s->nsub), blk, s->lds_fast, st, T, D, O, s->lcut, h); \
+        hipLaunchKernelGGL((f_top<nx, nu, md>), dim3(1), blk, s->lds_fast, st, T, D, O, s->lcut, h);      \
+        hipLaunchKernelGGL((f_down<nx, nu, md>), dim3(s->nsub), blk, s->lds_fast, st, T, D, s->lcut, h);  \
+        break;
+        FAST_TABLE(X)
+#undef X
+        default: break;
+    }
+    hipLaunchKernelGGL(k_ls_decide, dim3(1), dim3(256), 0, st, T, D, O, h, 1, 1);
+    launches += 4;
+}
+
+void launch_generic_iteration(tqgpu_solver *s, const Opts &O, int h, int &launches) {
+    const Tree &T = s->T; const Data &D = s->D; hipStream_t st = s->stream;
+    hipLaunchKernelGGL(k_grad, dim3(T.Nn - 1), dim3(WAVE), 0, st, T, D, O.termCondition, h); launches++;
+    hipLaunchKernelGGL(k_check, dim3(1), dim3(256), 0, st, T, D, O, h); launches++;
+    hipLaunchKernelGGL(k_hess, dim3(T.Np), dim3(WAVE), s->lds_hess, st, T, D, h); launches++;
+    for (int lvl = T.Nh - 1; lvl >= 0; lvl--) {
+        const int first = s->lvl_first[lvl], count = s->lvl_first[lvl + 1] - first;
+        hipLaunchKernelGGL(k_factor, dim3(count), dim3(WAVE), s->lds_factor, st, T, D, O, first, h); launches++;
+    }
+    for (int lvl = 1; lvl < T.Nh; lvl++) {
+        const int first = s->lvl_first[lvl], count = s->lvl_first[lvl + 1] - first;
+        hipLaunchKernelGGL(k_forward, dim3(count), dim3(WAVE), s->lds_forward, st, T, D, first, h); launches++;
+    }
+    hipLaunchKernelGGL(k_ls_begin, dim3(1), dim3(256), 0, st, T, D, h); launches++;
+    hipLaunchKernelGGL(k_stage, dim3(T.Nn), dim3(WAVE), s->lds_stage, st, T, D, 1, h, 1); launches++;
+    hipLaunchKernelGGL(k_ls_decide, dim3(1), dim3(256), 0, st, T, D, O, h, 1, 0); launches++;
+}
+
 }  // namespace
 
 extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *nk, const int *nx, const int *nu) {
@@ -665,6 +770,13 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
     s->nk.assign(nk, nk + Nn); s->nx.assign(nx, nx + Nn); s->nu.assign(nu, nu + Nn);
     int rc = build_tables(s);
     if (rc != TQGPU_OK) { delete s; return rc; }
+    detect_fast(s);
+    {
+        const char *env = getenv("TREEQP_AMD_PATH");
+        if (env && strcmp(env, "generic") == 0) s->use_fast = 0;
+        const char *ch = getenv("TREEQP_AMD_CHUNK");
+        if (ch && atoi(ch) > 0) s->chunk = atoi(ch);
+    }
 
     /* one slab for everything */
     Carver cv;
@@ -682,7 +794,9 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
     const size_t o_lam0 = cv.take(SX * Dbl), o_lam1 = cv.take(SX * Dbl), o_dlam = cv.take(SX * Dbl), o_res = cv.take(SX * Dbl), o_resMod = cv.take(SX * Dbl);
     const size_t o_invd = cv.take(SX * Dbl);
     const size_t o_W = cv.take(s->sum_W * Dbl), o_CW = cv.take(s->sum_W * Dbl), o_Ut = cv.take(s->sum_Ut * Dbl), o_CUt = cv.take(s->sum_Ut * Dbl);
-    const size_t o_fval = cv.take(Nn * Dbl), o_perr = cv.take(Nn * Dbl), o_pdot = cv.take(Nn * Dbl);
+    const size_t o_fval = cv.take(Nn * Dbl), o_perr = cv.take((SX + Nn + 1) * Dbl), o_pdot = cv.take(Nn * Dbl);
+    const size_t maxnx = (size_t)*std::max_element(s->nx.begin(), s->nx.end());
+    const size_t o_sbuf = cv.take((s->fast >= 0 ? (size_t)Nn * maxnx * maxnx : 1) * Dbl), o_vbuf = cv.take((SX + 1) * Dbl);
     const size_t o_mux = cv.take(SX * Dbl), o_muu = cv.take(SU * Dbl);
     const size_t o_lami = cv.take(SX * Dbl);
     const size_t o_ctrl = cv.take(sizeof(Ctrl));
@@ -723,6 +837,7 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
     D.res = at<double>(base, o_res); D.resMod = at<double>(base, o_resMod); D.invd = at<double>(base, o_invd);
     D.W = at<double>(base, o_W); D.CholW = at<double>(base, o_CW); D.Ut = at<double>(base, o_Ut); D.CholUt = at<double>(base, o_CUt);
     D.fval = at<double>(base, o_fval); D.part_err = at<double>(base, o_perr); D.part_dot = at<double>(base, o_pdot);
+    D.Sbuf = at<double>(base, o_sbuf); D.vbuf = at<double>(base, o_vbuf);
     D.ctrl = at<Ctrl>(base, o_ctrl); D.ls_log = at<int>(base, o_log); D.ls_log_cap = s->ls_log_cap;
     s->d_mu_x = at<double>(base, o_mux); s->d_mu_u = at<double>(base, o_muu);
     s->d_lam_init = at<double>(base, o_lami);
@@ -730,6 +845,10 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
     if ((rc = allow_lds(k_stage, s->lds_stage)) || (rc = allow_lds(k_hess, s->lds_hess)) ||
         (rc = allow_lds(k_factor, s->lds_factor)) || (rc = allow_lds(k_forward, s->lds_forward)))
         return cleanup_fail(rc);
+    if (s->fast >= 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess || prop.maxThreadsPerBlock < FAST_WAVES * WAVE) s->fast = -1;
+    }
     *out = s;
     return TQGPU_OK;
 }
@@ -747,6 +866,8 @@ extern "C" void tqgpu_destroy(tqgpu_solver *s) {
     if (s->slab) (void)hipFree(s->slab);
     delete s;
 }
+
+extern "C" int tqgpu_uses_fused_path(const tqgpu_solver *s) { return s && s->fast >= 0 && s->use_fast ? 1 : 0; }
 
 extern "C" int tqgpu_dims(const tqgpu_solver *s, int *sum_nx, int *sum_nu, int *sum_lam, int *sum_A, int *sum_B) {
     if (!s) return fail(TQGPU_EINVAL, "null solver");
@@ -846,40 +967,42 @@ extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *r
         s->need_init = false;
     }
     /* first sweep at lambda0 (phase S of iteration 0 + fval0) */
-    hipLaunchKernelGGL(k_stage, dim3(T.Nn), dim3(WAVE), s->lds_stage, st, T, D, 0); launches++;
+    hipLaunchKernelGGL(k_stage, dim3(T.Nn), dim3(WAVE), s->lds_stage, st, T, D, 0, 0, 0); launches++;
     hipLaunchKernelGGL(k_fval_init, dim3(1), dim3(256), 0, st, T, D); launches++;
 
-    int host_iter = 0;
+    /* Newton loop (dual_Newton_tree.c:1166-1228).  The device decides (termination, Armijo);
+     * the host enqueues `chunk` tagged iterations ahead and reads the control block once per chunk.
+     * Iterations enqueued beyond convergence, or while a line search still needs trials, are
+     * no-ops by their phase guards. */
+    const bool fast = s->fast >= 0 && s->use_fast;
+    int h = 0, ev_idx = 0;
     bool finished = o->maxIter <= 0;       /* nothing to iterate: reported as "maximum iterations" */
     if (finished) { HIP_TRY(hipStreamSynchronize(st)); memset(s->h_ctrl, 0, sizeof(Ctrl)); s->h_ctrl->status = 1; }
     if (o->profile) HIP_TRY(hipEventRecord(s->iter_ev[0], st));
+    int chunk = s->last_iter > 0 ? std::min(s->last_iter + 1, 16) : s->chunk;
     while (!finished) {
-        /* ---- one Newton iteration (dual_Newton_tree.c:1166-1228) ---- */
-        hipLaunchKernelGGL(k_grad, dim3(T.Nn - 1), dim3(WAVE), 0, st, T, D, O.termCondition); launches++;
-        hipLaunchKernelGGL(k_check, dim3(1), dim3(256), 0, st, T, D, O); launches++;
-        hipLaunchKernelGGL(k_hess, dim3(T.Np), dim3(WAVE), s->lds_hess, st, T, D); launches++;
-        for (int lvl = T.Nh - 1; lvl >= 0; lvl--) {
-            const int first = s->lvl_first[lvl], count = s->lvl_first[lvl + 1] - first;
-            hipLaunchKernelGGL(k_factor, dim3(count), dim3(WAVE), s->lds_factor, st, T, D, O, first); launches++;
+        const int n = std::min(chunk, o->maxIter - h);
+        for (int i = 0; i < n; i++) {
+            if (fast) launch_fast_iteration(s, O, h + i, launches);
+            else launch_generic_iteration(s, O, h + i, launches);
+            if (o->profile && ev_idx + 1 < (int)s->iter_ev.size()) HIP_TRY(hipEventRecord(s->iter_ev[++ev_idx], st));
         }
-        for (int lvl = 1; lvl < T.Nh; lvl++) {
-            const int first = s->lvl_first[lvl], count = s->lvl_first[lvl + 1] - first;
-            hipLaunchKernelGGL(k_forward, dim3(count), dim3(WAVE), s->lds_forward, st, T, D, first); launches++;
-        }
-        hipLaunchKernelGGL(k_ls_begin, dim3(1), dim3(256), 0, st, T, D); launches++;
-        hipLaunchKernelGGL(k_stage, dim3(T.Nn), dim3(WAVE), s->lds_stage, st, T, D, 1); launches++;
-        hipLaunchKernelGGL(k_ls_decide, dim3(1), dim3(256), 0, st, T, D, O); launches++;
         int rc = read_ctrl(s);
         if (rc != TQGPU_OK) return rc;
         while (!s->h_ctrl->done && s->h_ctrl->ls_pending) {
-            hipLaunchKernelGGL(k_stage, dim3(T.Nn), dim3(WAVE), s->lds_stage, st, T, D, 1); launches++;
-            hipLaunchKernelGGL(k_ls_decide, dim3(1), dim3(256), 0, st, T, D, O); launches++;
+            /* the line search of iteration `iter` wants more trials (rare): a batch of them */
+            const int it = s->h_ctrl->iter, t0 = s->h_ctrl->ls_iter;
+            for (int t = t0; t < t0 + 8 && t <= O.lsMaxIter; t++) {
+                hipLaunchKernelGGL(k_stage, dim3(T.Nn), dim3(WAVE), s->lds_stage, st, T, D, 1, it, t); launches++;
+                hipLaunchKernelGGL(k_ls_decide, dim3(1), dim3(256), 0, st, T, D, O, it, t, 0); launches++;
+            }
             if ((rc = read_ctrl(s)) != TQGPU_OK) return rc;
         }
-        host_iter++;
-        if (o->profile && host_iter < (int)s->iter_ev.size()) HIP_TRY(hipEventRecord(s->iter_ev[host_iter], st));
+        h = s->h_ctrl->iter;
         finished = s->h_ctrl->done != 0;
+        chunk = s->chunk;
     }
+    const int host_iter = ev_idx;
     HIP_TRY(hipEventRecord(s->ev1, st));
     HIP_TRY(hipMemcpyAsync(s->h_ls_log, D.ls_log, sizeof(int) * (size_t)s->ls_log_cap, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
