@@ -1,0 +1,184 @@
+// Microbenchmark: single-wave tall Cholesky (25 x 16, f64) variants, cycles per factorization.
+// Build: hipcc --offload-arch=gfx950 -O3 -o potrf_bench potrf_bench.hip ; run on the GPU box.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <cmath>
+
+#define D 16
+#define R 25
+
+__device__ __forceinline__ double rdlane(double v, int lane) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double pivot_rsqrt(double p) {
+    double y = __builtin_amdgcn_rsq(p);
+    double e = fma(-(p * y), y, 1.0);
+    y = fma(0.5 * y, e, y);
+    e = fma(-(p * y), y, 1.0);
+    y = fma(0.5 * y, e, y);
+    return p > 0.0 ? y : 0.0;
+}
+
+// V1: right-looking, readlane broadcasts
+__device__ __forceinline__ void potrf_v1(double (&T)[D], int lane) {
+#pragma unroll
+    for (int j = 0; j < D; j++) {
+        const double pj = rdlane(T[j], j);
+        const double finv = pivot_rsqrt(pj);
+        T[j] *= finv;
+#pragma unroll
+        for (int c = j + 1; c < D; c++) { const double lc = rdlane(T[j], c); T[c] = fma(-T[j], lc, T[c]); }
+    }
+}
+
+// V2: right-looking, column all-gather through LDS (1 write + 8 b128 reads per column)
+__device__ __forceinline__ void potrf_v2(double (&T)[D], int lane, double *lds) {
+#pragma unroll
+    for (int j = 0; j < D; j++) {
+        if (lane < D) lds[lane] = T[j];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const double pj = lds[j];
+        const double finv = pivot_rsqrt(pj);
+        T[j] *= finv;
+#pragma unroll
+        for (int c = j + 1; c < D; c++) { const double lc = lds[c] * finv; T[c] = fma(-T[j], lc, T[c]); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+// V3: left-looking with row broadcast through LDS: L kept in LDS row-major (stride 17)
+__device__ __forceinline__ void potrf_v3(double (&T)[D], int lane, double *lds) {
+#pragma unroll
+    for (int j = 0; j < D; j++) {
+        double s = T[j];
+#pragma unroll
+        for (int k = 0; k < j; k++) s = fma(-T[k], lds[j * 17 + k], s);     // row j of L (broadcast read)
+        // pivot = s of lane j
+        if (lane == j) lds[16 * 17 + 0] = s;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const double pj = lds[16 * 17 + 0];
+        const double finv = pivot_rsqrt(pj);
+        s *= finv;
+        T[j] = s;
+        if (lane < D) lds[lane * 17 + j] = s;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+// V4: left-looking, row broadcast by readlane (j readlanes per column, issued up front)
+__device__ __forceinline__ void potrf_v4(double (&T)[D], int lane) {
+#pragma unroll
+    for (int j = 0; j < D; j++) {
+        double s = T[j];
+#pragma unroll
+        for (int k = 0; k < j; k++) s = fma(-T[k], rdlane(T[k], j), s);
+        const double pj = rdlane(s, j);
+        const double finv = pivot_rsqrt(pj);
+        T[j] = s * finv;
+    }
+}
+
+// V5: right-looking with ds_bpermute broadcast (__shfl)
+__device__ __forceinline__ void potrf_v5(double (&T)[D], int lane) {
+#pragma unroll
+    for (int j = 0; j < D; j++) {
+        const double pj = __shfl(T[j], j, 64);
+        const double finv = pivot_rsqrt(pj);
+        T[j] *= finv;
+#pragma unroll
+        for (int c = j + 1; c < D; c++) { const double lc = __shfl(T[j], c, 64); T[c] = fma(-T[j], lc, T[c]); }
+    }
+}
+
+template <int V>
+__global__ void bench(const double *in, double *out, long long *cycles, int reps) {
+    __shared__ double lds[17 * 17 + 8];
+    const int lane = threadIdx.x;
+    double T0[D], T[D];
+#pragma unroll
+    for (int j = 0; j < D; j++) T0[j] = in[(lane < R ? lane : 0) * D + j];
+    double acc = 0.0;
+    long long t0 = clock64();
+    for (int r = 0; r < reps; r++) {
+#pragma unroll
+        for (int j = 0; j < D; j++) T[j] = T0[j] + acc * 1e-300;
+        if (V == 1) potrf_v1(T, lane);
+        if (V == 2) potrf_v2(T, lane, lds);
+        if (V == 3) potrf_v3(T, lane, lds);
+        if (V == 4) potrf_v4(T, lane);
+        if (V == 5) potrf_v5(T, lane);
+#pragma unroll
+        for (int j = 0; j < D; j++) acc += T[j];
+    }
+    long long t1 = clock64();
+#pragma unroll
+    for (int j = 0; j < D; j++) out[lane * D + j] = T[j];
+    if (lane == 0) { cycles[0] = (t1 - t0) / reps; }
+    if (acc == 12345.678) out[0] = acc;
+}
+
+// pure latency probes
+__global__ void probe(double *out, long long *cycles) {
+    const int lane = threadIdx.x;
+    double x = 1.0 + lane * 1e-3, y = 0.5;
+    long long t0 = clock64();
+#pragma unroll
+    for (int i = 0; i < 256; i++) x = fma(x, y, 1.0);          // dependent DP FMA chain
+    long long t1 = clock64();
+    double z = x;
+#pragma unroll
+    for (int i = 0; i < 256; i++) { z = fma(z, rdlane(z, i & 15), 1.0); }   // readlane + dependent FMA
+    long long t2 = clock64();
+    double w = z;
+#pragma unroll
+    for (int i = 0; i < 256; i++) { w = fma(w, __shfl(w, i & 15, 64), 1.0); }   // bpermute + dependent FMA
+    long long t3 = clock64();
+    double a0 = w, a1 = w + 1, a2 = w + 2, a3 = w + 3;
+#pragma unroll
+    for (int i = 0; i < 64; i++) { a0 = fma(a0, y, 1.0); a1 = fma(a1, y, 1.0); a2 = fma(a2, y, 1.0); a3 = fma(a3, y, 1.0); }  // 4 independent chains
+    long long t4 = clock64();
+    double r = a0 + a1 + a2 + a3;
+#pragma unroll
+    for (int i = 0; i < 64; i++) r = pivot_rsqrt(r + 2.0);
+    long long t5 = clock64();
+    out[lane] = r;
+    if (lane == 0) { cycles[0] = (t1 - t0) / 256; cycles[1] = (t2 - t1) / 256; cycles[2] = (t3 - t2) / 256; cycles[3] = (t4 - t3) / 256; cycles[4] = (t5 - t4) / 64; }
+}
+
+int main() {
+    std::vector<double> h(R * D, 0.0);
+    // SPD 16x16 + extra rows
+    for (int i = 0; i < D; i++) for (int j = 0; j < D; j++) h[i * D + j] = (i == j ? 20.0 : 0.0) + 1.0 / (1.0 + abs(i - j));
+    for (int i = D; i < R; i++) for (int j = 0; j < D; j++) h[i * D + j] = 0.1 * ((i * 7 + j * 3) % 11);
+    double *din, *dout; long long *dc;
+    hipMalloc(&din, sizeof(double) * R * D); hipMalloc(&dout, sizeof(double) * 64 * D); hipMalloc(&dc, 64);
+    hipMemcpy(din, h.data(), sizeof(double) * R * D, hipMemcpyHostToDevice);
+    long long c[8];
+    std::vector<double> ref(64 * D), got(64 * D);
+    for (int v = 1; v <= 5; v++) {
+        for (int it = 0; it < 2; it++) {
+            switch (v) {
+                case 1: hipLaunchKernelGGL(bench<1>, dim3(1), dim3(64), 0, 0, din, dout, dc, 200); break;
+                case 2: hipLaunchKernelGGL(bench<2>, dim3(1), dim3(64), 0, 0, din, dout, dc, 200); break;
+                case 3: hipLaunchKernelGGL(bench<3>, dim3(1), dim3(64), 0, 0, din, dout, dc, 200); break;
+                case 4: hipLaunchKernelGGL(bench<4>, dim3(1), dim3(64), 0, 0, din, dout, dc, 200); break;
+                case 5: hipLaunchKernelGGL(bench<5>, dim3(1), dim3(64), 0, 0, din, dout, dc, 200); break;
+            }
+            hipDeviceSynchronize();
+        }
+        hipMemcpy(c, dc, 8, hipMemcpyDeviceToHost);
+        hipMemcpy(got.data(), dout, sizeof(double) * 64 * D, hipMemcpyDeviceToHost);
+        if (v == 1) ref = got;
+        double err = 0;
+        for (int i = 0; i < R; i++) for (int j = 0; j <= (i < D ? i : D - 1); j++) err = fmax(err, fabs(got[i * D + j] - ref[i * D + j]));
+        printf("variant %d: %lld cycles per 25x16 tall potrf   (max diff vs v1 %.2e)\n", v, c[0], err);
+    }
+    hipLaunchKernelGGL(probe, dim3(1), dim3(64), 0, 0, dout, dc); hipDeviceSynchronize();
+    hipLaunchKernelGGL(probe, dim3(1), dim3(64), 0, 0, dout, dc); hipDeviceSynchronize();
+    hipMemcpy(c, dc, 40, hipMemcpyDeviceToHost);
+    printf("dependent DP fma: %lld cyc | readlane+fma: %lld | bpermute+fma: %lld | 4 indep fma chains (per fma): %lld | pivot_rsqrt chain: %lld\n", c[0], c[1], c[2], c[3], c[4]);
+    return 0;
+}

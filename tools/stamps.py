@@ -1,0 +1,38 @@
+"""Diagnostic: in-kernel phase stamps of the fused kernels (workgroup 0) on the GPU box.
+Usage: TREEQP_AMD_STAMPS=1 python tools/stamps.py [Nr]"""
+import ctypes as C
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+os.environ["TREEQP_AMD_STAMPS"] = "1"
+from treeqp_amd import capi, problems as P
+
+Nr = int(sys.argv[1]) if len(sys.argv) > 1 else 9
+p = P.linear_chain(2, Nr, Nr)
+nk = p.nk()
+nx = np.full(p.Nn, p.nx, dtype=np.int32)
+nu = np.where(nk > 0, p.nu, 0).astype(np.int32)
+qp = capi.TreeQp(nx, nu, nk).fill_lti(p)
+g = capi.TqGpu(nk, nx, nu).upload(qp.flat(), p.lambda0)
+for _ in range(5):
+    r = g.solve(maxIter=1)          # one real iteration so that the stamps belong to a full iteration
+print(r)
+buf = np.zeros(3 * 64 * 2, dtype=np.uint64)
+capi.lib().tqgpu_get_stamps(g.h, buf.ctypes.data_as(C.POINTER(C.c_ulonglong)), len(buf))
+st = buf.reshape(3, 64, 2).astype(np.int64)
+for kern, name in enumerate(("f_up", "f_top", "f_down")):
+    s = st[kern]
+    n = int((s[:, 1] > 0).sum())
+    if n < 2:
+        continue
+    cyc = np.diff(s[:n, 0])
+    wall = np.diff(s[:n, 1]) * 10.0          # 100 MHz -> ns
+    print(name, "phases:", n - 1)
+    for i in range(n - 1):
+        print(f"   {i:2d}: {wall[i] / 1e3:8.2f} us  {cyc[i]:8d} cycles  ({cyc[i] / max(wall[i], 1):.2f} GHz)")
+    print(f"   total {wall.sum() / 1e3:.2f} us")

@@ -86,13 +86,14 @@ struct Data {            /* device pointers, passed by value */
     double *W, *CholW, *invd, *Ut, *CholUt;
     double *fval, *part_err, *part_dot;
     double *Sbuf, *vbuf;     /* fused path: per-block Schur complement hand-off (NX x NX, NX) */
+    unsigned long long *stamps;   /* diagnostic time stamps (written only when Opts.stamps != 0; never read by kernels) */
     Ctrl *ctrl;
     int *ls_log;
     int ls_log_cap;
 };
 
 struct Opts {
-    int maxIter, termCondition, regType, lsMaxIter, lsRestartTrigger;
+    int maxIter, termCondition, regType, lsMaxIter, lsRestartTrigger, stamps;
     double tol, regTol, regValue, gamma, beta;
 };
 
@@ -724,7 +725,7 @@ void launch_fast_iteration(tqgpu_solver *s, const Opts &O, int h, int &launches)
     case idx:                                                                                           \
         hipLaunchKernelGGL((f_up<nx, nu, md>), dim3(s->nsub), blk, s->lds_fast, st, T, D, O, s->lcut, h); \
         hipLaunchKernelGGL((f_top<nx, nu, md>), dim3(1), blk, s->lds_fast, st, T, D, O, s->lcut, h);      \
-        hipLaunchKernelGGL((f_down<nx, nu, md>), dim3(s->nsub), blk, s->lds_fast, st, T, D, s->lcut, h);  \
+        hipLaunchKernelGGL((f_down<nx, nu, md>), dim3(s->nsub), blk, s->lds_fast, st, T, D, O, s->lcut, h);  \
         break;
         FAST_TABLE(X)
 #undef X
@@ -800,6 +801,7 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
     const size_t o_mux = cv.take(SX * Dbl), o_muu = cv.take(SU * Dbl);
     const size_t o_lami = cv.take(SX * Dbl);
     const size_t o_ctrl = cv.take(sizeof(Ctrl));
+    const size_t o_stamps = cv.take(3 * 64 * 2 * sizeof(unsigned long long));
     s->ls_log_cap = 4096;
     const size_t o_log = cv.take(s->ls_log_cap * I);
     s->slab_bytes = cv.off + 256;
@@ -838,6 +840,7 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
     D.W = at<double>(base, o_W); D.CholW = at<double>(base, o_CW); D.Ut = at<double>(base, o_Ut); D.CholUt = at<double>(base, o_CUt);
     D.fval = at<double>(base, o_fval); D.part_err = at<double>(base, o_perr); D.part_dot = at<double>(base, o_pdot);
     D.Sbuf = at<double>(base, o_sbuf); D.vbuf = at<double>(base, o_vbuf);
+    D.stamps = at<unsigned long long>(base, o_stamps);
     D.ctrl = at<Ctrl>(base, o_ctrl); D.ls_log = at<int>(base, o_log); D.ls_log_cap = s->ls_log_cap;
     s->d_mu_x = at<double>(base, o_mux); s->d_mu_u = at<double>(base, o_muu);
     s->d_lam_init = at<double>(base, o_lami);
@@ -868,6 +871,15 @@ extern "C" void tqgpu_destroy(tqgpu_solver *s) {
 }
 
 extern "C" int tqgpu_uses_fused_path(const tqgpu_solver *s) { return s && s->fast >= 0 && s->use_fast ? 1 : 0; }
+
+/* diagnostic: copy the in-kernel time stamps of the last fused iteration (3 kernels x 64 slots x
+ * {shader clock, 100 MHz wall clock}); only filled when TREEQP_AMD_STAMPS is set */
+extern "C" int tqgpu_get_stamps(tqgpu_solver *s, unsigned long long *out, int cap) {
+    if (!s || !out) return fail(TQGPU_EINVAL, "bad arguments");
+    const int n = std::min(cap, 3 * 64 * 2);
+    HIP_TRY(hipMemcpy(out, s->D.stamps, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToHost));
+    return TQGPU_OK;
+}
 
 extern "C" int tqgpu_dims(const tqgpu_solver *s, int *sum_nx, int *sum_nu, int *sum_lam, int *sum_A, int *sum_B) {
     if (!s) return fail(TQGPU_EINVAL, "null solver");
@@ -940,6 +952,7 @@ extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *r
     O.lsMaxIter = o->lineSearchMaxIter; O.lsRestartTrigger = o->lineSearchRestartTrigger;
     O.tol = o->stationarityTolerance; O.regTol = o->regTol; O.regValue = o->regValue;
     O.gamma = o->lineSearchGamma; O.beta = o->lineSearchBeta;
+    O.stamps = getenv("TREEQP_AMD_STAMPS") ? 1 : 0;
     if (O.termCondition < 0 || O.termCondition > 2 || O.regType < 0 || O.regType > 2 || O.regValue < 0)
         return fail(TQGPU_EINVAL, "invalid option value");
 

@@ -72,6 +72,14 @@ __device__ __forceinline__ double pivot_rsqrt(double p) {
     return p > 0.0 ? y : 0.0;
 }
 
+/* diagnostic stamp: slot of kernel `kern` (0 f_up, 1 f_top, 2 f_down), workgroup 0 / thread 0 only */
+__device__ __forceinline__ void stamp(const Data &Dt, const Opts &O, int kern, int slot) {
+    if (O.stamps && threadIdx.x == 0 && blockIdx.x == 0 && slot < 64) {
+        Dt.stamps[(kern * 64 + slot) * 2 + 0] = clock64();
+        Dt.stamps[(kern * 64 + slot) * 2 + 1] = wall_clock64();
+    }
+}
+
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -361,6 +369,8 @@ __global__ void __launch_bounds__(FAST_WAVES * WAVE) f_up(Tree T, Data Dt, Opts 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     double *lds = lds_all + wave * U::WAVE_LDS;
     const int s = blockIdx.x, Nh = T.Nh, depth = Nh - lcut;       /* block levels lcut .. Nh-1 */
+    int sl = 0;
+    stamp(Dt, O, 0, sl++);
     for (int t = 0; t < depth; t++) {
         const int nb = U::width(t), f0 = U::first(lcut + t) + s * nb;
         for (int b = wave; b < nb; b += FAST_WAVES) fast_gh<NX, NU, MD>(Dt, f0 + b, lane, O.termCondition);
@@ -368,10 +378,12 @@ __global__ void __launch_bounds__(FAST_WAVES * WAVE) f_up(Tree T, Data Dt, Opts 
     const int ntop = U::first(lcut);
     for (int p = s * FAST_WAVES + wave; p < ntop; p += gridDim.x * FAST_WAVES) fast_gh<NX, NU, MD>(Dt, p, lane, O.termCondition);
     __syncthreads();
+    stamp(Dt, O, 0, sl++);
     for (int t = depth - 1; t >= 0; t--) {
         const int nb = U::width(t), f0 = U::first(lcut + t) + s * nb;
         for (int b = wave; b < nb; b += FAST_WAVES) fast_factor<NX, NU, MD>(Dt, O, f0 + b, T.Np, lane, lds, false);
         __syncthreads();
+        stamp(Dt, O, 0, sl++);
     }
 }
 
@@ -387,6 +399,8 @@ __global__ void __launch_bounds__(FAST_WAVES * WAVE) f_top(Tree T, Data Dt, Opts
     if (!phase_main(c, h)) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     double *lds = lds_all + wave * U::WAVE_LDS;
+    int sl = 0;
+    stamp(Dt, O, 1, sl++);
     /* termination test (calculate_error_in_residuals + :542-546) */
     {
         const int n0 = NX, n1 = NX * T.Nn;
@@ -401,17 +415,21 @@ __global__ void __launch_bounds__(FAST_WAVES * WAVE) f_top(Tree T, Data Dt, Opts
         __syncthreads();
         if (stop) return;
     }
+    stamp(Dt, O, 1, sl++);
     for (int l = lcut - 1; l >= 1; l--) {
         const int nb = U::width(l), f0 = U::first(l);
         for (int b = wave; b < nb; b += FAST_WAVES) fast_factor<NX, NU, MD>(Dt, O, f0 + b, T.Np, lane, lds, false);
         __syncthreads();
+        stamp(Dt, O, 1, sl++);
     }
     if (wave == 0) fast_factor<NX, NU, MD>(Dt, O, 0, T.Np, lane, lds, true);
     __syncthreads();
+    stamp(Dt, O, 1, sl++);
     for (int l = 1; l < lcut; l++) {
         const int nb = U::width(l), f0 = U::first(l);
         for (int b = wave; b < nb; b += FAST_WAVES) fast_forward<NX, NU, MD>(Dt, f0 + b, lane);
         __syncthreads();
+        stamp(Dt, O, 1, sl++);
     }
     /* first trial: nodes of levels 0 .. lcut-1 (their own and their children's duals are final) */
     const double *lamc = c->cur ? Dt.lam1 : Dt.lam0;
@@ -419,12 +437,13 @@ __global__ void __launch_bounds__(FAST_WAVES * WAVE) f_top(Tree T, Data Dt, Opts
     const int ntop = U::first(lcut);
     for (int k = wave; k < ntop; k += FAST_WAVES) fast_stage<NX, NU, MD>(Dt, k, T.Np, lane, lds, 1.0, lamc, lamn);
     __syncthreads();
+    stamp(Dt, O, 1, sl++);
     if (threadIdx.x == 0) { c->tau = 1.0; c->tauPrev = 0.0; c->ls_iter = 1; c->ls_pending = 1; }
 }
 
 /* f_down: one workgroup per subtree: forward sweep top-down, then the first trial for its nodes */
 template <int NX, int NU, int MD>
-__global__ void __launch_bounds__(FAST_WAVES * WAVE) f_down(Tree T, Data Dt, int lcut, int h) {
+__global__ void __launch_bounds__(FAST_WAVES * WAVE) f_down(Tree T, Data Dt, Opts O, int lcut, int h) {
     using U = Uni<NX, NU, MD>;
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     const Ctrl *c = Dt.ctrl;
@@ -432,10 +451,13 @@ __global__ void __launch_bounds__(FAST_WAVES * WAVE) f_down(Tree T, Data Dt, int
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     double *lds = lds_all + wave * U::WAVE_LDS;
     const int s = blockIdx.x, Nh = T.Nh, depth = Nh - lcut;
+    int sl = 0;
+    stamp(Dt, O, 2, sl++);
     for (int t = 0; t < depth; t++) {
         const int nb = U::width(t), f0 = U::first(lcut + t) + s * nb;
         for (int b = wave; b < nb; b += FAST_WAVES) fast_forward<NX, NU, MD>(Dt, f0 + b, lane);
         __syncthreads();
+        stamp(Dt, O, 2, sl++);
     }
     const double *lamc = c->cur ? Dt.lam1 : Dt.lam0;
     double *lamn = c->cur ? Dt.lam0 : Dt.lam1;
@@ -443,4 +465,6 @@ __global__ void __launch_bounds__(FAST_WAVES * WAVE) f_down(Tree T, Data Dt, int
         const int nb = U::width(t), f0 = U::first(lcut + t) + s * nb;
         for (int b = wave; b < nb; b += FAST_WAVES) fast_stage<NX, NU, MD>(Dt, f0 + b, T.Np, lane, lds, 1.0, lamc, lamn);
     }
+    __syncthreads();
+    stamp(Dt, O, 2, sl++);
 }
