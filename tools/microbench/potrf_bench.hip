@@ -81,6 +81,61 @@ __device__ __forceinline__ void potrf_v4(double (&T)[D], int lane) {
     }
 }
 
+// one-Newton-step reciprocal square root
+__device__ __forceinline__ double pivot_rsqrt1(double p) {
+    double y = __builtin_amdgcn_rsq(p);
+    double e = fma(-(p * y), y, 1.0);
+    y = fma(0.5 * y, e, y);
+    return p > 0.0 ? y : 0.0;
+}
+// V6: left-looking, readlane, 4 partial accumulators per dot product
+__device__ __forceinline__ void potrf_v6(double (&T)[D], int lane) {
+#pragma unroll
+    for (int j = 0; j < D; j++) {
+        double s0 = T[j], s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+        for (int k = 0; k < j; k++) {
+            const double l = rdlane(T[k], j);
+            if ((k & 3) == 0) s0 = fma(-T[k], l, s0);
+            if ((k & 3) == 1) s1 = fma(-T[k], l, s1);
+            if ((k & 3) == 2) s2 = fma(-T[k], l, s2);
+            if ((k & 3) == 3) s3 = fma(-T[k], l, s3);
+        }
+        const double s = (s0 + s1) + (s2 + s3);
+        const double pj = rdlane(s, j);
+        const double finv = pivot_rsqrt(pj);
+        T[j] = s * finv;
+    }
+}
+// V7: V4 with one Newton step
+__device__ __forceinline__ void potrf_v7(double (&T)[D], int lane) {
+#pragma unroll
+    for (int j = 0; j < D; j++) {
+        double s = T[j];
+#pragma unroll
+        for (int k = 0; k < j; k++) s = fma(-T[k], rdlane(T[k], j), s);
+        const double pj = rdlane(s, j);
+        const double finv = pivot_rsqrt1(pj);
+        T[j] = s * finv;
+    }
+}
+// V8: pivot lane computes its own pivot first (its dot product needs only its own registers), so the
+// reciprocal square root chain overlaps the other rows' updates
+__device__ __forceinline__ void potrf_v8(double (&T)[D], int lane) {
+#pragma unroll
+    for (int j = 0; j < D; j++) {
+        // pivot: p_j = T[j][j] - sum_k l_jk^2 needs lane j's own registers only -> broadcast squares
+        double pj = rdlane(T[j], j);
+#pragma unroll
+        for (int k = 0; k < j; k++) { const double l = rdlane(T[k], j); pj = fma(-l, l, pj); }
+        const double finv = pivot_rsqrt(pj);
+        double s = T[j];
+#pragma unroll
+        for (int k = 0; k < j; k++) s = fma(-T[k], rdlane(T[k], j), s);
+        T[j] = s * finv;
+    }
+}
+
 // V5: right-looking with ds_bpermute broadcast (__shfl)
 __device__ __forceinline__ void potrf_v5(double (&T)[D], int lane) {
 #pragma unroll
@@ -110,6 +165,9 @@ __global__ void bench(const double *in, double *out, long long *cycles, int reps
         if (V == 3) potrf_v3(T, lane, lds);
         if (V == 4) potrf_v4(T, lane);
         if (V == 5) potrf_v5(T, lane);
+        if (V == 6) potrf_v6(T, lane);
+        if (V == 7) potrf_v7(T, lane);
+        if (V == 8) potrf_v8(T, lane);
 #pragma unroll
         for (int j = 0; j < D; j++) acc += T[j];
     }
@@ -148,6 +206,12 @@ __global__ void probe(double *out, long long *cycles) {
     if (lane == 0) { cycles[0] = (t1 - t0) / 256; cycles[1] = (t2 - t1) / 256; cycles[2] = (t3 - t2) / 256; cycles[3] = (t4 - t3) / 256; cycles[4] = (t5 - t4) / 64; }
 }
 
+__global__ void rsq_acc(double *out) {
+    const int l = threadIdx.x;
+    const double p = 0.37 + 1.731 * l + 1e-3 * l * l;
+    out[l] = __builtin_amdgcn_rsq(p); out[64 + l] = pivot_rsqrt1(p); out[128 + l] = pivot_rsqrt(p); out[192 + l] = p;
+}
+
 int main() {
     std::vector<double> h(R * D, 0.0);
     // SPD 16x16 + extra rows
@@ -158,7 +222,7 @@ int main() {
     hipMemcpy(din, h.data(), sizeof(double) * R * D, hipMemcpyHostToDevice);
     long long c[8];
     std::vector<double> ref(64 * D), got(64 * D);
-    for (int v = 1; v <= 5; v++) {
+    for (int v = 1; v <= 8; v++) {
         for (int it = 0; it < 2; it++) {
             switch (v) {
                 case 1: hipLaunchKernelGGL(bench<1>, dim3(1), dim3(64), 0, 0, din, dout, dc, 200); break;
@@ -166,6 +230,9 @@ int main() {
                 case 3: hipLaunchKernelGGL(bench<3>, dim3(1), dim3(64), 0, 0, din, dout, dc, 200); break;
                 case 4: hipLaunchKernelGGL(bench<4>, dim3(1), dim3(64), 0, 0, din, dout, dc, 200); break;
                 case 5: hipLaunchKernelGGL(bench<5>, dim3(1), dim3(64), 0, 0, din, dout, dc, 200); break;
+                case 6: hipLaunchKernelGGL(bench<6>, dim3(1), dim3(64), 0, 0, din, dout, dc, 200); break;
+                case 7: hipLaunchKernelGGL(bench<7>, dim3(1), dim3(64), 0, 0, din, dout, dc, 200); break;
+                case 8: hipLaunchKernelGGL(bench<8>, dim3(1), dim3(64), 0, 0, din, dout, dc, 200); break;
             }
             hipDeviceSynchronize();
         }
@@ -176,6 +243,9 @@ int main() {
         for (int i = 0; i < R; i++) for (int j = 0; j <= (i < D ? i : D - 1); j++) err = fmax(err, fabs(got[i * D + j] - ref[i * D + j]));
         printf("variant %d: %lld cycles per 25x16 tall potrf   (max diff vs v1 %.2e)\n", v, c[0], err);
     }
+    { hipLaunchKernelGGL(rsq_acc, dim3(1), dim3(64), 0, 0, dout); hipDeviceSynchronize(); std::vector<double> r(256); hipMemcpy(r.data(), dout, 256 * 8, hipMemcpyDeviceToHost);
+      double e0 = 0, e1 = 0, e2 = 0; for (int i = 0; i < 64; i++) { double t = 1.0 / sqrt(r[192 + i]); e0 = fmax(e0, fabs(r[i] / t - 1)); e1 = fmax(e1, fabs(r[64 + i] / t - 1)); e2 = fmax(e2, fabs(r[128 + i] / t - 1)); }
+      printf("rsq relative error: raw %.2e, 1 Newton %.2e, 2 Newton %.2e\n", e0, e1, e2); }
     hipLaunchKernelGGL(probe, dim3(1), dim3(64), 0, 0, dout, dc); hipDeviceSynchronize();
     hipLaunchKernelGGL(probe, dim3(1), dim3(64), 0, 0, dout, dc); hipDeviceSynchronize();
     hipMemcpy(c, dc, 40, hipMemcpyDeviceToHost);

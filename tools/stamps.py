@@ -22,17 +22,22 @@ g = capi.TqGpu(nk, nx, nu).upload(qp.flat(), p.lambda0)
 for _ in range(5):
     r = g.solve(maxIter=1)          # one real iteration so that the stamps belong to a full iteration
 print(r)
-buf = np.zeros(3 * 64 * 2, dtype=np.uint64)
+buf = np.zeros(8 * 32 * 2, dtype=np.uint64)
 capi.lib().tqgpu_get_stamps(g.h, buf.ctypes.data_as(C.POINTER(C.c_ulonglong)), len(buf))
-st = buf.reshape(3, 64, 2).astype(np.int64)
-for kern, name in enumerate(("f_up", "f_top", "f_down")):
+st = buf.reshape(8, 32, 2).astype(np.int64)
+t_first = min(int(st[k][0, 1]) for k in range(8) if st[k][0, 1] > 0)
+for kern in range(8):
+    name = f"kernel#{kern} (back tiers, top, fwd tiers, stage in launch order)"
     s = st[kern]
     n = int((s[:, 1] > 0).sum())
     if n < 2:
         continue
+    if kern == 6:
+        print('fine stamps (cycles):', [int(v) for v in np.diff(s[:4, 0])], [int(v) for v in np.diff(s[8:12, 0])])
+        continue
     cyc = np.diff(s[:n, 0])
     wall = np.diff(s[:n, 1]) * 10.0          # 100 MHz -> ns
-    print(name, "phases:", n - 1)
+    print(name, "phases:", n - 1, f" starts at +{(int(s[0, 1]) - t_first) * 0.01:.2f} us")
     for i in range(n - 1):
         print(f"   {i:2d}: {wall[i] / 1e3:8.2f} us  {cyc[i]:8d} cycles  ({cyc[i] / max(wall[i], 1):.2f} GHz)")
     print(f"   total {wall.sum() / 1e3:.2f} us")

@@ -85,7 +85,7 @@ struct Data {            /* device pointers, passed by value */
     double *lam0, *lam1, *dlam, *res, *resMod;
     double *W, *CholW, *invd, *Ut, *CholUt;
     double *fval, *part_err, *part_dot;
-    double *Sbuf, *vbuf;     /* fused path: per-block Schur complement hand-off (NX x NX, NX) */
+    double *Sbuf, *ybuf;     /* fused path: Schur hand-off records across tiers; backward solution L^-1 resMod */
     unsigned long long *stamps;   /* diagnostic time stamps (written only when Opts.stamps != 0; never read by kernels) */
     Ctrl *ctrl;
     int *ls_log;
@@ -581,8 +581,10 @@ struct tqgpu_solver {
     bool need_init = true;
     /* fused path for uniform complete trees */
     int fast = -1;            /* index into the instantiation table, -1: generic path only */
-    int fNX = 0, fNU = 0, fMD = 0, lcut = 0, nsub = 0;
-    size_t lds_fast = 0;
+    int fNX = 0, fNU = 0, fMD = 0;
+    int n_tiers = 0;          /* tiers of block levels, index 0 = bottom */
+    std::vector<int> tier_l0, tier_l1, tier_grid;
+    size_t lds_fast = 0, lds_fstage = 0;
     int use_fast = 1;         /* can be switched off (TREEQP_AMD_PATH=generic) */
     int chunk = 4;            /* Newton iterations enqueued per status read-back */
 };
@@ -687,11 +689,10 @@ int fast_index(int NX, int NU, int MD) {
     return -1;
 }
 
-size_t fast_wave_lds(int idx) {
-#define X(i, nx, nu, md) if (idx == i) return Uni<nx, nu, md>::WAVE_LDS * sizeof(double);
+void fast_geometry(int idx, int &TH, size_t &tier_lds, size_t &stage_lds) {
+#define X(i, nx, nu, md) if (idx == i) { TH = Uni<nx, nu, md>::TH; tier_lds = Uni<nx, nu, md>::TIER_LDS * sizeof(double); stage_lds = FW * (Uni<nx, nu, md>::D + nx + 8) * sizeof(double); }
     FAST_TABLE(X)
 #undef X
-    return 0;
 }
 
 /* uniform complete tree? (every node nx, every parent nu + md children, one leaf depth) */
@@ -707,32 +708,62 @@ void detect_fast(tqgpu_solver *s) {
     const int idx = fast_index(NX, NU, MD);
     if (idx < 0) return;
     s->fast = idx; s->fNX = NX; s->fNU = NU; s->fMD = MD;
-    /* cut level: the widest level handled by the single top workgroup has <= FAST_WAVES blocks */
-    int lcut = 1, w = 1;
-    while (lcut < s->Nh - 1 && w * MD <= FAST_WAVES) { w *= MD; lcut++; }
-    s->lcut = lcut;
-    int nsub = 1;
-    for (int l = 0; l < lcut; l++) nsub *= MD;
-    s->nsub = nsub;
-    s->lds_fast = FAST_WAVES * fast_wave_lds(idx);
+    int TH = 1;
+    fast_geometry(idx, TH, s->lds_fast, s->lds_fstage);
+    /* block levels 0 .. Nh-1 grouped bottom-up into tiers of TH levels; the top tier takes the rest */
+    const int Nh = s->Nh;
+    s->n_tiers = (Nh + TH - 1) / TH;
+    s->tier_l0.clear(); s->tier_l1.clear(); s->tier_grid.clear();
+    for (int i = 0; i < s->n_tiers; i++) {
+        const int l1 = Nh - i * TH, l0 = std::max(0, l1 - TH);
+        int grid = 1;
+        for (int l = 0; l < l0; l++) grid *= MD;
+        s->tier_l0.push_back(l0); s->tier_l1.push_back(l1); s->tier_grid.push_back(grid);
+    }
 }
 
 void launch_fast_iteration(tqgpu_solver *s, const Opts &O, int h, int &launches) {
     const Tree &T = s->T; const Data &D = s->D; hipStream_t st = s->stream;
-    const dim3 blk(FAST_WAVES * WAVE);
+    const dim3 blk(FW * WAVE);
+    const int nt = s->n_tiers, nparts = nt > 1 ? s->tier_grid[0] : FW;
+    const int nstage = (T.Nn + FW - 1) / FW;
     switch (s->fast) {
-#define X(idx, nx, nu, md)                                                                              \
-    case idx:                                                                                           \
-        hipLaunchKernelGGL((f_up<nx, nu, md>), dim3(s->nsub), blk, s->lds_fast, st, T, D, O, s->lcut, h); \
-        hipLaunchKernelGGL((f_top<nx, nu, md>), dim3(1), blk, s->lds_fast, st, T, D, O, s->lcut, h);      \
-        hipLaunchKernelGGL((f_down<nx, nu, md>), dim3(s->nsub), blk, s->lds_fast, st, T, D, O, s->lcut, h);  \
+#define X(idx, nx, nu, md)                                                                                              \
+    case idx:                                                                                                           \
+        for (int i = 0; i < nt - 1; i++)                                                                                \
+            hipLaunchKernelGGL((f_back<nx, nu, md>), dim3(s->tier_grid[i]), blk, s->lds_fast, st, T, D, O,              \
+                               s->tier_l0[i], s->tier_l1[i], i == 0, i == 1, nparts, i, h);                             \
+        hipLaunchKernelGGL((f_top<nx, nu, md>), dim3(1), blk, s->lds_fast, st, T, D, O, s->tier_l1[nt - 1],              \
+                           nt == 1, nt == 2, nparts, nt - 1, h);                                                        \
+        for (int i = nt - 2; i >= 0; i--)                                                                               \
+            hipLaunchKernelGGL((f_fwd<nx, nu, md>), dim3(s->tier_grid[i]), blk, s->lds_fast, st, T, D, O,               \
+                               s->tier_l0[i], s->tier_l1[i], nt + (nt - 2 - i), h);                                     \
+        hipLaunchKernelGGL((f_stage<nx, nu, md>), dim3(nstage), blk, s->lds_fstage, st, T, D, O, 2 * nt - 1, h, 1);      \
         break;
         FAST_TABLE(X)
 #undef X
         default: break;
     }
     hipLaunchKernelGGL(k_ls_decide, dim3(1), dim3(256), 0, st, T, D, O, h, 1, 1);
-    launches += 4;
+    launches += 2 * nt + 1;
+}
+
+/* one more line-search trial of iteration `it` */
+void launch_trial(tqgpu_solver *s, const Opts &O, bool fast, int it, int t, int &launches) {
+    const Tree &T = s->T; const Data &D = s->D; hipStream_t st = s->stream;
+    bool done = false;
+    if (fast) {
+        const int nstage = (T.Nn + FW - 1) / FW;
+        switch (s->fast) {
+#define X(idx, nx, nu, md) case idx: hipLaunchKernelGGL((f_stage<nx, nu, md>), dim3(nstage), dim3(FW * WAVE), s->lds_fstage, st, T, D, O, 7, it, t); done = true; break;
+            FAST_TABLE(X)
+#undef X
+            default: break;
+        }
+    }
+    if (!done) hipLaunchKernelGGL(k_stage, dim3(T.Nn), dim3(WAVE), s->lds_stage, st, T, D, 1, it, t);
+    hipLaunchKernelGGL(k_ls_decide, dim3(1), dim3(256), 0, st, T, D, O, it, t, 0);
+    launches += 2;
 }
 
 void launch_generic_iteration(tqgpu_solver *s, const Opts &O, int h, int &launches) {
@@ -797,11 +828,11 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
     const size_t o_W = cv.take(s->sum_W * Dbl), o_CW = cv.take(s->sum_W * Dbl), o_Ut = cv.take(s->sum_Ut * Dbl), o_CUt = cv.take(s->sum_Ut * Dbl);
     const size_t o_fval = cv.take(Nn * Dbl), o_perr = cv.take((SX + Nn + 1) * Dbl), o_pdot = cv.take(Nn * Dbl);
     const size_t maxnx = (size_t)*std::max_element(s->nx.begin(), s->nx.end());
-    const size_t o_sbuf = cv.take((s->fast >= 0 ? (size_t)Nn * maxnx * maxnx : 1) * Dbl), o_vbuf = cv.take((SX + 1) * Dbl);
+    const size_t o_sbuf = cv.take((s->fast >= 0 ? (size_t)Nn * (maxnx * maxnx + maxnx) : 1) * Dbl), o_ybuf = cv.take((SX + 1) * Dbl);
     const size_t o_mux = cv.take(SX * Dbl), o_muu = cv.take(SU * Dbl);
     const size_t o_lami = cv.take(SX * Dbl);
     const size_t o_ctrl = cv.take(sizeof(Ctrl));
-    const size_t o_stamps = cv.take(3 * 64 * 2 * sizeof(unsigned long long));
+    const size_t o_stamps = cv.take(8 * 32 * 2 * sizeof(unsigned long long));
     s->ls_log_cap = 4096;
     const size_t o_log = cv.take(s->ls_log_cap * I);
     s->slab_bytes = cv.off + 256;
@@ -839,7 +870,7 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
     D.res = at<double>(base, o_res); D.resMod = at<double>(base, o_resMod); D.invd = at<double>(base, o_invd);
     D.W = at<double>(base, o_W); D.CholW = at<double>(base, o_CW); D.Ut = at<double>(base, o_Ut); D.CholUt = at<double>(base, o_CUt);
     D.fval = at<double>(base, o_fval); D.part_err = at<double>(base, o_perr); D.part_dot = at<double>(base, o_pdot);
-    D.Sbuf = at<double>(base, o_sbuf); D.vbuf = at<double>(base, o_vbuf);
+    D.Sbuf = at<double>(base, o_sbuf); D.ybuf = at<double>(base, o_ybuf);
     D.stamps = at<unsigned long long>(base, o_stamps);
     D.ctrl = at<Ctrl>(base, o_ctrl); D.ls_log = at<int>(base, o_log); D.ls_log_cap = s->ls_log_cap;
     s->d_mu_x = at<double>(base, o_mux); s->d_mu_u = at<double>(base, o_muu);
@@ -850,7 +881,7 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
         return cleanup_fail(rc);
     if (s->fast >= 0) {
         hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device) != hipSuccess || prop.maxThreadsPerBlock < FAST_WAVES * WAVE) s->fast = -1;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess || prop.maxThreadsPerBlock < FW * WAVE) s->fast = -1;
     }
     *out = s;
     return TQGPU_OK;
@@ -872,11 +903,11 @@ extern "C" void tqgpu_destroy(tqgpu_solver *s) {
 
 extern "C" int tqgpu_uses_fused_path(const tqgpu_solver *s) { return s && s->fast >= 0 && s->use_fast ? 1 : 0; }
 
-/* diagnostic: copy the in-kernel time stamps of the last fused iteration (3 kernels x 64 slots x
+/* diagnostic: copy the in-kernel time stamps of the last fused iteration (8 kernels x 32 slots x
  * {shader clock, 100 MHz wall clock}); only filled when TREEQP_AMD_STAMPS is set */
 extern "C" int tqgpu_get_stamps(tqgpu_solver *s, unsigned long long *out, int cap) {
     if (!s || !out) return fail(TQGPU_EINVAL, "bad arguments");
-    const int n = std::min(cap, 3 * 64 * 2);
+    const int n = std::min(cap, 8 * 32 * 2);
     HIP_TRY(hipMemcpy(out, s->D.stamps, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToHost));
     return TQGPU_OK;
 }
@@ -1005,10 +1036,7 @@ extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *r
         while (!s->h_ctrl->done && s->h_ctrl->ls_pending) {
             /* the line search of iteration `iter` wants more trials (rare): a batch of them */
             const int it = s->h_ctrl->iter, t0 = s->h_ctrl->ls_iter;
-            for (int t = t0; t < t0 + 8 && t <= O.lsMaxIter; t++) {
-                hipLaunchKernelGGL(k_stage, dim3(T.Nn), dim3(WAVE), s->lds_stage, st, T, D, 1, it, t); launches++;
-                hipLaunchKernelGGL(k_ls_decide, dim3(1), dim3(256), 0, st, T, D, O, it, t, 0); launches++;
-            }
+            for (int t = t0; t < t0 + 8 && t <= O.lsMaxIter; t++) launch_trial(s, O, fast, it, t, launches);
             if ((rc = read_ctrl(s)) != TQGPU_OK) return rc;
         }
         h = s->h_ctrl->iter;

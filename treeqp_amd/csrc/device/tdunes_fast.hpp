@@ -4,36 +4,34 @@
  *
  * Included by tdunes_device.hip (shares Tree/Data/Ctrl/Opts and the phase guards).
  *
- * Why a second path: on this workload a Newton iteration is a chain of 2*levels dependent
- * block steps (SURVEY.md §7 "Latency, not bandwidth").  The generic path pays one kernel boundary
- * plus an LDS round-trip heavy block step per level (13 us per level measured, profiles/r01_v1_*).
- * Here
+ * Why a second path: on this workload a Newton iteration is a chain of 2*levels dependent block
+ * steps (SURVEY.md §7 "Latency, not bandwidth").  The generic path pays one kernel boundary plus
+ * an LDS round-trip heavy block step per level (13 us per level, profiles/r01_v1_*).  Here
  *   - a dual-Hessian block lives in the REGISTERS of one wavefront while it is factorised: lane i
  *     owns row i of the tall matrix T = [W ; resMod' ; Ut] (D + 1 + NX <= 64 rows, D doubles per
- *     lane); the rank-1 updates read the pivot column of other rows with v_readlane_b32 (SGPR
- *     broadcast, no LDS in the dependency chain); the reciprocal pivot is v_rsq_f64 + two Newton
- *     steps instead of sqrt + divide (the latency-critical part of every pivot);
- *   - W = C P C' for a block is ONE 16x16 f64 MFMA tile (v_mfma_f64_16x16x4_f64, K = NX+NU padded
+ *     lane); row j of the factor is broadcast with v_readlane_b32 (SGPR operand of the FMAs, no
+ *     LDS in the dependency chain; measured 3.3k cycles per 25x16 block against 6.3k-12.9k for
+ *     LDS / ds_bpermute broadcasts, tools/microbench/potrf_bench.hip); the reciprocal pivot is
+ *     v_rsq_f64 + two Newton steps instead of sqrt + divide;
+ *   - W = C P C' of a block is ONE 16x16 f64 MFMA tile (v_mfma_f64_16x16x4_f64, K = NX+NU padded
  *     to a multiple of 4), operands loaded straight from the packed [A B] edge data;
- *   - the tree is cut at level `lcut`: every subtree below the cut is owned by one workgroup that
- *     walks its levels bottom-up with workgroup barriers only (f_up), the levels above the cut are
- *     owned by a single workgroup (f_top), the forward sweep mirrors that (f_top, f_down).  One
- *     Newton iteration = 4 launches (f_up, f_top, f_down, k_ls_decide) instead of ~31;
- *   - children hand their Schur complement to the parent through small per-block buffers
- *     (Sbuf/vbuf) instead of read-modify-write on the parent's block, so no two workgroups ever
- *     write the same words;
- *   - the first line-search trial (tau = 1) is evaluated speculatively inside f_top/f_down; the
- *     accepted trial sweep doubles as phase S of the next iteration.
+ *   - the block levels are grouped into TIERS of TH levels (MD^(TH-1) <= 4 blocks at the widest
+ *     level of a tier subtree): one 4-wave workgroup owns one tier subtree, one wave per block, one
+ *     wave per SIMD; inside a tier children hand their Schur complement to the parent through LDS
+ *     and the next level's rows are prefetched before the workgroup barrier; tiers are separate
+ *     launches (f_back ... f_top ... f_fwd), a kernel boundary costs about one block step;
+ *   - the first line-search trial (tau = 1) is evaluated speculatively by f_stage right after the
+ *     forward sweep; the accepted trial sweep doubles as phase S of the next iteration.
  *
- * Arithmetic follows the same operation order as the generic path except (i) the reciprocal
- * pivot (<= 1 ulp from 1/sqrt) and (ii) MFMA / cross-lane summation order in W and res; the parity
- * tests hold it to the same 1e-10 tolerance against the oracle.
+ * Arithmetic follows the generic path's operation order except (i) the reciprocal pivot (<= 1 ulp
+ * from 1/sqrt) and (ii) MFMA / cross-lane summation order in W and res; the parity tests hold it
+ * to the same 1e-10 tolerance against the oracle.
  */
 #pragma once
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-#define FAST_WAVES 16      /* waves per workgroup of the fused kernels (1024 threads) */
+#define FW 4            /* waves per workgroup of the tier kernels: one per SIMD */
 
 template <int NX, int NU, int MD>
 struct Uni {
@@ -42,11 +40,14 @@ struct Uni {
     static constexpr int R = D + 1 + NX;     /* rows of the tall matrix         */
     static constexpr int KS = (NZ + 3) / 4;  /* MFMA k-steps                    */
     static constexpr int LDW = D + 1;        /* LDS row stride (bank spread)    */
-    static constexpr int WAVE_LDS = (NX + 1) * (D + 1) + D + NX + 8;   /* doubles of LDS per wave */
+    static constexpr int SCH = NX * NX + NX; /* Schur hand-off record: S (NX x NX) then v (NX) */
+    static constexpr int TH = (MD == 2) ? 3 : ((MD <= 4) ? 2 : 1);     /* tier height: MD^(TH-1) <= FW */
+    static constexpr int NBT = (MD == 2) ? 7 : (1 + MD);               /* blocks of a full tier subtree */
+    static constexpr int WAVE_LDS = (NX + 1) * LDW + D + NX + 8;       /* per-wave scratch (doubles) */
+    static constexpr int TIER_LDS = NBT * SCH + NBT * D + FW * WAVE_LDS + 16;   /* doubles per workgroup */
     static_assert(D <= 16, "the MFMA tile path needs a dual block of at most 16 rows");
     static_assert(R <= 64, "tall matrix must fit one wavefront");
     __device__ static __forceinline__ int kid0(int k) { return MD * k + 1; }
-    __device__ static __forceinline__ int dad(int k) { return (k - 1) / MD; }
     __device__ static __forceinline__ int bo(int p) { return NX * (MD * p + 1); }      /* block vector offset */
     __device__ static __forceinline__ int first(int level) {                            /* first node of a level */
         int n = 0, w = 1;
@@ -72,21 +73,26 @@ __device__ __forceinline__ double pivot_rsqrt(double p) {
     return p > 0.0 ? y : 0.0;
 }
 
-/* diagnostic stamp: slot of kernel `kern` (0 f_up, 1 f_top, 2 f_down), workgroup 0 / thread 0 only */
+/* diagnostic stamp: slot of kernel `kern`, workgroup 0 / thread 0 only; the buffer is never read
+ * by any kernel */
 __device__ __forceinline__ void stamp(const Data &Dt, const Opts &O, int kern, int slot) {
-    if (O.stamps && threadIdx.x == 0 && blockIdx.x == 0 && slot < 64) {
-        Dt.stamps[(kern * 64 + slot) * 2 + 0] = clock64();
-        Dt.stamps[(kern * 64 + slot) * 2 + 1] = wall_clock64();
+    if (O.stamps && threadIdx.x == 0 && blockIdx.x == 0 && slot < 32 && kern < 8) {
+        Dt.stamps[(kern * 32 + slot) * 2 + 0] = clock64();
+        Dt.stamps[(kern * 32 + slot) * 2 + 1] = wall_clock64();
     }
 }
 
-__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+/* workgroup barrier that orders LDS traffic only: global stores stay in flight (they are consumed
+ * by a later kernel) */
+__device__ __forceinline__ void lds_barrier() { lds_fence(); __builtin_amdgcn_s_barrier(); lds_fence(); }
 
 /* ------------------------------------------------------------------------------------------ */
 /* G + H for one parent block p (one wave): res/resMod of its children, W_p, Ut_p             */
+/* returns this wave's contribution to the termination norm (valid in every lane)             */
 /* ------------------------------------------------------------------------------------------ */
 template <int NX, int NU, int MD>
-__device__ __forceinline__ void fast_gh(const Data &Dt, int p, int lane, int termCondition) {
+__device__ __forceinline__ double fast_gh(const Data &Dt, int p, int lane, int termCondition) {
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D, NZ = U::NZ;
     const int row = lane & 15, g = lane >> 4;
@@ -95,33 +101,41 @@ __device__ __forceinline__ void fast_gh(const Data &Dt, int p, int lane, int ter
     const bool live = row < D;
     const double *A = Dt.A + (size_t)(k - 1) * NX * NX + r;
     const double *B = Dt.B + (size_t)(k - 1) * NX * NU + r;
+    const int bo = U::bo(p);
+    /* issue every load before the first use */
+    double a[U::KS], pc[U::KS], z[U::KS];
+#pragma unroll
+    for (int s = 0; s < U::KS; s++) {
+        const int cc = g + 4 * s;
+        a[s] = 0.0; pc[s] = 0.0; z[s] = 0.0;
+        if (live && cc < NZ) {
+            if (cc < NX) { a[s] = A[(size_t)cc * NX]; pc[s] = Dt.QinvCal[NX * p + cc]; z[s] = Dt.x[NX * p + cc]; }
+            else { a[s] = B[(size_t)(cc - NX) * NX]; pc[s] = Dt.RinvCal[NU * p + cc - NX]; z[s] = Dt.u[NU * p + cc - NX]; }
+        }
+    }
+    double xk = 0.0, bk = 0.0, qk = 0.0;
+    if (live && g == 0) { xk = Dt.x[bo + row]; bk = Dt.b[bo + row]; }
+    if (live) qk = Dt.QinvCal[bo + row];
     f64x4 acc = {0.0, 0.0, 0.0, 0.0};
     double part = 0.0;                                   /* this lane's share of (A x_p + B u_p)[row] */
     double *Ut = Dt.Ut + (size_t)(p > 0 ? p - 1 : 0) * NX * D;
 #pragma unroll
     for (int s = 0; s < U::KS; s++) {
         const int cc = g + 4 * s;
-        double a = 0.0, pc = 0.0, z = 0.0;
-        if (live && cc < NZ) {
-            if (cc < NX) { a = A[(size_t)cc * NX]; pc = Dt.QinvCal[NX * p + cc]; z = Dt.x[NX * p + cc]; }
-            else { a = B[(size_t)(cc - NX) * NX]; pc = Dt.RinvCal[NU * p + cc - NX]; z = Dt.u[NU * p + cc - NX]; }
-        }
-        const double ap = a * pc;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, ap, acc, 0, 0, 0);
-        part = fma(a, z, part);
+        const double ap = a[s] * pc[s];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], ap, acc, 0, 0, 0);
+        part = fma(a[s], z[s], part);
         if (p > 0 && live && cc < NX) Ut[cc + (size_t)row * NX] = -1.0 * ap;      /* Ut = -(A Qcal)' */
     }
     /* residual: reduce the 4 k-groups of a row (lanes row, row+16, row+32, row+48) */
     part += __shfl_xor(part, 16, 64);
     part += __shfl_xor(part, 32, 64);
-    const int bo = U::bo(p);
     double e = 0.0;
     if (live && g == 0) {
-        const double rv = fma(-1.0, Dt.x[bo + row], Dt.b[bo + row]) + part;
+        const double rv = fma(-1.0, xk, bk) + part;
         Dt.res[bo + row] = rv;
         Dt.resMod[bo + row] = rv;
         e = (termCondition == 2) ? fabs(rv) : rv * rv;
-        Dt.part_err[bo + row] = e;
     }
     /* W tile: lane holds W[i = g + 4 rr][j = row] */
     double *W = Dt.W + (size_t)p * D * D;
@@ -130,341 +144,534 @@ __device__ __forceinline__ void fast_gh(const Data &Dt, int p, int lane, int ter
         const int i = g + 4 * rr;
         if (live && i < D) {
             double w = acc[rr];
-            if (i == row) w += Dt.QinvCal[bo + i];
+            if (i == row) w += qk;
             W[i + (size_t)row * D] = w;
+        }
+    }
+    return (termCondition == 2) ? wave_max(e) : wave_sum(e);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* backward step of one block, split into pieces so that loads can be issued early            */
+/* ------------------------------------------------------------------------------------------ */
+
+/* rows of T = [W ; resMod' ; Ut] of block ii: lane i < D row i of W, lane D the right-hand side,
+ * lanes D+1 .. R-1 the rows of Ut (none for the root) */
+template <int NX, int NU, int MD>
+__device__ __forceinline__ void load_rows(const Data &Dt, int ii, int lane, bool is_root, double (&T)[Uni<NX, NU, MD>::D]) {
+    using U = Uni<NX, NU, MD>;
+    constexpr int D = U::D, R = U::R;
+    const double *src; int stride;
+    if (lane < D) { src = Dt.W + (size_t)ii * D * D + lane; stride = D; }
+    else if (lane == D) { src = Dt.resMod + U::bo(ii); stride = 1; }
+    else if (lane < R && !is_root) { src = Dt.Ut + (size_t)(ii - 1) * NX * D + (lane - D - 1); stride = NX; }
+    else { src = Dt.W + (size_t)ii * D * D; stride = D; }
+#pragma unroll
+    for (int j = 0; j < D; j++) T[j] = src[(size_t)j * stride];
+}
+
+/* subtract the children's Schur complements; `sch` points at MD consecutive records (S then v) */
+template <int NX, int NU, int MD>
+__device__ __forceinline__ void sub_children(const double *sch, int lane, double (&T)[Uni<NX, NU, MD>::D]) {
+    using U = Uni<NX, NU, MD>;
+    constexpr int D = U::D;
+#pragma unroll
+    for (int c = 0; c < MD; c++) {
+        const double *S = sch + c * U::SCH, *v = S + NX * NX;
+        const int r = lane - c * NX;
+        if (lane < D && r >= 0 && r < NX) {
+#pragma unroll
+            for (int j = 0; j < NX; j++) T[c * NX + j] -= S[r + j * NX];
+        }
+        if (lane == D) {
+#pragma unroll
+            for (int j = 0; j < NX; j++) T[c * NX + j] -= v[j];
         }
     }
 }
 
-/* ------------------------------------------------------------------------------------------ */
-/* factor one block (one wave, block in registers)                                            */
-/* ------------------------------------------------------------------------------------------ */
+/* in-register tall Cholesky, left-looking, row broadcasts by readlane; returns true when a diagonal
+ * entry of the factor is <= regTol (on-the-fly regularisation trigger) */
+template <int D>
+__device__ __forceinline__ bool potrf_rows(double (&T)[D], int lane, double regTol, double &myinv) {
+    int small = 0;
+#pragma unroll
+    for (int j = 0; j < D; j++) {
+        double s = T[j];
+#pragma unroll
+        for (int k = 0; k < j; k++) s = fma(-T[k], rdlane(T[k], j), s);
+        const double pj = rdlane(s, j);
+        const double finv = pivot_rsqrt(pj);
+        small |= (pj * finv <= regTol);
+        T[j] = s * finv;
+        if (lane == j) myinv = finv;
+    }
+    return small != 0;
+}
+
+/* stores of the factorised block + Schur complement for the parent.
+ * sdst: where S (NX x NX) and v (NX) go (LDS record inside a tier, global Sbuf at a tier top) */
 template <int NX, int NU, int MD>
-__device__ __forceinline__ void fast_factor(const Data &Dt, const Opts &O, int ii, int Np, int lane, double *lds, bool is_root) {
+__device__ __forceinline__ void store_block(const Data &Dt, int ii, int lane, const double (&T)[Uni<NX, NU, MD>::D],
+                                            double myinv, double *lds, double *sdst) {
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D, R = U::R, LDW = U::LDW;
     const int bo = U::bo(ii);
-    const bool has_parent_kids = U::kid0(ii) < Np;        /* children are parents themselves -> Schur inputs */
-    /* per-lane row source */
-    const double *src; int stride;
-    if (lane < D) { src = Dt.W + (size_t)ii * D * D + lane; stride = D; }
-    else if (lane == D) { src = Dt.resMod + bo; stride = 1; }
-    else if (lane < R && !is_root) { src = Dt.Ut + (size_t)(ii - 1) * NX * D + (lane - D - 1); stride = NX; }
-    else { src = Dt.W + (size_t)ii * D * D; stride = D; }
-    double T[D];
-    double myinv = 0.0;
-    for (int pass = 0; pass < 2; pass++) {
-#pragma unroll
-        for (int j = 0; j < D; j++) T[j] = src[(size_t)j * stride];
-        if (has_parent_kids) {
-            /* subtract the children's Schur complements: rows of child c get -S_c in its column
-             * range, the right-hand side row gets -v_c */
-#pragma unroll
-            for (int c = 0; c < MD; c++) {
-                const int kid = U::kid0(ii) + c;
-                const double *S = Dt.Sbuf + (size_t)kid * NX * NX;
-                const double *v = Dt.vbuf + (size_t)kid * NX;
-                const int r = lane - c * NX;
-                if (lane < D && r >= 0 && r < NX) {
-#pragma unroll
-                    for (int j = 0; j < NX; j++) T[c * NX + j] -= S[r + (size_t)j * NX];
-                }
-                if (lane == D) {
-#pragma unroll
-                    for (int j = 0; j < NX; j++) T[c * NX + j] -= v[j];
-                }
-            }
-        }
-        if (O.regType == 1 || pass == 1) {
-#pragma unroll
-            for (int j = 0; j < D; j++) if (lane == j) T[j] += O.regValue;           /* ddiare */
-        }
-        int small = 0;
-#pragma unroll
-        for (int j = 0; j < D; j++) {
-            const double pj = rdlane(T[j], j);
-            const double finv = pivot_rsqrt(pj);
-            small |= (pj * finv <= O.regTol);
-            T[j] *= finv;
-            if (lane == j) myinv = finv;
-#pragma unroll
-            for (int c = j + 1; c < D; c++) {
-                const double lc = rdlane(T[j], c);
-                T[c] = fma(-T[j], lc, T[c]);
-            }
-        }
-        if (O.regType != 2 || pass == 1 || !small) break;
-        if (lane == 0) atomicAdd(&Dt.ctrl->n_reg, 1);
-    }
-    /* stores: factor rows, reciprocal diagonal */
     if (lane < D) {
         double *L = Dt.CholW + (size_t)ii * D * D + lane;
 #pragma unroll
         for (int j = 0; j < D; j++) L[(size_t)j * D] = T[j];
         Dt.invd[bo + lane] = myinv;
     }
-    if (!is_root) {
-        if (lane == D) {
+    if (lane == D) {
 #pragma unroll
-            for (int j = 0; j < D; j++) Dt.dlam[bo + j] = T[j];
-        }
-        if (lane > D && lane < R) {
-            double *CUt = Dt.CholUt + (size_t)(ii - 1) * NX * D + (lane - D - 1);
+        for (int j = 0; j < D; j++) Dt.ybuf[bo + j] = T[j];
+    }
+    if (lane > D && lane < R) {
+        double *CUt = Dt.CholUt + (size_t)(ii - 1) * NX * D + (lane - D - 1);
 #pragma unroll
-            for (int j = 0; j < D; j++) CUt[(size_t)j * NX] = T[j];
-        }
-        /* Schur complement for the parent: S = CUt CUt', v = CUt y, through LDS (rows D..R-1) */
-        if (lane >= D && lane < R) {
+        for (int j = 0; j < D; j++) CUt[(size_t)j * NX] = T[j];
+    }
+    /* S = CUt CUt', v = CUt y through the wave's LDS scratch (rows D .. R-1 of T) */
+    if (lane >= D && lane < R) {
 #pragma unroll
-            for (int j = 0; j < D; j++) lds[(lane - D) * LDW + j] = T[j];
-        }
-        wave_lds_fence();
-        if (lane < NX * NX) {
-            const int i = lane % NX, j = lane / NX;
-            const double *ri = lds + (1 + i) * LDW, *rj = lds + (1 + j) * LDW;
-            double acc = 0.0;
+        for (int j = 0; j < D; j++) lds[(lane - D) * LDW + j] = T[j];
+    }
+    lds_fence();
+    if (lane < NX * NX) {
+        const int i = lane % NX, j = lane / NX;
+        const double *ri = lds + (1 + i) * LDW, *rj = lds + (1 + j) * LDW;
+        double acc = 0.0;
 #pragma unroll
-            for (int c = 0; c < D; c++) acc = fma(ri[c], rj[c], acc);
-            Dt.Sbuf[(size_t)ii * NX * NX + i + (size_t)j * NX] = acc;
-        }
-        if (lane < NX) {
-            const double *ri = lds + (1 + lane) * LDW;
-            double acc = 0.0;
+        for (int c = 0; c < D; c++) acc = fma(ri[c], rj[c], acc);
+        sdst[i + j * NX] = acc;
+    }
+    if (lane < NX) {
+        const double *ri = lds + (1 + lane) * LDW;
+        double acc = 0.0;
 #pragma unroll
-            for (int c = 0; c < D; c++) acc = fma(ri[c], lds[c], acc);
-            Dt.vbuf[(size_t)ii * NX + lane] = acc;
-        }
-        wave_lds_fence();
+        for (int c = 0; c < D; c++) acc = fma(ri[c], lds[c], acc);
+        sdst[NX * NX + lane] = acc;
+    }
+    lds_fence();
+}
+
+/* regularised factorisation of the rows in T (treeqp_dpotrf_l_with_reg_opts, dual_Newton_common.c:36-78) */
+template <int NX, int NU, int MD>
+__device__ __forceinline__ void factor_rows(const Data &Dt, const Opts &O, int lane, double (&T)[Uni<NX, NU, MD>::D], double &myinv) {
+    constexpr int D = Uni<NX, NU, MD>::D;
+    if (O.regType == 1) {
+#pragma unroll
+        for (int j = 0; j < D; j++) if (lane == j) T[j] += O.regValue;            /* ddiare (ALWAYS) */
+    }
+    if (O.regType != 2) {
+        potrf_rows<D>(T, lane, O.regTol, myinv);
     } else {
-        /* root: dlam_0 = L^-T y, k descending; y and L rows are broadcast with readlane */
-        double y[D];
+        double K[D];
 #pragma unroll
-        for (int j = 0; j < D; j++) y[j] = rdlane(T[j], D);
-        double mine = 0.0;
+        for (int j = 0; j < D; j++) K[j] = T[j];
+        if (potrf_rows<D>(T, lane, O.regTol, myinv)) {                           /* rare: shift and refactorise */
 #pragma unroll
-        for (int k = D - 1; k >= 0; k--) {
-            const double zk = y[k] * rdlane(myinv, k);
-            if (lane == k) mine = zk;
-#pragma unroll
-            for (int i = 0; i < k; i++) y[i] = fma(-rdlane(T[i], k), zk, y[i]);
+            for (int j = 0; j < D; j++) T[j] = (lane == j) ? K[j] + O.regValue : K[j];
+            potrf_rows<D>(T, lane, O.regTol, myinv);
+            if (lane == 0) atomicAdd(&Dt.ctrl->n_reg, 1);
         }
-        double pd = 0.0;
-        if (lane < D) { Dt.dlam[bo + lane] = mine; pd = Dt.res[bo + lane] * mine; }
-        pd = wave_sum(pd);
-        if (lane == 0) Dt.part_dot[0] = pd;
     }
 }
 
-/* ------------------------------------------------------------------------------------------ */
-/* forward substitution of one block (one wave): lane i owns column i of L                     */
-/* ------------------------------------------------------------------------------------------ */
+/* one complete backward step; `kids_sch` = Schur records of the MD children (LDS or global) or
+ * nullptr for blocks of the last level */
 template <int NX, int NU, int MD>
-__device__ __forceinline__ void fast_forward(const Data &Dt, int ii, int lane) {
+__device__ __forceinline__ void backward_block(const Data &Dt, const Opts &O, int ii, int lane, double (&T)[Uni<NX, NU, MD>::D],
+                                               const double *kids_sch, double *lds, double *sdst) {
+    double myinv = 0.0;
+#ifdef TQ_FINE_STAMPS
+    int fs = (ii == 8 || ii == 1) ? (ii == 8 ? 0 : 8) : 100;      /* block 8: first of level 3 (tier 1 bottom); block 1 */
+    stamp(Dt, O, 6, fs++);
+#endif
+    if (kids_sch) sub_children<NX, NU, MD>(kids_sch, lane, T);
+#ifdef TQ_FINE_STAMPS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    stamp(Dt, O, 6, fs++);
+#endif
+    factor_rows<NX, NU, MD>(Dt, O, lane, T, myinv);
+#ifdef TQ_FINE_STAMPS
+    stamp(Dt, O, 6, fs++);
+#endif
+    store_block<NX, NU, MD>(Dt, ii, lane, T, myinv, lds, sdst);
+#ifdef TQ_FINE_STAMPS
+    stamp(Dt, O, 6, fs++);
+#endif
+}
+
+/* root: factor [W_0 ; resMod_0'], then dlam_0 = L^-T y (k descending), dot-product partial */
+template <int NX, int NU, int MD>
+__device__ __forceinline__ void root_block(const Data &Dt, const Opts &O, int lane, double (&T)[Uni<NX, NU, MD>::D],
+                                           const double *kids_sch, double *dl_out) {
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D;
-    const int bo = U::bo(ii), xo = NX * ii;
-    const int li = lane < D ? lane : 0;
-    const double *Lc = Dt.CholW + (size_t)ii * D * D + (size_t)li * D;
-    const double *Cc = Dt.CholUt + (size_t)(ii - 1) * NX * D + (size_t)li * NX;
-    double Lcol[D];
+    const int bo = U::bo(0);
+    double myinv = 0.0;
+    if (kids_sch) sub_children<NX, NU, MD>(kids_sch, lane, T);
+    factor_rows<NX, NU, MD>(Dt, O, lane, T, myinv);
+    if (lane < D) {
+        double *L = Dt.CholW + lane;
 #pragma unroll
-    for (int k = 0; k < D; k++) Lcol[k] = Lc[k];
-    double acc = 0.0;
+        for (int j = 0; j < D; j++) L[(size_t)j * D] = T[j];
+        Dt.invd[bo + lane] = myinv;
+    }
+    double y[D];
 #pragma unroll
-    for (int r = 0; r < NX; r++) acc = fma(Cc[r], Dt.dlam[xo + r], acc);
-    double s = fma(-1.0, acc, Dt.dlam[bo + li]);
-    const double inv = Dt.invd[bo + li];
+    for (int j = 0; j < D; j++) y[j] = rdlane(T[j], D);
     double mine = 0.0;
 #pragma unroll
     for (int k = D - 1; k >= 0; k--) {
-        const double zk = rdlane(s * inv, k);
+        const double zk = y[k] * rdlane(myinv, k);
         if (lane == k) mine = zk;
-        if (lane < k) s = fma(-Lcol[k], zk, s);
+#pragma unroll
+        for (int i = 0; i < k; i++) y[i] = fma(-rdlane(T[i], k), zk, y[i]);
     }
     double pd = 0.0;
-    if (lane < D) { Dt.dlam[bo + lane] = mine; pd = Dt.res[bo + lane] * mine; }
+    if (lane < D) { Dt.dlam[bo + lane] = mine; dl_out[lane] = mine; pd = Dt.res[bo + lane] * mine; }
+    pd = wave_sum(pd);
+    if (lane == 0) Dt.part_dot[0] = pd;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* forward step of one block: lane i owns column i of L                                       */
+/* ------------------------------------------------------------------------------------------ */
+template <int NX, int NU, int MD>
+struct FwdRegs {
+    double Lcol[Uni<NX, NU, MD>::D];
+    double Ccol[NX];
+    double y, inv, res;
+};
+
+template <int NX, int NU, int MD>
+__device__ __forceinline__ void load_fwd(const Data &Dt, int ii, int lane, FwdRegs<NX, NU, MD> &F) {
+    using U = Uni<NX, NU, MD>;
+    constexpr int D = U::D;
+    const int bo = U::bo(ii), li = lane < D ? lane : 0;
+    const double *Lc = Dt.CholW + (size_t)ii * D * D + (size_t)li * D;
+    const double *Cc = Dt.CholUt + (size_t)(ii - 1) * NX * D + (size_t)li * NX;
+#pragma unroll
+    for (int k = 0; k < D; k++) F.Lcol[k] = Lc[k];
+#pragma unroll
+    for (int r = 0; r < NX; r++) F.Ccol[r] = Cc[r];
+    F.y = Dt.ybuf[bo + li]; F.inv = Dt.invd[bo + li]; F.res = Dt.res[bo + li];
+}
+
+/* delta: the NX entries of the parent's solution that belong to node ii (LDS or global) */
+template <int NX, int NU, int MD>
+__device__ __forceinline__ void forward_block(const Data &Dt, int ii, int lane, const FwdRegs<NX, NU, MD> &F,
+                                              const double *delta, double *dl_out) {
+    using U = Uni<NX, NU, MD>;
+    constexpr int D = U::D;
+    double acc = 0.0;
+#pragma unroll
+    for (int r = 0; r < NX; r++) acc = fma(F.Ccol[r], delta[r], acc);
+    double s = fma(-1.0, acc, F.y);
+    double mine = 0.0;
+#pragma unroll
+    for (int k = D - 1; k >= 0; k--) {
+        const double zk = rdlane(s * F.inv, k);
+        if (lane == k) mine = zk;
+        if (lane < k) s = fma(-F.Lcol[k], zk, s);
+    }
+    double pd = 0.0;
+    if (lane < D) { Dt.dlam[U::bo(ii) + lane] = mine; if (dl_out) dl_out[lane] = mine; pd = F.res * mine; }
     pd = wave_sum(pd);
     if (lane == 0) Dt.part_dot[ii] = pd;
 }
 
 /* ------------------------------------------------------------------------------------------ */
-/* stage QP of one node at the trial point lam_cur + step * dlam (one wave); writes lam_next  */
+/* termination test run by the kernel that comes second in an iteration: every workgroup        */
+/* reduces the per-workgroup partials of the first kernel; workgroup 0 records the decision     */
 /* ------------------------------------------------------------------------------------------ */
-template <int NX, int NU, int MD>
-__device__ __forceinline__ void fast_stage(const Data &Dt, int k, int Np, int lane, double *lds, double step,
-                                           const double *lamc, double *lamn) {
-    using U = Uni<NX, NU, MD>;
-    constexpr int D = U::D, NZ = U::NZ;
-    const bool parent = k < Np;
-    const int nuk = parent ? NU : 0;
-    const int xo = NX * k, uo = NU * k, ko = U::bo(k);
-    double *lk = lds, *lown = lds + D;
-    if (parent && lane < D) lk[lane] = fma(step, Dt.dlam[ko + lane], lamc[ko + lane]);
-    if (lane < NX) {
-        double v = 0.0;
-        if (k > 0) { v = fma(step, Dt.dlam[xo + lane], lamc[xo + lane]); lamn[xo + lane] = v; }
-        lown[lane] = v;
-    }
-    wave_lds_fence();
-    double p_qx = 0.0, p_hx = 0.0, p_ru = 0.0, p_hu = 0.0, p_c = 0.0;
-    if (lane < NX + nuk) {
-        const bool isx = lane < NX;
-        const int j = isx ? lane : lane - NX;
-        double v = isx ? fma(-1.0, Dt.q[xo + j], lown[j]) : -1.0 * Dt.r[uo + j];
-        if (parent) {
-#pragma unroll
-            for (int cc = 0; cc < MD; cc++) {
-                const int kid = U::kid0(k) + cc;
-                const double *col = isx ? Dt.A + (size_t)(kid - 1) * NX * NX + (size_t)j * NX
-                                        : Dt.B + (size_t)(kid - 1) * NX * NU + (size_t)j * NX;
-                double acc = 0.0;
-#pragma unroll
-                for (int i = 0; i < NX; i++) acc = fma(col[i], lk[cc * NX + i], acc);
-                v = fma(-1.0, acc, v);
+__device__ __forceinline__ bool converged_now(const Data &Dt, const Opts &O, int nparts, int *flag_lds) {
+    if (threadIdx.x < WAVE) {
+        double e = 0.0;
+        for (int i = threadIdx.x; i < nparts; i += WAVE) e = (O.termCondition == 2) ? fmax(e, Dt.part_err[i]) : e + Dt.part_err[i];
+        e = (O.termCondition == 2) ? wave_max(e) : wave_sum(e);
+        if (O.termCondition == 1) e = sqrt(e);
+        if (threadIdx.x == 0) {
+            *flag_lds = e < O.tol;
+            if (blockIdx.x == 0) {
+                Dt.ctrl->err = e;
+                if (e < O.tol) { Dt.ctrl->status = 0; Dt.ctrl->done = 1; }
             }
         }
-        if (isx) {
-            Dt.qmod[xo + j] = v;
-            const double qi = Dt.Qinv[xo + j];
-            const double unc = qi * v, lo = Dt.xmin[xo + j], hi = Dt.xmax[xo + j];
-            double xv, cal;
-            if (unc >= hi) { xv = hi; cal = 0.0; } else if (unc <= lo) { xv = lo; cal = 0.0; } else { xv = unc; cal = qi; }
-            Dt.xUnc[xo + j] = unc; Dt.x[xo + j] = xv; Dt.QinvCal[xo + j] = cal;
-            p_qx = (Dt.Qd[xo + j] * xv) * xv;
-            p_hx = v * xv;
-        } else {
-            Dt.rmod[uo + j] = v;
-            const double ri = Dt.Rinv[uo + j];
-            const double unc = ri * v, lo = Dt.umin[uo + j], hi = Dt.umax[uo + j];
-            double uv, cal;
-            if (unc >= hi) { uv = hi; cal = 0.0; } else if (unc <= lo) { uv = lo; cal = 0.0; } else { uv = unc; cal = ri; }
-            Dt.uUnc[uo + j] = unc; Dt.u[uo + j] = uv; Dt.RinvCal[uo + j] = cal;
-            p_ru = (Dt.Rd[uo + j] * uv) * uv;
-            p_hu = v * uv;
-        }
     }
-    if (parent && lane < D) p_c = Dt.b[ko + lane] * lk[lane];
-    p_qx = wave_sum(p_qx); p_hx = wave_sum(p_hx); p_ru = wave_sum(p_ru); p_hu = wave_sum(p_hu); p_c = wave_sum(p_c);
-    if (lane == 0) {
-        double f = -0.5 * p_qx - p_c;
-        f += p_hx;
-        f -= 0.5 * p_ru;
-        f += p_hu;
-        Dt.fval[k] = f;
-    }
-    wave_lds_fence();
+    lds_barrier();
+    return *flag_lds != 0;
 }
 
 /* ------------------------------------------------------------------------------------------ */
-/* fused kernels                                                                              */
+/* tier kernels                                                                               */
 /* ------------------------------------------------------------------------------------------ */
 
-/* f_up: one workgroup per subtree rooted at level lcut: G+H for its blocks (and a share of the
- * top blocks), then the backward sweep over its levels, bottom-up. */
+/* LDS carve of a tier workgroup */
 template <int NX, int NU, int MD>
-__global__ void __launch_bounds__(FAST_WAVES * WAVE) f_up(Tree T, Data Dt, Opts O, int lcut, int h) {
+struct TierLds {
     using U = Uni<NX, NU, MD>;
+    double *sch;       /* NBT Schur records, heap order inside the tier subtree */
+    double *dl;        /* NBT block solutions (forward sweep)                   */
+    double *wave0;     /* scratch of wave 0                                     */
+    double *wave;      /* this wave's scratch                                   */
+    int *flag;
+    __device__ TierLds(double *base, int wave_id) {
+        sch = base; dl = sch + U::NBT * U::SCH; wave0 = dl + U::NBT * U::D; wave = wave0 + wave_id * U::WAVE_LDS;
+        flag = reinterpret_cast<int *>(wave0 + FW * U::WAVE_LDS);
+    }
+};
+
+/* f_back: one workgroup per subtree of block levels [l0, l1): backward sweep bottom-up.
+ * first != 0: this is the first kernel of the iteration: G+H (and norm partials) before the sweep.
+ * check != 0: this is the second kernel of the iteration: termination test first. */
+template <int NX, int NU, int MD>
+__global__ void __launch_bounds__(FW * WAVE) f_back(Tree T, Data Dt, Opts O, int l0, int l1, int first, int check, int nparts, int kern, int h) {
+    using U = Uni<NX, NU, MD>;
+    constexpr int D = U::D;
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     if (!phase_main(Dt.ctrl, h)) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    double *lds = lds_all + wave * U::WAVE_LDS;
-    const int s = blockIdx.x, Nh = T.Nh, depth = Nh - lcut;       /* block levels lcut .. Nh-1 */
+    TierLds<NX, NU, MD> L(lds_all, wave);
+    const int s = blockIdx.x, th = l1 - l0;
     int sl = 0;
-    stamp(Dt, O, 0, sl++);
-    for (int t = 0; t < depth; t++) {
-        const int nb = U::width(t), f0 = U::first(lcut + t) + s * nb;
-        for (int b = wave; b < nb; b += FAST_WAVES) fast_gh<NX, NU, MD>(Dt, f0 + b, lane, O.termCondition);
+    stamp(Dt, O, kern, sl++);
+    if (check && converged_now(Dt, O, nparts, L.flag)) return;
+    if (first) {
+        /* G + H: the blocks of this subtree, plus a share of the blocks above this tier */
+        double e = 0.0;
+        int cnt = 0;
+        for (int t = 0; t < th; t++) {
+            const int nb = U::width(t), f0 = U::first(l0 + t) + s * nb;
+            for (int b = 0; b < nb; b++, cnt++)
+                if ((cnt & (FW - 1)) == wave) { const double v = fast_gh<NX, NU, MD>(Dt, f0 + b, lane, O.termCondition); e = (O.termCondition == 2) ? fmax(e, v) : e + v; }
+        }
+        const int nup = U::first(l0);
+        for (int p = s * FW + wave; p < nup; p += gridDim.x * FW) { const double v = fast_gh<NX, NU, MD>(Dt, p, lane, O.termCondition); e = (O.termCondition == 2) ? fmax(e, v) : e + v; }
+        if (lane == 0) L.dl[wave] = e;       /* L.dl is not used by the backward sweep */
+        __syncthreads();                     /* W / Ut / resMod of this subtree are read back below */
+        if (threadIdx.x == 0) {
+            double acc = 0.0;
+            for (int w = 0; w < FW; w++) { const double v = L.dl[w]; acc = (O.termCondition == 2) ? fmax(acc, v) : acc + v; }
+            Dt.part_err[blockIdx.x] = acc;
+        }
+        stamp(Dt, O, kern, sl++);
     }
-    const int ntop = U::first(lcut);
-    for (int p = s * FAST_WAVES + wave; p < ntop; p += gridDim.x * FAST_WAVES) fast_gh<NX, NU, MD>(Dt, p, lane, O.termCondition);
-    __syncthreads();
-    stamp(Dt, O, 0, sl++);
-    for (int t = depth - 1; t >= 0; t--) {
-        const int nb = U::width(t), f0 = U::first(lcut + t) + s * nb;
-        for (int b = wave; b < nb; b += FAST_WAVES) fast_factor<NX, NU, MD>(Dt, O, f0 + b, T.Np, lane, lds, false);
-        __syncthreads();
-        stamp(Dt, O, 0, sl++);
+    double Tc[D], Tn[D];
+    {
+        const int t = th - 1, nb = U::width(t);
+        if (wave < nb) load_rows<NX, NU, MD>(Dt, U::first(l0 + t) + s * nb + wave, lane, false, Tc);
+    }
+    for (int t = th - 1; t >= 0; t--) {
+        const int nb = U::width(t), nbn = nb / MD;
+        const bool act = wave < nb, act_next = t > 0 && wave < nbn;
+        if (act_next) load_rows<NX, NU, MD>(Dt, U::first(l0 + t - 1) + s * nbn + wave, lane, false, Tn);     /* prefetch */
+        if (act) {
+            const int ii = U::first(l0 + t) + s * nb + wave;
+            const int loc = U::first(t) + wave;                       /* heap index inside the tier subtree */
+            const double *kids = nullptr;
+            if (t < th - 1) kids = L.sch + (U::first(t + 1) + MD * wave) * U::SCH;          /* children in this tier: LDS */
+            else if (l1 < T.Nh) kids = Dt.Sbuf + (size_t)U::kid0(ii) * U::SCH;              /* children in the tier below  */
+            double *sdst = (t > 0) ? L.sch + loc * U::SCH : Dt.Sbuf + (size_t)ii * U::SCH;
+            backward_block<NX, NU, MD>(Dt, O, ii, lane, Tc, kids, L.wave, sdst);
+        }
+        lds_barrier();
+        if (act_next) {
+#pragma unroll
+            for (int j = 0; j < D; j++) Tc[j] = Tn[j];
+        }
+        stamp(Dt, O, kern, sl++);
     }
 }
 
-/* f_top: single workgroup: termination test, levels above the cut backward + root + forward,
- * then the speculative first line-search trial (tau = 1) for the nodes above the cut. */
+/* f_top: single workgroup, block levels [0, l1): (G+H if it is the only tier) termination test,
+ * backward sweep, root, forward sweep of its levels; arms the line search. */
 template <int NX, int NU, int MD>
-__global__ void __launch_bounds__(FAST_WAVES * WAVE) f_top(Tree T, Data Dt, Opts O, int lcut, int h) {
+__global__ void __launch_bounds__(FW * WAVE) f_top(Tree T, Data Dt, Opts O, int l1, int first, int check, int nparts, int kern, int h) {
     using U = Uni<NX, NU, MD>;
+    constexpr int D = U::D;
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
-    __shared__ double sh[FAST_WAVES * WAVE];
-    __shared__ int stop;
     Ctrl *c = Dt.ctrl;
     if (!phase_main(c, h)) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    double *lds = lds_all + wave * U::WAVE_LDS;
+    TierLds<NX, NU, MD> L(lds_all, wave);
     int sl = 0;
-    stamp(Dt, O, 1, sl++);
-    /* termination test (calculate_error_in_residuals + :542-546) */
+    stamp(Dt, O, kern, sl++);
+    if (first) {
+        double e = 0.0;
+        const int nblk = U::first(l1);
+        for (int p = wave; p < nblk; p += FW) { const double v = fast_gh<NX, NU, MD>(Dt, p, lane, O.termCondition); e = (O.termCondition == 2) ? fmax(e, v) : e + v; }
+        if (lane == 0) Dt.part_err[wave] = e;
+        __syncthreads();
+        nparts = FW;
+        check = 1;
+    }
+    if (check && converged_now(Dt, O, nparts, L.flag)) return;
+    stamp(Dt, O, kern, sl++);
+    double Tc[D], Tn[D];
     {
-        const int n0 = NX, n1 = NX * T.Nn;
-        double err = (O.termCondition == 2) ? block_reduce<true>(Dt.part_err + n0, n1 - n0, sh)
-                                            : block_reduce<false>(Dt.part_err + n0, n1 - n0, sh);
-        if (threadIdx.x == 0) {
-            if (O.termCondition == 1) err = sqrt(err);
-            c->err = err;
-            stop = err < O.tol;
-            if (stop) { c->done = 1; c->status = 0; }
+        const int t = l1 - 1, nb = U::width(t);
+        if (wave < nb) load_rows<NX, NU, MD>(Dt, U::first(t) + wave, lane, t == 0, Tc);
+    }
+    for (int t = l1 - 1; t >= 1; t--) {
+        const int nb = U::width(t), nbn = nb / MD;
+        const bool act = wave < nb, act_next = wave < nbn;
+        if (act_next) load_rows<NX, NU, MD>(Dt, U::first(t - 1) + wave, lane, t - 1 == 0, Tn);
+        if (act) {
+            const int ii = U::first(t) + wave;
+            const double *kids = nullptr;
+            if (t < l1 - 1) kids = L.sch + (U::first(t + 1) + MD * wave) * U::SCH;
+            else if (l1 < T.Nh) kids = Dt.Sbuf + (size_t)U::kid0(ii) * U::SCH;
+            backward_block<NX, NU, MD>(Dt, O, ii, lane, Tc, kids, L.wave, L.sch + ii * U::SCH);
         }
-        __syncthreads();
-        if (stop) return;
+        lds_barrier();
+        if (act_next) {
+#pragma unroll
+            for (int j = 0; j < D; j++) Tc[j] = Tn[j];
+        }
+        stamp(Dt, O, kern, sl++);
     }
-    stamp(Dt, O, 1, sl++);
-    for (int l = lcut - 1; l >= 1; l--) {
-        const int nb = U::width(l), f0 = U::first(l);
-        for (int b = wave; b < nb; b += FAST_WAVES) fast_factor<NX, NU, MD>(Dt, O, f0 + b, T.Np, lane, lds, false);
-        __syncthreads();
-        stamp(Dt, O, 1, sl++);
+    if (wave == 0) {
+        const double *kids = nullptr;
+        if (l1 > 1) kids = L.sch + 1 * U::SCH;
+        else if (l1 < T.Nh) kids = Dt.Sbuf + (size_t)1 * U::SCH;
+        root_block<NX, NU, MD>(Dt, O, lane, Tc, kids, L.dl);
     }
-    if (wave == 0) fast_factor<NX, NU, MD>(Dt, O, 0, T.Np, lane, lds, true);
-    __syncthreads();
-    stamp(Dt, O, 1, sl++);
-    for (int l = 1; l < lcut; l++) {
-        const int nb = U::width(l), f0 = U::first(l);
-        for (int b = wave; b < nb; b += FAST_WAVES) fast_forward<NX, NU, MD>(Dt, f0 + b, lane);
-        __syncthreads();
-        stamp(Dt, O, 1, sl++);
+    __syncthreads();                             /* factors written above are re-read below */
+    stamp(Dt, O, kern, sl++);
+    for (int t = 1; t < l1; t++) {
+        const int nb = U::width(t);
+        if (wave < nb) {
+            const int ii = U::first(t) + wave;
+            FwdRegs<NX, NU, MD> F;
+            load_fwd<NX, NU, MD>(Dt, ii, lane, F);
+            const int par = (ii - 1) / MD, pos = ((ii - 1) % MD) * NX;
+            forward_block<NX, NU, MD>(Dt, ii, lane, F, L.dl + par * D + pos, L.dl + ii * D);
+        }
+        lds_barrier();
+        stamp(Dt, O, kern, sl++);
     }
-    /* first trial: nodes of levels 0 .. lcut-1 (their own and their children's duals are final) */
-    const double *lamc = c->cur ? Dt.lam1 : Dt.lam0;
-    double *lamn = c->cur ? Dt.lam0 : Dt.lam1;
-    const int ntop = U::first(lcut);
-    for (int k = wave; k < ntop; k += FAST_WAVES) fast_stage<NX, NU, MD>(Dt, k, T.Np, lane, lds, 1.0, lamc, lamn);
-    __syncthreads();
-    stamp(Dt, O, 1, sl++);
     if (threadIdx.x == 0) { c->tau = 1.0; c->tauPrev = 0.0; c->ls_iter = 1; c->ls_pending = 1; }
 }
 
-/* f_down: one workgroup per subtree: forward sweep top-down, then the first trial for its nodes */
+/* f_fwd: one workgroup per subtree of block levels [l0, l1): forward sweep top-down */
 template <int NX, int NU, int MD>
-__global__ void __launch_bounds__(FAST_WAVES * WAVE) f_down(Tree T, Data Dt, Opts O, int lcut, int h) {
+__global__ void __launch_bounds__(FW * WAVE) f_fwd(Tree T, Data Dt, Opts O, int l0, int l1, int kern, int h) {
     using U = Uni<NX, NU, MD>;
+    constexpr int D = U::D;
+    extern __shared__ __attribute__((aligned(16))) double lds_all[];
+    if (!phase_trial(Dt.ctrl, h, 1)) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    TierLds<NX, NU, MD> L(lds_all, wave);
+    const int s = blockIdx.x, th = l1 - l0;
+    int sl = 0;
+    stamp(Dt, O, kern, sl++);
+    FwdRegs<NX, NU, MD> Fc, Fn;
+    if (wave == 0) load_fwd<NX, NU, MD>(Dt, U::first(l0) + s, lane, Fc);
+    for (int t = 0; t < th; t++) {
+        const int nb = U::width(t), nbn = nb * MD;
+        const bool act = wave < nb, act_next = t + 1 < th && wave < nbn;
+        if (act_next) load_fwd<NX, NU, MD>(Dt, U::first(l0 + t + 1) + s * nbn + wave, lane, Fn);
+        if (act) {
+            const int ii = U::first(l0 + t) + s * nb + wave;
+            const int loc = U::first(t) + wave;
+            const double *delta;
+            if (t == 0) delta = Dt.dlam + NX * ii;                                   /* parent in the tier above: memory */
+            else delta = L.dl + (U::first(t - 1) + wave / MD) * D + (wave % MD) * NX;   /* parent in this tier: LDS */
+            forward_block<NX, NU, MD>(Dt, ii, lane, Fc, delta, L.dl + loc * D);
+        }
+        lds_barrier();
+        if (act_next) Fc = Fn;
+        stamp(Dt, O, kern, sl++);
+    }
+}
+
+/* f_stage: trial point lam_cur + (tau - tauPrev) dlam for every node, one wave per node: stage QP by
+ * clipping, elimination vectors, dual-function term; writes lam_next.  All loads are issued before
+ * the first dependent use. */
+template <int NX, int NU, int MD>
+__global__ void __launch_bounds__(FW * WAVE) f_stage(Tree T, Data Dt, Opts O, int kern, int h, int trial) {
+    using U = Uni<NX, NU, MD>;
+    constexpr int D = U::D;
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     const Ctrl *c = Dt.ctrl;
-    if (!phase_trial(c, h, 1)) return;
+    if (!phase_trial(c, h, trial)) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    double *lds = lds_all + wave * U::WAVE_LDS;
-    const int s = blockIdx.x, Nh = T.Nh, depth = Nh - lcut;
-    int sl = 0;
-    stamp(Dt, O, 2, sl++);
-    for (int t = 0; t < depth; t++) {
-        const int nb = U::width(t), f0 = U::first(lcut + t) + s * nb;
-        for (int b = wave; b < nb; b += FAST_WAVES) fast_forward<NX, NU, MD>(Dt, f0 + b, lane);
-        __syncthreads();
-        stamp(Dt, O, 2, sl++);
-    }
+    const int k = blockIdx.x * FW + wave;
+    stamp(Dt, O, kern, 0);
+    if (k >= T.Nn) return;
+    double *lds = lds_all + wave * (D + NX + 8);
     const double *lamc = c->cur ? Dt.lam1 : Dt.lam0;
     double *lamn = c->cur ? Dt.lam0 : Dt.lam1;
-    for (int t = 0; t <= depth; t++) {                 /* node levels lcut .. Nh (leaves included) */
-        const int nb = U::width(t), f0 = U::first(lcut + t) + s * nb;
-        for (int b = wave; b < nb; b += FAST_WAVES) fast_stage<NX, NU, MD>(Dt, f0 + b, T.Np, lane, lds, 1.0, lamc, lamn);
+    const double step = c->tau - c->tauPrev;
+    const bool parent = k < T.Np;
+    const int nuk = parent ? NU : 0;
+    const int xo = NX * k, uo = NU * k, ko = U::bo(k);
+    const bool isx = lane < NX, live = lane < NX + nuk;
+    const int j = isx ? lane : lane - NX;
+    /* loads */
+    double lkv = 0.0, dkv = 0.0, bkv = 0.0, lo_ = 0.0, do_ = 0.0;
+    if (parent && lane < D) { lkv = lamc[ko + lane]; dkv = Dt.dlam[ko + lane]; bkv = Dt.b[ko + lane]; }
+    if (isx && k > 0) { lo_ = lamc[xo + lane]; do_ = Dt.dlam[xo + lane]; }
+    double col[MD][NX];
+    if (parent && live) {
+#pragma unroll
+        for (int cc = 0; cc < MD; cc++) {
+            const int kid = U::kid0(k) + cc;
+            const double *cp = isx ? Dt.A + (size_t)(kid - 1) * NX * NX + (size_t)j * NX
+                                   : Dt.B + (size_t)(kid - 1) * NX * NU + (size_t)j * NX;
+#pragma unroll
+            for (int i = 0; i < NX; i++) col[cc][i] = cp[i];
+        }
     }
-    __syncthreads();
-    stamp(Dt, O, 2, sl++);
+    double lin = 0.0, winv = 0.0, wd = 0.0, lob = 0.0, hib = 0.0;
+    if (live) {
+        if (isx) { lin = Dt.q[xo + j]; winv = Dt.Qinv[xo + j]; wd = Dt.Qd[xo + j]; lob = Dt.xmin[xo + j]; hib = Dt.xmax[xo + j]; }
+        else { lin = Dt.r[uo + j]; winv = Dt.Rinv[uo + j]; wd = Dt.Rd[uo + j]; lob = Dt.umin[uo + j]; hib = Dt.umax[uo + j]; }
+    }
+    /* trial multipliers */
+    double *lk = lds, *lown = lds + D;
+    double p_c = 0.0;
+    if (parent && lane < D) { const double v = fma(step, dkv, lkv); lk[lane] = v; p_c = bkv * v; }
+    if (isx) {
+        double v = 0.0;
+        if (k > 0) { v = fma(step, do_, lo_); lamn[xo + lane] = v; }
+        lown[lane] = v;
+    }
+    lds_fence();
+    double p_q = 0.0, p_h = 0.0;
+    if (live) {
+        double v = isx ? fma(-1.0, lin, lown[j]) : -1.0 * lin;
+        if (parent) {
+#pragma unroll
+            for (int cc = 0; cc < MD; cc++) {
+                double acc = 0.0;
+#pragma unroll
+                for (int i = 0; i < NX; i++) acc = fma(col[cc][i], lk[cc * NX + i], acc);
+                v = fma(-1.0, acc, v);
+            }
+        }
+        const double unc = winv * v;
+        double val, cal;
+        if (unc >= hib) { val = hib; cal = 0.0; } else if (unc <= lob) { val = lob; cal = 0.0; } else { val = unc; cal = winv; }
+        if (isx) { Dt.qmod[xo + j] = v; Dt.xUnc[xo + j] = unc; Dt.x[xo + j] = val; Dt.QinvCal[xo + j] = cal; }
+        else { Dt.rmod[uo + j] = v; Dt.uUnc[uo + j] = unc; Dt.u[uo + j] = val; Dt.RinvCal[uo + j] = cal; }
+        p_q = (wd * val) * val;
+        p_h = v * val;
+    }
+    /* dual-function term (clipping.c:371-381): x part then u part, summed per part */
+    const double qx = wave_sum(isx ? p_q : 0.0), hx = wave_sum(isx ? p_h : 0.0);
+    const double ru = wave_sum(isx ? 0.0 : p_q), hu = wave_sum(isx ? 0.0 : p_h);
+    p_c = wave_sum(p_c);
+    if (lane == 0) {
+        double f = -0.5 * qx - p_c;
+        f += hx;
+        f -= 0.5 * ru;
+        f += hu;
+        Dt.fval[k] = f;
+    }
+    stamp(Dt, O, kern, 1);
 }
