@@ -212,15 +212,17 @@ __global__ void __launch_bounds__(WAVE) k_stage(Tree T, Data D, int mode, int h,
 /* ------------------------------------------------------------------------------------------ */
 template <bool IS_MAX>
 __device__ double block_reduce(const double *v, int n, double *sh) {
+    /* strided per-thread partials, wave shuffle tree, then the (<= 16) wave results in order */
     double acc = 0.0;
     for (int i = threadIdx.x; i < n; i += blockDim.x) acc = IS_MAX ? fmax(acc, v[i]) : acc + v[i];
-    sh[threadIdx.x] = acc;
+    acc = IS_MAX ? wave_max(acc) : wave_sum(acc);
+    __syncthreads();                                   /* sh may still be read from a previous call */
+    if ((threadIdx.x & (WAVE - 1)) == 0) sh[threadIdx.x >> 6] = acc;
     __syncthreads();
-    for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) sh[threadIdx.x] = IS_MAX ? fmax(sh[threadIdx.x], sh[threadIdx.x + s]) : sh[threadIdx.x] + sh[threadIdx.x + s];
-        __syncthreads();
-    }
-    return sh[0];
+    double r = 0.0;
+    const int nw = (blockDim.x + WAVE - 1) / WAVE;
+    for (int w = 0; w < nw; w++) r = IS_MAX ? fmax(r, sh[w]) : r + sh[w];
+    return r;
 }
 
 /* first sweep of a solve: fval0 = sum of the node terms */

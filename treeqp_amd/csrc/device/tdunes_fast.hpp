@@ -43,7 +43,8 @@ struct Uni {
     static constexpr int SCH = NX * NX + NX; /* Schur hand-off record: S (NX x NX) then v (NX) */
     static constexpr int TH = (MD == 2) ? 3 : ((MD <= 4) ? 2 : 1);     /* tier height: MD^(TH-1) <= FW */
     static constexpr int NBT = (MD == 2) ? 7 : (1 + MD);               /* blocks of a full tier subtree */
-    static constexpr int WAVE_LDS = (NX + 1) * LDW + D + NX + 8;       /* per-wave scratch (doubles) */
+    static constexpr int WAVE_LDS = (D + 1) * LDW + D + NX + 8;        /* per-wave scratch (doubles) */
+    static_assert(D % 4 == 0 && NX < 16, "Schur MFMA tile needs D % 4 == 0 and NX < 16");
     static constexpr int TIER_LDS = NBT * SCH + NBT * D + FW * WAVE_LDS + 16;   /* doubles per workgroup */
     static_assert(D <= 16, "the MFMA tile path needs a dual block of at most 16 rows");
     static_assert(R <= 64, "tall matrix must fit one wavefront");
@@ -238,20 +239,25 @@ __device__ __forceinline__ void store_block(const Data &Dt, int ii, int lane, co
         for (int j = 0; j < D; j++) lds[(lane - D) * LDW + j] = T[j];
     }
     lds_fence();
-    if (lane < NX * NX) {
-        const int i = lane % NX, j = lane / NX;
-        const double *ri = lds + (1 + i) * LDW, *rj = lds + (1 + j) * LDW;
-        double acc = 0.0;
+    /* [S | v] = CUt * [CUt' | y] as one f64 MFMA tile (K = D): lane (i, g) feeds row 1+i of the
+     * scratch as A and row 1+i (i < NX) or row 0 (= y, i == NX) as B */
+    {
+        const int i = lane & 15, g = lane >> 4;
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int c = 0; c < D; c++) acc = fma(ri[c], rj[c], acc);
-        sdst[i + j * NX] = acc;
-    }
-    if (lane < NX) {
-        const double *ri = lds + (1 + lane) * LDW;
-        double acc = 0.0;
+        for (int st = 0; st < D / 4; st++) {
+            const int kk = g + 4 * st;
+            const double m = (i <= NX) ? lds[(i < NX ? 1 + i : 0) * LDW + kk] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(i < NX ? m : 0.0, m, acc, 0, 0, 0);
+        }
 #pragma unroll
-        for (int c = 0; c < D; c++) acc = fma(ri[c], lds[c], acc);
-        sdst[NX * NX + lane] = acc;
+        for (int rr = 0; rr < 4; rr++) {
+            const int ip = g + 4 * rr;                 /* acc[rr] = [S | v][ip][i] */
+            if (ip < NX) {
+                if (i < NX) sdst[ip + i * NX] = acc[rr];
+                else if (i == NX) sdst[NX * NX + ip] = acc[rr];
+            }
+        }
     }
     lds_fence();
 }
@@ -307,7 +313,7 @@ __device__ __forceinline__ void backward_block(const Data &Dt, const Opts &O, in
 /* root: factor [W_0 ; resMod_0'], then dlam_0 = L^-T y (k descending), dot-product partial */
 template <int NX, int NU, int MD>
 __device__ __forceinline__ void root_block(const Data &Dt, const Opts &O, int lane, double (&T)[Uni<NX, NU, MD>::D],
-                                           const double *kids_sch, double *dl_out) {
+                                           const double *kids_sch, double *lds, double *dl_out) {
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D;
     const int bo = U::bo(0);
@@ -320,17 +326,29 @@ __device__ __forceinline__ void root_block(const Data &Dt, const Opts &O, int la
         for (int j = 0; j < D; j++) L[(size_t)j * D] = T[j];
         Dt.invd[bo + lane] = myinv;
     }
-    double y[D];
+    /* dlam_0 = L^-T y: transpose through the wave's LDS scratch so that lane i owns column i of L */
+    if (lane <= D) {
 #pragma unroll
-    for (int j = 0; j < D; j++) y[j] = rdlane(T[j], D);
+        for (int j = 0; j < D; j++) lds[lane * U::LDW + j] = T[j];
+    }
+    lds_fence();
+    double s = 0.0, Lcol[D];
+    if (lane < D) {
+        s = lds[D * U::LDW + lane];
+#pragma unroll
+        for (int k = 0; k < D; k++) Lcol[k] = lds[k * U::LDW + lane];
+    } else {
+#pragma unroll
+        for (int k = 0; k < D; k++) Lcol[k] = 0.0;
+    }
     double mine = 0.0;
 #pragma unroll
     for (int k = D - 1; k >= 0; k--) {
-        const double zk = y[k] * rdlane(myinv, k);
+        const double zk = rdlane(s * myinv, k);
         if (lane == k) mine = zk;
-#pragma unroll
-        for (int i = 0; i < k; i++) y[i] = fma(-rdlane(T[i], k), zk, y[i]);
+        if (lane < k) s = fma(-Lcol[k], zk, s);
     }
+    lds_fence();
     double pd = 0.0;
     if (lane < D) { Dt.dlam[bo + lane] = mine; dl_out[lane] = mine; pd = Dt.res[bo + lane] * mine; }
     pd = wave_sum(pd);
@@ -538,7 +556,7 @@ __global__ void __launch_bounds__(FW * WAVE) f_top(Tree T, Data Dt, Opts O, int 
         const double *kids = nullptr;
         if (l1 > 1) kids = L.sch + 1 * U::SCH;
         else if (l1 < T.Nh) kids = Dt.Sbuf + (size_t)1 * U::SCH;
-        root_block<NX, NU, MD>(Dt, O, lane, Tc, kids, L.dl);
+        root_block<NX, NU, MD>(Dt, O, lane, Tc, kids, L.wave, L.dl);
     }
     __syncthreads();                             /* factors written above are re-read below */
     stamp(Dt, O, kern, sl++);
