@@ -9,8 +9,10 @@ For N > 1 it is launched under torch.distributed.run (one rank per GPU, RCCL).
               index tables and lambda0 are resident in HBM before the timed region starts.
 * value     = Newton iterations of ALL ranks / wall time of the K steps (max over ranks).
 * workload  = BASELINE.json configs[1] ("C2"): linear-chain spring-mass tree nx=8, nu=3, 10 levels,
-              branching 2 -> 1023 nodes.  N > 1 runs one such tree per GPU
-              (independent scenario trees, weak scaling, no data-path collective).
+              branching 2 -> 1023 nodes.  N > 1, default `--mode batch`: one such tree per
+              GPU (independent scenario trees, weak scaling, no data-path collective).  `--mode shard`:
+              ONE tree, subtrees partitioned over the ranks, two small RCCL all-gathers per Newton
+              iteration (strong scaling, latency-bound by construction).
 * roofline  = algorithmic bytes of the Newton iterations (closed form of SURVEY.md §8d, evaluated
               by tqgpu_iteration_cost) / device time between HIP events recorded on the solver's own
               stream around the iteration kernels, against the 8 TB/s HBM3E peak.
@@ -77,6 +79,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["batch", "shard"], default="batch", help="N > 1: independent trees (weak) or one sharded tree (strong)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -103,6 +106,14 @@ def main():
     qp = capi.TreeQp(nx, nu, nk).fill_lti(p)
     flat = qp.flat()
     g = capi.TqGpu(nk, nx, nu, device=local_rank if world > 1 else -1).upload(flat, p.lambda0)
+    shard = world > 1 and args.mode == "shard"
+    if shard:
+        import torch
+        idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(capi.shard_unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, src=0)
+        g.shard_init(rank, world, bytes(idt.cpu().numpy().tobytes()))
 
     def barrier():
         if dist is not None:
@@ -137,7 +148,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         n = torch.tensor([float(iters)], dtype=torch.float64, device="cuda")
         dist.all_reduce(n, op=dist.ReduceOp.SUM)
-        tmax, tot_iters = float(t.item()), float(n.item())
+        tmax = float(t.item())
+        # batch: every rank solved its own tree; shard: all ranks worked on the same iterations
+        tot_iters = float(n.item()) if not shard else float(iters)
+    if shard:
+        g.shard_gather_solution()
 
     if rank == 0:
         sol = g.solution()
@@ -148,6 +163,10 @@ def main():
         ls_per_iter = ls / max(iters, 1)
         bytes_it, flops_it = g.iteration_cost(max(1, round(ls_per_iter)))
         achieved = bytes_it * iters / dev_time / 1e9
+        traffic = None
+        tf = ROOT / "profiles" / f"traffic_{args.workload}.json"
+        if tf.exists() and g.fused:
+            traffic = json.loads(tf.read_text()).get("bytes_per_iteration")     # from the committed PMC passes
         out = {
             "metric": "dual_newton_iterations_per_second",
             "value": tot_iters / tmax,
@@ -157,7 +176,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * tmax / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if shard else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -165,10 +184,13 @@ def main():
                        "ls_trials_per_iter": ls_per_iter, "ms_per_newton_iter": 1e3 * tmax / max(iters, 1),
                        "device_ms_per_newton_iter": 1e3 * dev_time / max(iters, 1),
                        "kernel_launches_per_solve": launches / args.steps, "max_kkt_residual": kkt,
-                       "parallelism": "1 tree per GPU (independent scenario trees)" if world > 1 else "single GPU"},
+                       "parallelism": ("one tree sharded by subtrees, 2 RCCL all-gathers per Newton iteration" if shard else
+                                       "1 tree per GPU (independent scenario trees), no collective") if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "all kernels of one Newton iteration (k_grad,k_check,k_hess,k_factor x levels,k_forward x levels,k_ls_*,k_stage)",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "one Newton iteration = f_back x tiers, f_top, f_fwd x tiers, f_stage, k_ls_decide (fused path)" if g.fused else
+                                   "one Newton iteration = k_grad,k_check,k_hess,k_factor x levels,k_forward x levels,k_ls_*,k_stage (generic path)",
+                         "traffic_note": "HBM-side bytes per Newton iteration (FETCH_SIZE raw + WRITE_SIZE) from profiles/traffic_<workload>.json",
                          "algorithmic_bytes_per_iteration": bytes_it, "algorithmic_flops_per_iteration": flops_it,
                          "note": "latency-bound: dependent tree-level steps dominate; working set sits in L2/Infinity Cache"},
         }

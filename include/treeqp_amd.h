@@ -97,6 +97,22 @@ int tqgpu_get_iteration_log(const tqgpu_solver *s, int *ls_iters, double *iter_t
  * trials (closed form of SURVEY.md §8(d) generalised to per-node dimensions) */
 int tqgpu_iteration_cost(const tqgpu_solver *s, int n_ls, double *bytes, double *flops);
 
+/* ---- one tree sharded over several devices --------------------------------------
+ * Every rank creates a mirror of the WHOLE tree and uploads the whole problem; tqgpu_shard_init then
+ * restricts the rank's work to a contiguous range of subtrees (tiers above the partition boundary
+ * are replicated).  Per Newton iteration two small in-place all-gathers over RCCL exchange the
+ * boundary Schur records + termination partials and the {fval, dot} partials + boundary x/QinvCal.
+ * id128: 128-byte RCCL unique id created by rank 0 (tqgpu_shard_unique_id) and broadcast by the
+ * caller (e.g. through torch.distributed); NULL creates a "virtual rank" without a communicator. */
+int tqgpu_shard_unique_id(void *id128);
+int tqgpu_shard_init(tqgpu_solver *s, int rank, int nranks, const void *id128);
+int tqgpu_shard_gather_solution(tqgpu_solver *s);
+/* test / diagnostic: n virtual ranks of one tree in one process on one device, lock-step */
+int tqgpu_solve_virtual_ranks(tqgpu_solver **ranks, int n, const tqgpu_opts *opts, tqgpu_result *res);
+
+/* diagnostic in-kernel time stamps of the last fused iteration (TREEQP_AMD_STAMPS=1) */
+int tqgpu_get_stamps(tqgpu_solver *s, unsigned long long *out, int cap);
+
 /* sizeof() of the public structs (0 dmat, 1 dvec, 2 node, 3 tree_qp_in, 4 tree_qp_out,
  * 5 tdunes opts, 6 tdunes workspace, 7 profiling record, 8 qp_internal_t) for FFI self-checks */
 int treeqp_amd_sizeof(int which);

@@ -1,0 +1,103 @@
+"""N > 1 paths on CPU (gloo, world_size 2): the sharded-mode exchange protocol and the bench harness'
+reductions.  The solver itself has no CPU path; these tests cover what runs on the host side of the
+multi-GPU modes: the partition plan (treeqp_amd/sharding.py mirrors shard_build_lists), the in-place
+rank-ordered all-gathers and the "identical decision on every rank" property."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from treeqp_amd import sharding
+
+
+def test_plan_covers_every_node_exactly_once():
+    for md, Nh, n in [(2, 9, 2), (2, 9, 4), (2, 9, 8), (2, 11, 8), (2, 6, 8), (3, 4, 3)]:
+        plans = [sharding.plan(md, Nh, n, r) for r in range(n)]
+        Nn = sharding.first_of_level(md, Nh + 1)
+        owned = np.concatenate([p.owned_nodes for p in plans])
+        repl = plans[0].replicated_nodes
+        assert len(np.unique(owned)) == len(owned)                      # no node owned twice
+        assert np.array_equal(np.sort(np.concatenate([owned, repl])), np.arange(Nn))
+        lb = plans[0].lb
+        f0, gb = sharding.first_of_level(md, lb), md ** lb
+        starts = [p.boundary_range[0] for p in plans]
+        assert starts == [f0 + r * gb // n for r in range(n)]           # rank-ordered contiguous ranges
+        # replicated G+H blocks are counted for the termination norm by rank 0 only
+        assert plans[0].gh_counted == len(plans[0].gh_list)
+        assert all(p.gh_counted == len(p.gh_list) - len(repl) for p in plans[1:])
+        # C2 / 8 ranks: one 72-double Schur record per rank (SURVEY §8e "nx^2 + nx doubles")
+    p8 = sharding.plan(2, 9, 8, 3)
+    assert p8.lb == 3 and p8.boundary_range == (7 + 3, 1) and p8.exchange_doubles["exchange1"] == 8 * 73
+
+
+def test_plan_rejects_too_many_ranks():
+    with pytest.raises(ValueError):
+        sharding.plan(2, 3, 64, 0)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        md, Nh, nx = 2, 9, 8
+        pl = sharding.plan(md, Nh, world, rank, nx)
+        Nn = sharding.first_of_level(md, Nh + 1)
+        sch = nx * nx + nx
+        # exchange 1: in-place all-gather of the boundary Schur records (rank r fills its own range)
+        f0, w = pl.boundary_range
+        fb, gb = sharding.first_of_level(md, pl.lb), md ** pl.lb
+        sbuf = torch.full((Nn * sch,), float("nan"), dtype=torch.float64)
+        sbuf[f0 * sch:(f0 + w) * sch] = torch.arange(f0 * sch, (f0 + w) * sch, dtype=torch.float64)
+        region = sbuf[fb * sch:(fb + gb) * sch]
+        dist.all_gather_into_tensor(region, region[rank * w * sch:(rank + 1) * w * sch].clone())
+        ok1 = bool(torch.equal(region, torch.arange(fb * sch, (fb + gb) * sch, dtype=torch.float64)))
+        # termination partials: max in rank order is the global max on every rank
+        xerr = torch.zeros(world, dtype=torch.float64)
+        mine = torch.tensor([0.25 + rank], dtype=torch.float64)
+        dist.all_gather_into_tensor(xerr, mine)
+        # exchange 2: {fval, dot} partials summed in RANK ORDER -> bitwise identical decision input
+        xs = torch.zeros(2 * world, dtype=torch.float64)
+        part = torch.tensor([1e16 * (rank == 0) + 1.0 + rank * 1e-3, -3.0 * (rank + 1)], dtype=torch.float64)
+        dist.all_gather_into_tensor(xs, part)
+        f = 0.0
+        d = 0.0
+        for r in range(world):
+            f += float(xs[2 * r])
+            d += float(xs[2 * r + 1])
+        # bench harness reductions (max time, summed iterations)
+        t = torch.tensor([1.0 + rank], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        n = torch.tensor([3.0 * 10], dtype=torch.float64)
+        dist.all_reduce(n, op=dist.ReduceOp.SUM)
+        dist.barrier()
+        q.put((rank, ok1, float(xerr.max()), f.hex() if hasattr(f, "hex") else f, d, float(t), float(n)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_world2_exchange_protocol():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, ok0, e0, f0, d0, t0, n0), (r1, ok1, e1, f1, d1, t1, n1) = out
+    assert ok0 and ok1                          # both ranks hold every boundary record after the gather
+    assert e0 == e1 == 1.25                     # same termination norm everywhere
+    assert f0 == f1 and d0 == d1                # rank-ordered sums: bitwise identical on both ranks
+    assert t0 == t1 == 2.0 and n0 == n1 == 60.0  # bench: max time over ranks, summed iterations

@@ -311,3 +311,66 @@ def test_fused_path_multi_trial_line_search(gpu, orc):
     assert fused and rf["status"] == 0
     assert rf["iter"] == ref["iter"] and rf["ls_total"] == ref["ls_total"]
     assert_solution_close(sf, ref, 1e-9)
+
+
+# --- one tree sharded over several (virtual) ranks -----------------------------------------------
+
+SHARD_CASES = [
+    ("c2_1023_n2", lambda: P.linear_chain(2, 9, 9), 2),
+    ("c2_1023_n4", lambda: P.linear_chain(2, 9, 9), 4),
+    ("c2_1023_n8", lambda: P.linear_chain(2, 9, 9), 8),
+    ("chain_h7_n2_tight", lambda: P.linear_chain(2, 7, 7, ubound=0.2), 2),
+    ("chain_h6_n8", lambda: P.linear_chain(2, 6, 6), 8),
+    ("spring_4_1_2_h7_n4", lambda: P.spring_mass(md=2, Nr=7, Nh=7), 4),
+]
+
+
+@pytest.mark.parametrize("name,make,n", SHARD_CASES, ids=[c[0] for c in SHARD_CASES])
+def test_sharded_virtual_ranks_match_single_device(gpu, orc, name, make, n):
+    """subtrees partitioned over n ranks, replicated top, two small exchanges per Newton
+    iteration.  The ranks are mirrors in one process on one GPU (device copies instead of RCCL), which
+    exercises the partition lists, workgroup offsets, exchange ranges and the rank-ordered decisions."""
+    p = make()
+    flat = oracle_flat_from_lti(orc, p)
+    ref = orc.solve(flat, lambda0=p.lambda0)
+    single, ssol, _ = _solve_flat_tq(gpu, flat, p.lambda0, "auto")
+    mirrors = [gpu.TqGpu(flat["nk"], flat["nx"], flat["nu"]).upload(flat, p.lambda0).shard_init(r, n) for r in range(n)]
+    res = gpu.solve_virtual_ranks(mirrors)
+    assert res["status"] == ref["status"] == 0
+    assert res["iter"] == ref["iter"] == single["iter"]
+    assert res["ls_total"] == ref["ls_total"]
+    for m in mirrors:                       # every rank ends with the full, identical solution
+        sol = m.solution()
+        assert_solution_close(sol, ref, TOL)
+        assert_solution_close(sol, ssol, 1e-11)
+        assert orc.max_kkt(flat, sol) < 1e-8
+    for m in mirrors:
+        m.close()
+
+
+def test_sharded_virtual_ranks_backtracking(gpu, orc):
+    p = P.linear_chain(2, 6, 6, ubound=0.1)
+    flat = oracle_flat_from_lti(orc, p)
+    rng = np.random.Generator(np.random.PCG64(2))
+    lam0 = 10.0 * rng.standard_normal(len(p.lambda0))
+    ref = orc.solve(flat, lambda0=lam0)
+    mirrors = [gpu.TqGpu(flat["nk"], flat["nx"], flat["nu"]).upload(flat, lam0).shard_init(r, 4) for r in range(4)]
+    res = gpu.solve_virtual_ranks(mirrors)
+    assert res["status"] == 0 and res["iter"] == ref["iter"] and res["ls_total"] == ref["ls_total"]
+    assert_solution_close(mirrors[3].solution(), ref, 1e-9)
+    for m in mirrors:
+        m.close()
+
+
+def test_shard_init_rejects_bad_configs(gpu):
+    f = P.irregular_clipping_qp()
+    g = gpu.TqGpu(f.nk, f.nx, f.nu)
+    with pytest.raises(RuntimeError, match="fused"):
+        g.shard_init(0, 2)
+    g.close()
+    p = P.linear_chain(2, 3, 3)
+    nx, nu, nk = lti_dims(p)
+    g = gpu.TqGpu(nk, nx, nu)
+    with pytest.raises(RuntimeError, match="too small"):
+        g.shard_init(0, 64)
+    g.close()

@@ -394,6 +394,31 @@ class TdunesSolver:
 # TqGpu: the device C-ABI proper (include/treeqp_amd.h)
 # ------------------------------------------------------------------------------------------------
 
+def shard_unique_id() -> bytes:
+    """128-byte RCCL unique id (call on rank 0, broadcast to the other ranks)."""
+    buf = C.create_string_buffer(128)
+    rc = lib().tqgpu_shard_unique_id(buf)
+    if rc != 0:
+        raise RuntimeError(f"tqgpu_shard_unique_id failed ({rc}): {lib().tqgpu_last_error().decode()}")
+    return buf.raw
+
+
+def solve_virtual_ranks(mirrors, **kw) -> dict:
+    """Lock-step sharded solve of n mirrors of one problem in this process (diagnostic / tests)."""
+    o = GpuOpts(maxIter=100, termCondition=2, stationarityTolerance=1e-8, regType=2, regTol=1e-6, regValue=1e-6,
+                lineSearchMaxIter=50, lineSearchGamma=0.1, lineSearchBeta=0.6, lineSearchRestartTrigger=-1, profile=0)
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise KeyError(k)
+        setattr(o, k, v)
+    arr = (C.c_void_p * len(mirrors))(*[m.h for m in mirrors])
+    r = GpuResult()
+    rc = lib().tqgpu_solve_virtual_ranks(arr, len(mirrors), C.byref(o), C.byref(r))
+    if rc != 0:
+        raise RuntimeError(f"tqgpu_solve_virtual_ranks failed ({rc}): {lib().tqgpu_last_error().decode()}")
+    return {f: getattr(r, f) for f, _ in GpuResult._fields_}
+
+
 class TqGpu:
     def __init__(self, nk, nx, nu, device: int = -1):
         L = lib()
@@ -459,6 +484,17 @@ class TqGpu:
         b, f = C.c_double(), C.c_double()
         self._chk(lib().tqgpu_iteration_cost(self.h, int(n_ls), C.byref(b), C.byref(f)))
         return b.value, f.value
+
+    # ---- one tree sharded over several devices ----
+    def shard_init(self, rank: int, nranks: int, unique_id: bytes | None = None):
+        """Restrict this mirror to rank `rank` of `nranks`.  unique_id: 128-byte RCCL id from
+        ``shard_unique_id()`` of rank 0 (broadcast by the caller); None = virtual rank (no communicator)."""
+        buf = None if unique_id is None else C.create_string_buffer(bytes(unique_id), 128)
+        self._chk(lib().tqgpu_shard_init(self.h, int(rank), int(nranks), buf))
+        return self
+
+    def shard_gather_solution(self):
+        self._chk(lib().tqgpu_shard_gather_solution(self.h))
 
     def close(self):
         if self.h:

@@ -28,6 +28,7 @@
  * returns if its phase is not due, so the host may enqueue ahead without reading back.
  */
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -499,47 +500,94 @@ __global__ void __launch_bounds__(256) k_ls_begin(Tree T, Data D, int h) {
     }
 }
 
+/* Armijo test and iteration bookkeeping for the trial whose dual value is f (line_search :973-1000) */
+__device__ void ls_decide_tail(Ctrl *c, const Data &D, const Opts &O, double f) {
+    c->cur ^= 1;                       /* the trial point is now the current point */
+    c->fval = f;
+    int finished = 0, lsIter = c->ls_iter;
+    if (c->restart_counter == O.lsRestartTrigger) finished = 1;                        /* :973 */
+    else if (f <= c->fval0 + O.gamma * c->tau * c->dot) finished = 1;                  /* :982 */
+    else {
+        c->tauPrev = c->tau;
+        c->tau = O.beta * c->tauPrev;
+        if (lsIter + 1 > O.lsMaxIter) { finished = 1; lsIter = lsIter + 1; }           /* loop exhausted */
+        else c->ls_iter = lsIter + 1;
+    }
+    if (finished) {
+        if (lsIter >= O.lsMaxIter) c->restart_counter++; else c->restart_counter = 0;  /* :993-1000 */
+        c->ls_pending = 0;
+        c->ls_last = lsIter;
+        c->ls_total += lsIter;
+        if (c->iter < D.ls_log_cap) D.ls_log[c->iter] = lsIter;
+        c->iter += 1;
+        c->fval0 = f;                  /* same point, same sweep => identical to a re-evaluation */
+        if (c->iter >= O.maxIter) { c->done = 1; c->status = 1; }                      /* MAXIMUM_ITERATIONS */
+    }
+}
+
+/* direction test (:944-954); returns true when the solve must stop with NOT_DESCENT_DIRECTION */
+__device__ bool ls_not_descent(Ctrl *c, double dotp) {
+    c->dot = dotp;
+    const bool bad = (dotp > 1e-10 || !((dotp > 1e-10) || (dotp < 1e-10)));
+    if (bad) { c->done = 1; c->status = 2; c->ls_pending = 0; }
+    return bad;
+}
+
 __global__ void __launch_bounds__(256) k_ls_decide(Tree T, Data D, Opts O, int h, int t, int with_descent_check) {
     __shared__ double sh[256];
     __shared__ int bail;
     Ctrl *c = D.ctrl;
     if (!phase_trial(c, h, t)) return;
     if (with_descent_check) {
-        /* fused path: the first trial was evaluated speculatively; test the direction now (:944-954) */
+        /* fused path: the first trial was evaluated speculatively; test the direction now */
         const double s = block_reduce<false>(D.part_dot, T.Np, sh);
-        if (threadIdx.x == 0) {
-            const double dotp = -s;
-            c->dot = dotp;
-            bail = (dotp > 1e-10 || !((dotp > 1e-10) || (dotp < 1e-10)));
-            if (bail) { c->done = 1; c->status = 2; c->ls_pending = 0; }
-        }
+        if (threadIdx.x == 0) bail = ls_not_descent(c, -s);
         __syncthreads();
         if (bail) return;
     }
     const double f = block_reduce<false>(D.fval, T.Nn, sh);
-    if (threadIdx.x == 0) {
-        c->cur ^= 1;                       /* the trial point is now the current point */
-        c->fval = f;
-        int finished = 0, lsIter = c->ls_iter;
-        if (c->restart_counter == O.lsRestartTrigger) finished = 1;                        /* :973 */
-        else if (f <= c->fval0 + O.gamma * c->tau * c->dot) finished = 1;                  /* :982 */
-        else {
-            c->tauPrev = c->tau;
-            c->tau = O.beta * c->tauPrev;
-            if (lsIter + 1 > O.lsMaxIter) { finished = 1; lsIter = lsIter + 1; }           /* loop exhausted */
-            else c->ls_iter = lsIter + 1;
-        }
-        if (finished) {
-            if (lsIter >= O.lsMaxIter) c->restart_counter++; else c->restart_counter = 0;  /* :993-1000 */
-            c->ls_pending = 0;
-            c->ls_last = lsIter;
-            c->ls_total += lsIter;
-            if (c->iter < D.ls_log_cap) D.ls_log[c->iter] = lsIter;
-            c->iter += 1;
-            c->fval0 = f;                  /* same point, same sweep => identical to a re-evaluation */
-            if (c->iter >= O.maxIter) { c->done = 1; c->status = 1; }                      /* MAXIMUM_ITERATIONS */
-        }
+    if (threadIdx.x == 0) ls_decide_tail(c, D, O, f);
+}
+
+/* ---- sharded mode (one tree over several devices): rank-local partials and the decision from the
+ * gathered per-rank records; sums run in rank order so that every rank takes the same decision ---- */
+__global__ void __launch_bounds__(256) k_shard_pack1(Data D, int nlocal, double *xerr, int rank, int termCondition, int h) {
+    __shared__ double sh[256];
+    if (!phase_main(D.ctrl, h)) return;
+    const double e = (termCondition == 2) ? block_reduce<true>(D.part_err, nlocal, sh) : block_reduce<false>(D.part_err, nlocal, sh);
+    if (threadIdx.x == 0) xerr[rank] = e;
+}
+
+__global__ void __launch_bounds__(WAVE) k_shard_pack2(Data D, const int *nodes, int n_nodes, const int *blocks, int n_blocks,
+                                                     double *xs, int rank, int b0, int bn, int own0, int ownn, int h, int t) {
+    const Ctrl *c = D.ctrl;
+    if (!phase_trial(c, h, t)) return;
+    /* The duals of the boundary nodes live in REPLICATED blocks but each boundary node is staged by its
+     * owner only: every rank advances the slices of the boundary nodes it does not own itself (same
+     * fma on the same replicated lam / dlam, hence identical values on every rank). */
+    {
+        const double *lamc = c->cur ? D.lam1 : D.lam0;
+        double *lamn = c->cur ? D.lam0 : D.lam1;
+        const double step = c->tau - c->tauPrev;
+        for (int e = threadIdx.x; e < bn; e += WAVE)
+            if (e < own0 || e >= own0 + ownn) lamn[b0 + e] = fma(step, D.dlam[b0 + e], lamc[b0 + e]);
     }
+    /* fixed order: lane-strided partials then the shuffle tree */
+    double f = 0.0, d = 0.0;
+    for (int i = threadIdx.x; i < n_nodes; i += WAVE) f += D.fval[nodes[i]];
+    for (int i = threadIdx.x; i < n_blocks; i += WAVE) d += D.part_dot[blocks[i]];
+    f = wave_sum(f); d = wave_sum(d);
+    if (threadIdx.x == 0) { xs[2 * rank] = f; xs[2 * rank + 1] = d; }
+}
+
+__global__ void __launch_bounds__(WAVE) k_ls_decide_parts(Data D, Opts O, const double *xs, int nranks, int h, int t, int with_descent_check) {
+    Ctrl *c = D.ctrl;
+    if (!phase_trial(c, h, t)) return;
+    if (threadIdx.x != 0) return;
+    double f = 0.0, d = 0.0;
+    for (int r = 0; r < nranks; r++) { f += xs[2 * r]; d += xs[2 * r + 1]; }
+    if (with_descent_check && ls_not_descent(c, -d)) return;
+    ls_decide_tail(c, D, O, f);
 }
 
 #include "tdunes_fast.hpp"
@@ -588,6 +636,14 @@ struct tqgpu_solver {
     std::vector<int> tier_l0, tier_l1, tier_grid;
     size_t lds_fast = 0, lds_fstage = 0;
     int use_fast = 1;         /* can be switched off (TREEQP_AMD_PATH=generic) */
+    /* sharded mode */
+    int nranks = 1, rank = 0, part_top = -1;      /* part_top: highest partitioned tier */
+    int *d_gh_list = nullptr, *d_node_list = nullptr, *d_node_cnt_list = nullptr, *d_blk_list = nullptr;
+    int gh_n = 0, gh_counted = 0, n_nodes = 0, n_nodes_counted = 0, n_blk_counted = 0;
+    double *d_xerr = nullptr, *d_xs = nullptr;
+    int bnd_b0 = 0, bnd_bn = 0, bnd_own0 = 0, bnd_ownn = 0;   /* element ranges of the boundary nodes' duals */
+    void *shard_slab = nullptr;
+    void *comm = nullptr;     /* RCCL communicator (nullptr: single device or virtual ranks) */
     int chunk = 4;            /* Newton iterations enqueued per status read-back */
 };
 
@@ -724,48 +780,192 @@ void detect_fast(tqgpu_solver *s) {
     }
 }
 
-void launch_fast_iteration(tqgpu_solver *s, const Opts &O, int h, int &launches) {
+/* ---- RCCL, loaded lazily so that single-device users do not depend on it ---- */
+struct RcclApi {
+    void *lib = nullptr;
+    struct UniqueId { char internal[128]; };
+    int (*GetUniqueId)(UniqueId *) = nullptr;
+    int (*CommInitRank)(void **, int, UniqueId, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+
+int rccl_load() {
+    if (g_rccl.lib) return TQGPU_OK;
+    const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void *lib = nullptr;
+    for (const char *n : names) if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!lib) return fail(TQGPU_ECOMM, std::string("cannot load librccl.so: ") + dlerror());
+#define SYM(field, name) g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(lib, name)); if (!g_rccl.field) return fail(TQGPU_ECOMM, std::string("librccl.so lacks ") + name)
+    SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
+    SYM(AllGather, "ncclAllGather"); SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    g_rccl.lib = lib;
+    return TQGPU_OK;
+}
+constexpr int NCCL_DOUBLE = 8;     /* ncclFloat64 */
+
+#define NCCL_TRY(expr) do { int r_ = (expr); if (r_ != 0) return fail(TQGPU_ECOMM, std::string(#expr) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "rccl error")); } while (0)
+
+int uni_first(int MD, int level) { int n = 0, w = 1; for (int l = 0; l < level; l++) { n += w; w *= MD; } return n; }
+
+Shard shard_desc(const tqgpu_solver *s, int tier) {
+    Shard sh{};
+    if (s->nranks > 1) {
+        if (tier >= 0 && tier <= s->part_top) sh.wg_off = s->rank * (s->tier_grid[tier] / s->nranks);
+        sh.gh_list = s->d_gh_list; sh.gh_n = s->gh_n; sh.gh_counted = s->gh_counted;
+        sh.err_src = s->d_xerr;
+    }
+    return sh;
+}
+
+/* exchange #1 (after the last partitioned backward tier): Schur records of the boundary subtree
+ * roots and the termination partials; exchange #2 (after the trial sweep): {fval, dot} partials and
+ * x / QinvCal of the boundary root nodes.  In-place all-gathers on the solver's stream. */
+int shard_exchange_rccl(tqgpu_solver *s, int which) {
+    const int N = s->nranks, r = s->rank, MD = s->fMD, NX = s->fNX;
+    const int lb = s->tier_l0[s->part_top], gb = s->tier_grid[s->part_top], w = gb / N;
+    const int f0 = uni_first(MD, lb);
+    const size_t SCH = (size_t)NX * NX + NX;
+    NCCL_TRY(g_rccl.GroupStart());
+    if (which == 1) {
+        double *base = s->D.Sbuf + (size_t)f0 * SCH;
+        NCCL_TRY(g_rccl.AllGather(base + (size_t)r * w * SCH, base, (size_t)w * SCH, NCCL_DOUBLE, s->comm, s->stream));
+        NCCL_TRY(g_rccl.AllGather(s->d_xerr + r, s->d_xerr, 1, NCCL_DOUBLE, s->comm, s->stream));
+    } else {
+        NCCL_TRY(g_rccl.AllGather(s->d_xs + 2 * r, s->d_xs, 2, NCCL_DOUBLE, s->comm, s->stream));
+        double *xb = s->D.x + (size_t)NX * f0, *qb = s->D.QinvCal + (size_t)NX * f0;
+        NCCL_TRY(g_rccl.AllGather(xb + (size_t)r * w * NX, xb, (size_t)w * NX, NCCL_DOUBLE, s->comm, s->stream));
+        NCCL_TRY(g_rccl.AllGather(qb + (size_t)r * w * NX, qb, (size_t)w * NX, NCCL_DOUBLE, s->comm, s->stream));
+    }
+    NCCL_TRY(g_rccl.GroupEnd());
+    return TQGPU_OK;
+}
+
+/* the same exchanges between `n` mirrors living in one process on one device ("virtual ranks"):
+ * used to validate the partition / hand-off logic on a single GPU */
+int shard_exchange_virtual(tqgpu_solver **R, int n, int which) {
+    tqgpu_solver *s0 = R[0];
+    const int MD = s0->fMD, NX = s0->fNX;
+    const int lb = s0->tier_l0[s0->part_top], gb = s0->tier_grid[s0->part_top], w = gb / n;
+    const int f0 = uni_first(MD, lb);
+    const size_t SCH = (size_t)NX * NX + NX;
+    for (int r = 0; r < n; r++) HIP_TRY(hipStreamSynchronize(R[r]->stream));
+    /* every source stream is idle now; the copies are ordered on the DESTINATION mirror's stream, in
+     * front of its next phase (the solver streams are non-blocking: the null stream would not order) */
+    for (int src = 0; src < n; src++) for (int dst = 0; dst < n; dst++) {
+        if (src == dst) continue;
+        tqgpu_solver *a = R[src], *b = R[dst];
+        hipStream_t st = b->stream;
+        if (which == 1) {
+            const size_t off = ((size_t)f0 + (size_t)src * w) * SCH;
+            HIP_TRY(hipMemcpyAsync(b->D.Sbuf + off, a->D.Sbuf + off, sizeof(double) * w * SCH, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(b->d_xerr + src, a->d_xerr + src, sizeof(double), hipMemcpyDeviceToDevice, st));
+        } else {
+            HIP_TRY(hipMemcpyAsync(b->d_xs + 2 * src, a->d_xs + 2 * src, 2 * sizeof(double), hipMemcpyDeviceToDevice, st));
+            const size_t off = (size_t)NX * (f0 + (size_t)src * w);
+            HIP_TRY(hipMemcpyAsync(b->D.x + off, a->D.x + off, sizeof(double) * w * NX, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(b->D.QinvCal + off, a->D.QinvCal + off, sizeof(double) * w * NX, hipMemcpyDeviceToDevice, st));
+        }
+    }
+    for (int r = 0; r < n; r++) HIP_TRY(hipStreamSynchronize(R[r]->stream));
+    return TQGPU_OK;
+}
+
+/* One fused Newton iteration, split in three phases around the two exchange points of the sharded
+ * mode.  Single device: phases run back to back, no exchange. */
+void launch_fast_phase(tqgpu_solver *s, const Opts &O, int h, int phase, int &launches) {
     const Tree &T = s->T; const Data &D = s->D; hipStream_t st = s->stream;
     const dim3 blk(FW * WAVE);
-    const int nt = s->n_tiers, nparts = nt > 1 ? s->tier_grid[0] : FW;
-    const int nstage = (T.Nn + FW - 1) / FW;
+    const int nt = s->n_tiers, N = s->nranks;
+    const bool sharded = N > 1;
+    const int P = sharded ? s->part_top : -1;
+    auto tgrid = [&](int i) { return (sharded && i <= P) ? s->tier_grid[i] / N : s->tier_grid[i]; };
+    /* which kernel runs first / performs the termination test */
+    const int check_tier = sharded ? P + 1 : 1;          /* index in 0..nt-1 (nt-1 = top) */
+    const int nparts = sharded ? N : (nt > 1 ? s->tier_grid[0] : FW);
+    const int n_stage = sharded ? s->n_nodes : T.Nn;
     switch (s->fast) {
-#define X(idx, nx, nu, md)                                                                                              \
-    case idx:                                                                                                           \
-        for (int i = 0; i < nt - 1; i++)                                                                                \
-            hipLaunchKernelGGL((f_back<nx, nu, md>), dim3(s->tier_grid[i]), blk, s->lds_fast, st, T, D, O,              \
-                               s->tier_l0[i], s->tier_l1[i], i == 0, i == 1, nparts, i, h);                             \
-        hipLaunchKernelGGL((f_top<nx, nu, md>), dim3(1), blk, s->lds_fast, st, T, D, O, s->tier_l1[nt - 1],              \
-                           nt == 1, nt == 2, nparts, nt - 1, h);                                                        \
-        for (int i = nt - 2; i >= 0; i--)                                                                               \
-            hipLaunchKernelGGL((f_fwd<nx, nu, md>), dim3(s->tier_grid[i]), blk, s->lds_fast, st, T, D, O,               \
-                               s->tier_l0[i], s->tier_l1[i], nt + (nt - 2 - i), h);                                     \
-        hipLaunchKernelGGL((f_stage<nx, nu, md>), dim3(nstage), blk, s->lds_fstage, st, T, D, O, 2 * nt - 1, h, 1);      \
+#define X(idx, nx, nu, md)                                                                                                   \
+    case idx:                                                                                                                \
+        if (phase == 0) {                                                                                                    \
+            for (int i = 0; i < nt - 1 && (!sharded || i <= P); i++) {                                                       \
+                hipLaunchKernelGGL((f_back<nx, nu, md>), dim3(tgrid(i)), blk, s->lds_fast, st, T, D, O, shard_desc(s, i),    \
+                                   s->tier_l0[i], s->tier_l1[i], i == 0, !sharded && i == check_tier, nparts, i, h); launches++; \
+            }                                                                                                                \
+            if (sharded) { hipLaunchKernelGGL(k_shard_pack1, dim3(1), dim3(256), 0, st, D, tgrid(0), s->d_xerr, s->rank, O.termCondition, h); launches++; } \
+        }                                                                                                                    \
+        if (phase == 1) {                                                                                                    \
+            for (int i = (sharded ? P + 1 : nt - 1); i < nt - 1; i++) {                                                      \
+                hipLaunchKernelGGL((f_back<nx, nu, md>), dim3(tgrid(i)), blk, s->lds_fast, st, T, D, O, shard_desc(s, i),    \
+                                   s->tier_l0[i], s->tier_l1[i], 0, i == check_tier, nparts, i, h); launches++;              \
+            }                                                                                                                \
+            hipLaunchKernelGGL((f_top<nx, nu, md>), dim3(1), blk, s->lds_fast, st, T, D, O, shard_desc(s, nt - 1),           \
+                               s->tier_l1[nt - 1], nt == 1, (nt - 1) == check_tier, nparts, nt - 1, h); launches++;          \
+            for (int i = nt - 2; i >= 0; i--) {                                                                              \
+                hipLaunchKernelGGL((f_fwd<nx, nu, md>), dim3(tgrid(i)), blk, s->lds_fast, st, T, D, O, shard_desc(s, i),     \
+                                   s->tier_l0[i], s->tier_l1[i], nt + (nt - 2 - i), h); launches++;                          \
+            }                                                                                                                \
+            hipLaunchKernelGGL((f_stage<nx, nu, md>), dim3((n_stage + FW - 1) / FW), blk, s->lds_fstage, st, T, D, O,        \
+                               sharded ? s->d_node_list : nullptr, n_stage, 2 * nt - 1, h, 1); launches++;                   \
+            if (sharded) { hipLaunchKernelGGL(k_shard_pack2, dim3(1), dim3(WAVE), 0, st, D, s->d_node_cnt_list, s->n_nodes_counted, \
+                                              s->d_blk_list, s->n_blk_counted, s->d_xs, s->rank, s->bnd_b0, s->bnd_bn, s->bnd_own0, s->bnd_ownn, h, 1); launches++; } \
+        }                                                                                                                    \
         break;
         FAST_TABLE(X)
 #undef X
         default: break;
     }
-    hipLaunchKernelGGL(k_ls_decide, dim3(1), dim3(256), 0, st, T, D, O, h, 1, 1);
-    launches += 2 * nt + 1;
+    if (phase == 2) {
+        if (sharded) hipLaunchKernelGGL(k_ls_decide_parts, dim3(1), dim3(WAVE), 0, st, D, O, s->d_xs, N, h, 1, 1);
+        else hipLaunchKernelGGL(k_ls_decide, dim3(1), dim3(256), 0, st, T, D, O, h, 1, 1);
+        launches++;
+    }
 }
 
-/* one more line-search trial of iteration `it` */
-void launch_trial(tqgpu_solver *s, const Opts &O, bool fast, int it, int t, int &launches) {
+int launch_fast_iteration(tqgpu_solver *s, const Opts &O, int h, int &launches) {
+    launch_fast_phase(s, O, h, 0, launches);
+    if (s->nranks > 1) { int rc = shard_exchange_rccl(s, 1); if (rc) return rc; }
+    launch_fast_phase(s, O, h, 1, launches);
+    if (s->nranks > 1) { int rc = shard_exchange_rccl(s, 2); if (rc) return rc; }
+    launch_fast_phase(s, O, h, 2, launches);
+    return TQGPU_OK;
+}
+
+/* one more line-search trial of iteration `it`; phase 0: sweep (+ pack), phase 1: decide */
+void launch_trial_phase(tqgpu_solver *s, const Opts &O, bool fast, int it, int t, int phase, int &launches) {
     const Tree &T = s->T; const Data &D = s->D; hipStream_t st = s->stream;
-    bool done = false;
-    if (fast) {
-        const int nstage = (T.Nn + FW - 1) / FW;
-        switch (s->fast) {
-#define X(idx, nx, nu, md) case idx: hipLaunchKernelGGL((f_stage<nx, nu, md>), dim3(nstage), dim3(FW * WAVE), s->lds_fstage, st, T, D, O, 7, it, t); done = true; break;
-            FAST_TABLE(X)
+    const bool sharded = s->nranks > 1;
+    if (phase == 0) {
+        bool done = false;
+        if (fast) {
+            const int n_stage = sharded ? s->n_nodes : T.Nn;
+            switch (s->fast) {
+#define X(idx, nx, nu, md) case idx: hipLaunchKernelGGL((f_stage<nx, nu, md>), dim3((n_stage + FW - 1) / FW), dim3(FW * WAVE), s->lds_fstage, st, T, D, O, sharded ? s->d_node_list : nullptr, n_stage, 7, it, t); done = true; break;
+                FAST_TABLE(X)
 #undef X
-            default: break;
+                default: break;
+            }
         }
+        if (!done) hipLaunchKernelGGL(k_stage, dim3(T.Nn), dim3(WAVE), s->lds_stage, st, T, D, 1, it, t);
+        launches++;
+        if (sharded) { hipLaunchKernelGGL(k_shard_pack2, dim3(1), dim3(WAVE), 0, st, D, s->d_node_cnt_list, s->n_nodes_counted, s->d_blk_list, s->n_blk_counted, s->d_xs, s->rank, s->bnd_b0, s->bnd_bn, s->bnd_own0, s->bnd_ownn, it, t); launches++; }
+    } else {
+        if (sharded) hipLaunchKernelGGL(k_ls_decide_parts, dim3(1), dim3(WAVE), 0, st, D, O, s->d_xs, s->nranks, it, t, 0);
+        else hipLaunchKernelGGL(k_ls_decide, dim3(1), dim3(256), 0, st, T, D, O, it, t, 0);
+        launches++;
     }
-    if (!done) hipLaunchKernelGGL(k_stage, dim3(T.Nn), dim3(WAVE), s->lds_stage, st, T, D, 1, it, t);
-    hipLaunchKernelGGL(k_ls_decide, dim3(1), dim3(256), 0, st, T, D, O, it, t, 0);
-    launches += 2;
+}
+
+int launch_trial(tqgpu_solver *s, const Opts &O, bool fast, int it, int t, int &launches) {
+    launch_trial_phase(s, O, fast, it, t, 0, launches);
+    if (s->nranks > 1) { int rc = shard_exchange_rccl(s, 2); if (rc) return rc; }
+    launch_trial_phase(s, O, fast, it, t, 1, launches);
+    return TQGPU_OK;
 }
 
 void launch_generic_iteration(tqgpu_solver *s, const Opts &O, int h, int &launches) {
@@ -899,6 +1099,8 @@ extern "C" void tqgpu_destroy(tqgpu_solver *s) {
     if (s->stream) (void)hipStreamDestroy(s->stream);
     if (s->h_ctrl) (void)hipHostFree(s->h_ctrl);
     if (s->h_ls_log) (void)hipHostFree(s->h_ls_log);
+    if (s->shard_slab) (void)hipFree(s->shard_slab);
+    if (s->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(s->comm);
     if (s->slab) (void)hipFree(s->slab);
     delete s;
 }
@@ -989,6 +1191,7 @@ extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *r
     if (O.termCondition < 0 || O.termCondition > 2 || O.regType < 0 || O.regType > 2 || O.regValue < 0)
         return fail(TQGPU_EINVAL, "invalid option value");
 
+    if (s->nranks > 1 && !s->comm) return fail(TQGPU_ECOMM, "sharded mirror without a communicator: use tqgpu_solve_virtual_ranks");
     const Tree &T = s->T; const Data &D = s->D;
     hipStream_t st = s->stream;
     int launches = 0;
@@ -1029,7 +1232,7 @@ extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *r
     while (!finished) {
         const int n = std::min(chunk, o->maxIter - h);
         for (int i = 0; i < n; i++) {
-            if (fast) launch_fast_iteration(s, O, h + i, launches);
+            if (fast) { int rcx = launch_fast_iteration(s, O, h + i, launches); if (rcx != TQGPU_OK) return rcx; }
             else launch_generic_iteration(s, O, h + i, launches);
             if (o->profile && ev_idx + 1 < (int)s->iter_ev.size()) HIP_TRY(hipEventRecord(s->iter_ev[++ev_idx], st));
         }
@@ -1038,7 +1241,7 @@ extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *r
         while (!s->h_ctrl->done && s->h_ctrl->ls_pending) {
             /* the line search of iteration `iter` wants more trials (rare): a batch of them */
             const int it = s->h_ctrl->iter, t0 = s->h_ctrl->ls_iter;
-            for (int t = t0; t < t0 + 8 && t <= O.lsMaxIter; t++) launch_trial(s, O, fast, it, t, launches);
+            for (int t = t0; t < t0 + 8 && t <= O.lsMaxIter; t++) { int rcx = launch_trial(s, O, fast, it, t, launches); if (rcx != TQGPU_OK) return rcx; }
             if ((rc = read_ctrl(s)) != TQGPU_OK) return rc;
         }
         h = s->h_ctrl->iter;
@@ -1064,6 +1267,198 @@ extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *r
     res->status = c.status; res->iter = c.iter; res->ls_total = c.ls_total; res->ls_last = c.ls_last;
     res->n_launches = launches; res->device_time = 1e-3 * ms; res->last_error_norm = c.err; res->last_fval = c.fval;
     s->last_iter = c.iter;
+    return TQGPU_OK;
+}
+
+/* ============================================================================================ */
+/* sharded mode: one tree over several devices                                  */
+/* ============================================================================================ */
+
+namespace {
+
+/* enumerate the (array, first element, count per rank) ranges that are rank-partitioned, one per
+ * node level >= lb; used for the final solution gather */
+struct RangeSpec { double *base; size_t per_rank; };
+
+std::vector<RangeSpec> solution_ranges(tqgpu_solver *s) {
+    std::vector<RangeSpec> out;
+    const int MD = s->fMD, NX = s->fNX, NU = s->fNU, N = s->nranks;
+    const int lb = s->tier_l0[s->part_top];
+    const Data &D = s->D;
+    double *lamc = s->h_ctrl->cur ? D.lam1 : D.lam0;
+    for (int l = lb; l <= s->Nh; l++) {
+        int wl = 1; for (int i = 0; i < l; i++) wl *= MD;
+        const size_t f0 = (size_t)uni_first(MD, l), w = (size_t)wl / N;
+        double *xs[] = {D.x, D.xUnc, lamc, D.dlam};
+        for (double *a : xs) out.push_back({a + NX * f0, w * NX});
+        if (l < s->Nh) { double *us[] = {D.u, D.uUnc}; for (double *a : us) out.push_back({a + NU * f0, w * NU}); }
+    }
+    return out;
+}
+
+int shard_build_lists(tqgpu_solver *s) {
+    const int MD = s->fMD, N = s->nranks, r = s->rank, nt = s->n_tiers;
+    /* highest partitioned tier: subtree count divisible by the number of ranks */
+    s->part_top = -1;
+    for (int i = 0; i < nt - 1; i++) if (s->tier_grid[i] % N == 0 && s->tier_grid[i] >= N) s->part_top = i;
+    if (s->part_top < 0) return fail(TQGPU_EUNSUPPORTED, "tree too small to shard over this many ranks");
+    const int lb = s->tier_l0[s->part_top], l00 = s->tier_l0[0], Nh = s->Nh;
+    auto width = [&](int l) { int w = 1; for (int i = 0; i < l; i++) w *= MD; return w; };
+    {
+        const int gb = width(lb), w = gb / N, NX = s->fNX;
+        s->bnd_b0 = NX * uni_first(MD, lb); s->bnd_bn = NX * gb; s->bnd_own0 = NX * r * w; s->bnd_ownn = NX * w;
+    }
+    std::vector<int> gh, nodes, nodes_cnt, blks;
+    /* owned */
+    for (int l = lb; l <= Nh; l++) {
+        const int w = width(l) / N, f0 = uni_first(MD, l) + r * w;
+        for (int i = 0; i < w; i++) {
+            nodes.push_back(f0 + i); nodes_cnt.push_back(f0 + i);
+            if (l < Nh) blks.push_back(f0 + i);
+            if (l < l00) gh.push_back(f0 + i);
+        }
+    }
+    s->gh_counted = (int)gh.size();
+    /* replicated (levels above the boundary): computed by every rank, counted by rank 0 only */
+    for (int l = 0; l < lb; l++) {
+        const int w = width(l), f0 = uni_first(MD, l);
+        for (int i = 0; i < w; i++) {
+            nodes.push_back(f0 + i); gh.push_back(f0 + i);
+            if (r == 0) { nodes_cnt.push_back(f0 + i); blks.push_back(f0 + i); }
+        }
+    }
+    if (r == 0) s->gh_counted = (int)gh.size();
+    s->gh_n = (int)gh.size(); s->n_nodes = (int)nodes.size(); s->n_nodes_counted = (int)nodes_cnt.size(); s->n_blk_counted = (int)blks.size();
+    const size_t ints = gh.size() + nodes.size() + nodes_cnt.size() + blks.size() + 16;
+    const size_t bytes = ints * sizeof(int) + (3 * (size_t)N + 8) * sizeof(double) + 1024;
+    if (s->shard_slab) { (void)hipFree(s->shard_slab); s->shard_slab = nullptr; }
+    HIP_TRY(hipMalloc(&s->shard_slab, bytes));
+    HIP_TRY(hipMemset(s->shard_slab, 0, bytes));
+    char *p = static_cast<char *>(s->shard_slab);
+    s->d_xerr = reinterpret_cast<double *>(p); p += sizeof(double) * (size_t)(N + 2);
+    s->d_xs = reinterpret_cast<double *>(p); p += sizeof(double) * (size_t)(2 * N + 2);
+    auto put = [&](std::vector<int> &v, int *&dst) -> int {
+        dst = reinterpret_cast<int *>(p); p += sizeof(int) * (v.size() + 2);
+        if (!v.empty() && hipMemcpy(dst, v.data(), sizeof(int) * v.size(), hipMemcpyHostToDevice) != hipSuccess) return fail(TQGPU_ENODEVICE, "shard list upload failed");
+        return TQGPU_OK;
+    };
+    int rc;
+    if ((rc = put(gh, s->d_gh_list)) || (rc = put(nodes, s->d_node_list)) || (rc = put(nodes_cnt, s->d_node_cnt_list)) || (rc = put(blks, s->d_blk_list))) return rc;
+    return TQGPU_OK;
+}
+
+}  // namespace
+
+extern "C" int tqgpu_shard_unique_id(void *id128) {
+    if (!id128) return fail(TQGPU_EINVAL, "null id buffer");
+    int rc = rccl_load();
+    if (rc) return rc;
+    RcclApi::UniqueId id;
+    NCCL_TRY(g_rccl.GetUniqueId(&id));
+    memcpy(id128, &id, sizeof(id));
+    return TQGPU_OK;
+}
+
+extern "C" int tqgpu_shard_init(tqgpu_solver *s, int rank, int nranks, const void *id128) {
+    if (!s || nranks < 1 || rank < 0 || rank >= nranks) return fail(TQGPU_EINVAL, "tqgpu_shard_init: bad arguments");
+    HIP_TRY(hipSetDevice(s->device));
+    if (nranks == 1) { s->nranks = 1; s->rank = 0; return TQGPU_OK; }
+    if (s->fast < 0 || !s->use_fast) return fail(TQGPU_EUNSUPPORTED, "sharding needs the fused uniform-tree path");
+    s->nranks = nranks; s->rank = rank;
+    int rc = shard_build_lists(s);
+    if (rc) { s->nranks = 1; s->rank = 0; return rc; }
+    if (id128) {
+        if ((rc = rccl_load())) return rc;
+        RcclApi::UniqueId id;
+        memcpy(&id, id128, sizeof(id));
+        NCCL_TRY(g_rccl.CommInitRank(&s->comm, nranks, id, rank));
+    }
+    return TQGPU_OK;
+}
+
+/* after a sharded solve every rank holds valid x,u,lambda,... only for its own and the replicated
+ * nodes: gather the partitioned ranges so that tqgpu_get_solution returns the full solution */
+extern "C" int tqgpu_shard_gather_solution(tqgpu_solver *s) {
+    if (!s) return fail(TQGPU_EINVAL, "null solver");
+    if (s->nranks == 1) return TQGPU_OK;
+    if (!s->comm) return fail(TQGPU_ECOMM, "no communicator (virtual ranks gather through tqgpu_solve_virtual_ranks)");
+    HIP_TRY(hipSetDevice(s->device));
+    auto ranges = solution_ranges(s);
+    NCCL_TRY(g_rccl.GroupStart());
+    for (auto &rg : ranges) NCCL_TRY(g_rccl.AllGather(rg.base + (size_t)s->rank * rg.per_rank, rg.base, rg.per_rank, NCCL_DOUBLE, s->comm, s->stream));
+    NCCL_TRY(g_rccl.GroupEnd());
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return TQGPU_OK;
+}
+
+/* Diagnostic / test entry: run `n` mirrors of the SAME problem as ranks 0..n-1 of a sharded solve
+ * inside one process on one device, exchanging by device copies.  Validates partition, hand-off and
+ * decision logic without a multi-GPU node.  Every mirror must have been shard-initialised with
+ * (rank = its index, nranks = n, id128 = NULL).  The full solution is gathered into every mirror. */
+extern "C" int tqgpu_solve_virtual_ranks(tqgpu_solver **R, int n, const tqgpu_opts *o, tqgpu_result *res) {
+    if (!R || n < 2 || !o || !res) return fail(TQGPU_EINVAL, "tqgpu_solve_virtual_ranks: bad arguments");
+    for (int r = 0; r < n; r++) if (!R[r] || R[r]->nranks != n || R[r]->rank != r || R[r]->comm) return fail(TQGPU_EINVAL, "mirror is not virtual rank r of n");
+    HIP_TRY(hipSetDevice(R[0]->device));
+    Opts O;
+    O.maxIter = o->maxIter; O.termCondition = o->termCondition; O.regType = o->regType;
+    O.lsMaxIter = o->lineSearchMaxIter; O.lsRestartTrigger = o->lineSearchRestartTrigger;
+    O.tol = o->stationarityTolerance; O.regTol = o->regTol; O.regValue = o->regValue;
+    O.gamma = o->lineSearchGamma; O.beta = o->lineSearchBeta; O.stamps = 0;
+    int launches = 0;
+    for (int r = 0; r < n; r++) {
+        tqgpu_solver *s = R[r];
+        hipStream_t st = s->stream;
+        Ctrl init; memset(&init, 0, sizeof(init));
+        HIP_TRY(hipMemcpyAsync(s->D.ctrl, &init, sizeof(Ctrl), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemsetAsync(s->D.ls_log, 0, sizeof(int) * (size_t)s->ls_log_cap, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpyAsync(s->D.lam0, s->d_lam_init, sizeof(double) * (size_t)s->sum_nx, hipMemcpyDeviceToDevice, st));
+        const int nxu = std::max(s->sum_nx, s->sum_nu);
+        if (s->need_init) { hipLaunchKernelGGL(k_init, dim3((nxu + 255) / 256), dim3(256), 0, st, s->sum_nx, s->sum_nu, s->D); s->need_init = false; }
+        hipLaunchKernelGGL(k_stage, dim3(s->T.Nn), dim3(WAVE), s->lds_stage, st, s->T, s->D, 0, 0, 0);
+        hipLaunchKernelGGL(k_fval_init, dim3(1), dim3(256), 0, st, s->T, s->D);
+    }
+    int rc;
+    bool finished = o->maxIter <= 0;
+    int h = 0;
+    while (!finished) {
+        for (int r = 0; r < n; r++) launch_fast_phase(R[r], O, h, 0, launches);
+        if ((rc = shard_exchange_virtual(R, n, 1))) return rc;
+        for (int r = 0; r < n; r++) launch_fast_phase(R[r], O, h, 1, launches);
+        if ((rc = shard_exchange_virtual(R, n, 2))) return rc;
+        for (int r = 0; r < n; r++) launch_fast_phase(R[r], O, h, 2, launches);
+        for (int r = 0; r < n; r++) if ((rc = read_ctrl(R[r]))) return rc;
+        while (!R[0]->h_ctrl->done && R[0]->h_ctrl->ls_pending) {
+            const int it = R[0]->h_ctrl->iter, t = R[0]->h_ctrl->ls_iter;
+            for (int r = 0; r < n; r++) launch_trial_phase(R[r], O, true, it, t, 0, launches);
+            if ((rc = shard_exchange_virtual(R, n, 2))) return rc;
+            for (int r = 0; r < n; r++) launch_trial_phase(R[r], O, true, it, t, 1, launches);
+            for (int r = 0; r < n; r++) if ((rc = read_ctrl(R[r]))) return rc;
+        }
+        for (int r = 1; r < n; r++)
+            if (R[r]->h_ctrl->iter != R[0]->h_ctrl->iter || R[r]->h_ctrl->done != R[0]->h_ctrl->done || R[r]->h_ctrl->status != R[0]->h_ctrl->status)
+                return fail(TQGPU_ECOMM, "virtual ranks took different decisions");
+        h = R[0]->h_ctrl->iter;
+        finished = R[0]->h_ctrl->done != 0;
+    }
+    /* gather the partitioned solution ranges into every mirror */
+    for (int r = 0; r < n; r++) HIP_TRY(hipStreamSynchronize(R[r]->stream));
+    if (o->maxIter > 0) {
+        for (int src = 0; src < n; src++) {
+            auto rs = solution_ranges(R[src]);
+            for (int dst = 0; dst < n; dst++) {
+                if (dst == src) continue;
+                auto rd = solution_ranges(R[dst]);
+                for (size_t i = 0; i < rs.size(); i++)
+                    HIP_TRY(hipMemcpyAsync(rd[i].base + (size_t)src * rd[i].per_rank, rs[i].base + (size_t)src * rs[i].per_rank, sizeof(double) * rs[i].per_rank, hipMemcpyDeviceToDevice, R[dst]->stream));
+            }
+        }
+        for (int r = 0; r < n; r++) HIP_TRY(hipStreamSynchronize(R[r]->stream));
+    }
+    const Ctrl &c = *R[0]->h_ctrl;
+    res->status = c.status; res->iter = c.iter; res->ls_total = c.ls_total; res->ls_last = c.ls_last;
+    res->n_launches = launches; res->device_time = 0.0; res->last_error_norm = c.err; res->last_fval = c.fval;
+    for (int r = 0; r < n; r++) R[r]->last_iter = c.iter;
     return TQGPU_OK;
 }
 

@@ -406,10 +406,10 @@ __device__ __forceinline__ void forward_block(const Data &Dt, int ii, int lane, 
 /* termination test run by the kernel that comes second in an iteration: every workgroup        */
 /* reduces the per-workgroup partials of the first kernel; workgroup 0 records the decision     */
 /* ------------------------------------------------------------------------------------------ */
-__device__ __forceinline__ bool converged_now(const Data &Dt, const Opts &O, int nparts, int *flag_lds) {
+__device__ __forceinline__ bool converged_now(const Data &Dt, const Opts &O, const double *parts, int nparts, int *flag_lds) {
     if (threadIdx.x < WAVE) {
         double e = 0.0;
-        for (int i = threadIdx.x; i < nparts; i += WAVE) e = (O.termCondition == 2) ? fmax(e, Dt.part_err[i]) : e + Dt.part_err[i];
+        for (int i = threadIdx.x; i < nparts; i += WAVE) e = (O.termCondition == 2) ? fmax(e, parts[i]) : e + parts[i];
         e = (O.termCondition == 2) ? wave_max(e) : wave_sum(e);
         if (O.termCondition == 1) e = sqrt(e);
         if (threadIdx.x == 0) {
@@ -443,21 +443,32 @@ struct TierLds {
     }
 };
 
+/* Sharding of one tree over several devices: a rank owns a contiguous range of
+ * the subtrees of every partitioned tier and computes the replicated tiers in full.  The same
+ * kernels serve the single-device case with the neutral descriptor {0, nullptr, 0, 0, nullptr, 0}. */
+struct Shard {
+    int wg_off;             /* first subtree of this rank in a partitioned tier (added to blockIdx.x) */
+    const int *gh_list;     /* blocks above tier 0 whose G+H this rank computes (nullptr: all of them) */
+    int gh_n, gh_counted;   /* list length; entries >= gh_counted do not enter the termination norm here */
+    const double *err_src;  /* termination partials for the check (nullptr: Dt.part_err)               */
+    int pad;
+};
+
 /* f_back: one workgroup per subtree of block levels [l0, l1): backward sweep bottom-up.
  * first != 0: this is the first kernel of the iteration: G+H (and norm partials) before the sweep.
  * check != 0: this is the second kernel of the iteration: termination test first. */
 template <int NX, int NU, int MD>
-__global__ void __launch_bounds__(FW * WAVE) f_back(Tree T, Data Dt, Opts O, int l0, int l1, int first, int check, int nparts, int kern, int h) {
+__global__ void __launch_bounds__(FW * WAVE) f_back(Tree T, Data Dt, Opts O, Shard Sh, int l0, int l1, int first, int check, int nparts, int kern, int h) {
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D;
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     if (!phase_main(Dt.ctrl, h)) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     TierLds<NX, NU, MD> L(lds_all, wave);
-    const int s = blockIdx.x, th = l1 - l0;
+    const int s = blockIdx.x + Sh.wg_off, th = l1 - l0;
     int sl = 0;
     stamp(Dt, O, kern, sl++);
-    if (check && converged_now(Dt, O, nparts, L.flag)) return;
+    if (check && converged_now(Dt, O, Sh.err_src ? Sh.err_src : Dt.part_err, nparts, L.flag)) return;
     if (first) {
         /* G + H: the blocks of this subtree, plus a share of the blocks above this tier */
         double e = 0.0;
@@ -467,8 +478,15 @@ __global__ void __launch_bounds__(FW * WAVE) f_back(Tree T, Data Dt, Opts O, int
             for (int b = 0; b < nb; b++, cnt++)
                 if ((cnt & (FW - 1)) == wave) { const double v = fast_gh<NX, NU, MD>(Dt, f0 + b, lane, O.termCondition); e = (O.termCondition == 2) ? fmax(e, v) : e + v; }
         }
-        const int nup = U::first(l0);
-        for (int p = s * FW + wave; p < nup; p += gridDim.x * FW) { const double v = fast_gh<NX, NU, MD>(Dt, p, lane, O.termCondition); e = (O.termCondition == 2) ? fmax(e, v) : e + v; }
+        if (Sh.gh_list) {
+            for (int q = blockIdx.x * FW + wave; q < Sh.gh_n; q += gridDim.x * FW) {
+                const double v = fast_gh<NX, NU, MD>(Dt, Sh.gh_list[q], lane, O.termCondition);
+                if (q < Sh.gh_counted) e = (O.termCondition == 2) ? fmax(e, v) : e + v;
+            }
+        } else {
+            const int nup = U::first(l0);
+            for (int p = s * FW + wave; p < nup; p += gridDim.x * FW) { const double v = fast_gh<NX, NU, MD>(Dt, p, lane, O.termCondition); e = (O.termCondition == 2) ? fmax(e, v) : e + v; }
+        }
         if (lane == 0) L.dl[wave] = e;       /* L.dl is not used by the backward sweep */
         __syncthreads();                     /* W / Ut / resMod of this subtree are read back below */
         if (threadIdx.x == 0) {
@@ -508,7 +526,7 @@ __global__ void __launch_bounds__(FW * WAVE) f_back(Tree T, Data Dt, Opts O, int
 /* f_top: single workgroup, block levels [0, l1): (G+H if it is the only tier) termination test,
  * backward sweep, root, forward sweep of its levels; arms the line search. */
 template <int NX, int NU, int MD>
-__global__ void __launch_bounds__(FW * WAVE) f_top(Tree T, Data Dt, Opts O, int l1, int first, int check, int nparts, int kern, int h) {
+__global__ void __launch_bounds__(FW * WAVE) f_top(Tree T, Data Dt, Opts O, Shard Sh, int l1, int first, int check, int nparts, int kern, int h) {
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D;
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
@@ -527,7 +545,7 @@ __global__ void __launch_bounds__(FW * WAVE) f_top(Tree T, Data Dt, Opts O, int 
         nparts = FW;
         check = 1;
     }
-    if (check && converged_now(Dt, O, nparts, L.flag)) return;
+    if (check && converged_now(Dt, O, (Sh.err_src && !first) ? Sh.err_src : Dt.part_err, nparts, L.flag)) return;
     stamp(Dt, O, kern, sl++);
     double Tc[D], Tn[D];
     {
@@ -577,14 +595,14 @@ __global__ void __launch_bounds__(FW * WAVE) f_top(Tree T, Data Dt, Opts O, int 
 
 /* f_fwd: one workgroup per subtree of block levels [l0, l1): forward sweep top-down */
 template <int NX, int NU, int MD>
-__global__ void __launch_bounds__(FW * WAVE) f_fwd(Tree T, Data Dt, Opts O, int l0, int l1, int kern, int h) {
+__global__ void __launch_bounds__(FW * WAVE) f_fwd(Tree T, Data Dt, Opts O, Shard Sh, int l0, int l1, int kern, int h) {
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D;
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     if (!phase_trial(Dt.ctrl, h, 1)) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     TierLds<NX, NU, MD> L(lds_all, wave);
-    const int s = blockIdx.x, th = l1 - l0;
+    const int s = blockIdx.x + Sh.wg_off, th = l1 - l0;
     int sl = 0;
     stamp(Dt, O, kern, sl++);
     FwdRegs<NX, NU, MD> Fc, Fn;
@@ -611,16 +629,17 @@ __global__ void __launch_bounds__(FW * WAVE) f_fwd(Tree T, Data Dt, Opts O, int 
  * clipping, elimination vectors, dual-function term; writes lam_next.  All loads are issued before
  * the first dependent use. */
 template <int NX, int NU, int MD>
-__global__ void __launch_bounds__(FW * WAVE) f_stage(Tree T, Data Dt, Opts O, int kern, int h, int trial) {
+__global__ void __launch_bounds__(FW * WAVE) f_stage(Tree T, Data Dt, Opts O, const int *node_list, int n_nodes, int kern, int h, int trial) {
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D;
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     const Ctrl *c = Dt.ctrl;
     if (!phase_trial(c, h, trial)) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int k = blockIdx.x * FW + wave;
+    const int q = blockIdx.x * FW + wave;
     stamp(Dt, O, kern, 0);
-    if (k >= T.Nn) return;
+    if (q >= n_nodes) return;
+    const int k = node_list ? node_list[q] : q;
     double *lds = lds_all + wave * (D + NX + 8);
     const double *lamc = c->cur ? Dt.lam1 : Dt.lam0;
     double *lamn = c->cur ? Dt.lam0 : Dt.lam1;
