@@ -82,8 +82,9 @@ int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *opts, tqgpu_result *res);
 /* any output pointer may be NULL */
 int tqgpu_get_solution(tqgpu_solver *s, double *x, double *u, double *lam, double *mu_x, double *mu_u, double *dlam);
 
-/* 1 if this mirror runs the fused uniform-tree kernels (tdunes_fast.hpp), 0 for the generic
- * per-level kernels.  TREEQP_AMD_PATH=generic in the environment at create time forces 0. */
+/* 2: persistent single-launch solve (tdunes_persist.hpp); 1: tiered fused kernels (tdunes_fast.hpp);
+ * 0: generic per-level kernels.  TREEQP_AMD_PATH=generic|tiered in the environment at create time
+ * forces the lower paths. */
 int tqgpu_uses_fused_path(const tqgpu_solver *s);
 
 /* sizes of the flat arrays, for callers that did not keep them */

@@ -272,18 +272,19 @@ def test_fused_path_matches_oracle_and_generic(gpu, orc, name, make):
     p = make()
     flat = oracle_flat_from_lti(orc, p)
     ref = orc.solve(flat, lambda0=p.lambda0)
-    rf, sf, fused = _solve_flat_tq(gpu, flat, p.lambda0, "auto")
-    rg, sg, fused_g = _solve_flat_tq(gpu, flat, p.lambda0, "generic")
-    assert fused and not fused_g
-    assert rf["status"] == rg["status"] == ref["status"] == 0
-    assert rf["iter"] == rg["iter"] == ref["iter"]
-    assert rf["ls_total"] == rg["ls_total"] == ref["ls_total"]
-    assert_solution_close(sf, ref, TOL)
-    assert_solution_close(sg, ref, TOL)
+    rf, sf, fused = _solve_flat_tq(gpu, flat, p.lambda0, "auto")          # persistent single launch
+    rt, stt, fused_t = _solve_flat_tq(gpu, flat, p.lambda0, "tiered")     # one launch per tier
+    rg, sg, fused_g = _solve_flat_tq(gpu, flat, p.lambda0, "generic")     # one launch per level
+    assert fused and fused_t and not fused_g
+    assert rf["status"] == rt["status"] == rg["status"] == ref["status"] == 0
+    assert rf["iter"] == rt["iter"] == rg["iter"] == ref["iter"]
+    assert rf["ls_total"] == rt["ls_total"] == rg["ls_total"] == ref["ls_total"]
+    for sol in (sf, stt, sg):
+        assert_solution_close(sol, ref, TOL)
+        assert orc.max_kkt(flat, sol) < 1e-8
     assert_solution_close(sf, sg, TOL)
-    assert orc.max_kkt(flat, sf) < 1e-8
-    # far fewer launches: 4 per Newton iteration instead of ~3 + 2*levels + 3
-    assert rf["n_launches"] < rg["n_launches"]
+    assert_solution_close(stt, sg, TOL)
+    assert rf["n_launches"] <= rt["n_launches"] < rg["n_launches"]
 
 
 @pytest.mark.parametrize("opts", [dict(regType=0), dict(regType=1, regValue=1e-8), dict(termCondition=0),

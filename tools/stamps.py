@@ -32,8 +32,8 @@ for kern in range(8):
     n = int((s[:, 1] > 0).sum())
     if n < 2:
         continue
-    if kern == 6:
-        print('fine stamps (cycles):', [int(v) for v in np.diff(s[:4, 0])], [int(v) for v in np.diff(s[8:12, 0])])
+    if kern == 7:
+        print('fine stamps (cycles) load_rows / sub_children / factor / store_block:', [int(v) for v in np.diff(s[:5, 0])])
         continue
     cyc = np.diff(s[:n, 0])
     wall = np.diff(s[:n, 1]) * 10.0          # 100 MHz -> ns

@@ -591,6 +591,7 @@ __global__ void __launch_bounds__(WAVE) k_ls_decide_parts(Data D, Opts O, const 
 }
 
 #include "tdunes_fast.hpp"
+#include "tdunes_persist.hpp"
 
 /* export_mu (clipping.c:386-399): mu = Q .* (xUnc - x) */
 __global__ void k_export_mu(int n_x, int n_u, Data D, double *mu_x, double *mu_u) {
@@ -636,6 +637,12 @@ struct tqgpu_solver {
     std::vector<int> tier_l0, tier_l1, tier_grid;
     size_t lds_fast = 0, lds_fstage = 0;
     int use_fast = 1;         /* can be switched off (TREEQP_AMD_PATH=generic) */
+    int use_persist = 1;      /* whole Newton loop in one launch when every tier workgroup can be co-resident */
+    bool persist_ok = false;
+    PGeom geom{};
+    PSync psync{};
+    void *sync_slab = nullptr;
+    size_t sync_words_bytes = 0, lds_persist = 0;
     /* sharded mode */
     int nranks = 1, rank = 0, part_top = -1;      /* part_top: highest partitioned tier */
     int *d_gh_list = nullptr, *d_node_list = nullptr, *d_node_cnt_list = nullptr, *d_blk_list = nullptr;
@@ -968,6 +975,57 @@ int launch_trial(tqgpu_solver *s, const Opts &O, bool fast, int it, int t, int &
     return TQGPU_OK;
 }
 
+
+/* persistent launch: geometry, sync words, co-residency test */
+int setup_persist(tqgpu_solver *s, int device) {
+    s->persist_ok = false;
+    if (s->fast < 0 || s->n_tiers > 8) return TQGPU_OK;
+    PGeom &G = s->geom;
+    G.n_tiers = s->n_tiers;
+    int wg = 0;
+    for (int i = 0; i < s->n_tiers; i++) { G.l0[i] = s->tier_l0[i]; G.l1[i] = s->tier_l1[i]; G.grid[i] = s->tier_grid[i]; G.wg0[i] = wg; wg += s->tier_grid[i]; }
+    G.G = wg;
+    int per_cu = 0;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    switch (s->fast) {
+#define X(idx, nx, nu, md)                                                                                                   \
+    case idx:                                                                                                                \
+        s->lds_persist = PLds<nx, nu, md>::DOUBLES * sizeof(double);                                                         \
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f_persist<nx, nu, md>, FW * WAVE, s->lds_persist));    \
+        break;
+        FAST_TABLE(X)
+#undef X
+        default: break;
+    }
+    /* every workgroup must be resident at once (they wait for each other); keep one block per CU of
+     * margin against the occupancy query over-reporting (MI355X guide, "Residency and cooperative launch") */
+    const int capacity = prop.multiProcessorCount * std::max(1, per_cu - 1);
+    if (per_cu < 1 || G.G > capacity) return TQGPU_OK;
+    const size_t nwords = 2 * (size_t)G.G + 8;
+    s->sync_words_bytes = (nwords * sizeof(unsigned) + 255) / 256 * 256;
+    const size_t bytes = s->sync_words_bytes + (2 * (size_t)G.G + (size_t)s->Nn + 16) * sizeof(double);
+    HIP_TRY(hipMalloc(&s->sync_slab, bytes));
+    HIP_TRY(hipMemset(s->sync_slab, 0, bytes));
+    unsigned *w = static_cast<unsigned *>(s->sync_slab);
+    s->psync.up_cnt = w; s->psync.down = w + G.G; s->psync.arrive = w + 2 * G.G; s->psync.go = w + 2 * G.G + 1; s->psync.timeout = w + 2 * G.G + 2;
+    double *d = reinterpret_cast<double *>(static_cast<char *>(s->sync_slab) + s->sync_words_bytes);
+    s->psync.parts = d; s->psync.errp = d + 2 * G.G;
+    s->persist_ok = true;
+    return TQGPU_OK;
+}
+
+void launch_persist(tqgpu_solver *s, const Opts &O, int &launches) {
+    const Tree &T = s->T; const Data &D = s->D; hipStream_t st = s->stream;
+    switch (s->fast) {
+#define X(idx, nx, nu, md) case idx: hipLaunchKernelGGL((f_persist<nx, nu, md>), dim3(s->geom.G), dim3(FW * WAVE), s->lds_persist, st, T, D, O, s->geom, s->psync); break;
+        FAST_TABLE(X)
+#undef X
+        default: break;
+    }
+    launches++;
+}
+
 void launch_generic_iteration(tqgpu_solver *s, const Opts &O, int h, int &launches) {
     const Tree &T = s->T; const Data &D = s->D; hipStream_t st = s->stream;
     hipLaunchKernelGGL(k_grad, dim3(T.Nn - 1), dim3(WAVE), 0, st, T, D, O.termCondition, h); launches++;
@@ -1008,6 +1066,7 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
     {
         const char *env = getenv("TREEQP_AMD_PATH");
         if (env && strcmp(env, "generic") == 0) s->use_fast = 0;
+        if (env && strcmp(env, "tiered") == 0) s->use_persist = 0;
         const char *ch = getenv("TREEQP_AMD_CHUNK");
         if (ch && atoi(ch) > 0) s->chunk = atoi(ch);
     }
@@ -1085,6 +1144,7 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) != hipSuccess || prop.maxThreadsPerBlock < FW * WAVE) s->fast = -1;
     }
+    if ((rc = setup_persist(s, device))) return cleanup_fail(rc);
     *out = s;
     return TQGPU_OK;
 }
@@ -1100,12 +1160,13 @@ extern "C" void tqgpu_destroy(tqgpu_solver *s) {
     if (s->h_ctrl) (void)hipHostFree(s->h_ctrl);
     if (s->h_ls_log) (void)hipHostFree(s->h_ls_log);
     if (s->shard_slab) (void)hipFree(s->shard_slab);
+    if (s->sync_slab) (void)hipFree(s->sync_slab);
     if (s->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(s->comm);
     if (s->slab) (void)hipFree(s->slab);
     delete s;
 }
 
-extern "C" int tqgpu_uses_fused_path(const tqgpu_solver *s) { return s && s->fast >= 0 && s->use_fast ? 1 : 0; }
+extern "C" int tqgpu_uses_fused_path(const tqgpu_solver *s) { return s && s->fast >= 0 && s->use_fast ? (s->persist_ok && s->use_persist && s->nranks == 1 ? 2 : 1) : 0; }
 
 /* diagnostic: copy the in-kernel time stamps of the last fused iteration (8 kernels x 32 slots x
  * {shader clock, 100 MHz wall clock}); only filled when TREEQP_AMD_STAMPS is set */
@@ -1224,13 +1285,16 @@ extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *r
      * Iterations enqueued beyond convergence, or while a line search still needs trials, are
      * no-ops by their phase guards. */
     const bool fast = s->fast >= 0 && s->use_fast;
+    const bool persist = fast && s->persist_ok && s->use_persist && s->nranks == 1 && !o->profile;
+    if (persist) HIP_TRY(hipMemsetAsync(s->sync_slab, 0, s->sync_words_bytes, st));
     int h = 0, ev_idx = 0;
     bool finished = o->maxIter <= 0;       /* nothing to iterate: reported as "maximum iterations" */
     if (finished) { HIP_TRY(hipStreamSynchronize(st)); memset(s->h_ctrl, 0, sizeof(Ctrl)); s->h_ctrl->status = 1; }
     if (o->profile) HIP_TRY(hipEventRecord(s->iter_ev[0], st));
     int chunk = s->last_iter > 0 ? std::min(s->last_iter + 1, 16) : s->chunk;
     while (!finished) {
-        const int n = std::min(chunk, o->maxIter - h);
+        const int n = persist ? 0 : std::min(chunk, o->maxIter - h);
+        if (persist) launch_persist(s, O, launches);
         for (int i = 0; i < n; i++) {
             if (fast) { int rcx = launch_fast_iteration(s, O, h + i, launches); if (rcx != TQGPU_OK) return rcx; }
             else launch_generic_iteration(s, O, h + i, launches);
@@ -1247,6 +1311,11 @@ extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *r
         h = s->h_ctrl->iter;
         finished = s->h_ctrl->done != 0;
         chunk = s->chunk;
+        if (persist && !finished) {
+            unsigned tmo = 0;
+            HIP_TRY(hipMemcpy(&tmo, s->psync.timeout, sizeof(unsigned), hipMemcpyDeviceToHost));
+            if (tmo) return fail(TQGPU_ENODEVICE, "persistent solve kernel: a bounded inter-workgroup wait timed out");
+        }
     }
     const int host_iter = ev_idx;
     HIP_TRY(hipEventRecord(s->ev1, st));

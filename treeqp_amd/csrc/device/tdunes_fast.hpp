@@ -30,6 +30,12 @@
 #pragma once
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
+/* LDS pointers carry their address space so that hipcc emits ds_read/ds_write, never flat_* */
+typedef __attribute__((address_space(3))) double lds_f64;
+typedef lds_f64 *lds_ptr;
+typedef const lds_f64 *lds_cptr;
+typedef __attribute__((address_space(3))) int *lds_iptr;
+__device__ __forceinline__ lds_ptr to_lds(double *p) { return (lds_ptr)p; }
 
 #define FW 4            /* waves per workgroup of the tier kernels: one per SIMD */
 
@@ -172,13 +178,13 @@ __device__ __forceinline__ void load_rows(const Data &Dt, int ii, int lane, bool
 }
 
 /* subtract the children's Schur complements; `sch` points at MD consecutive records (S then v) */
-template <int NX, int NU, int MD>
-__device__ __forceinline__ void sub_children(const double *sch, int lane, double (&T)[Uni<NX, NU, MD>::D]) {
+template <int NX, int NU, int MD, typename P>
+__device__ __forceinline__ void sub_children(P sch, int lane, double (&T)[Uni<NX, NU, MD>::D]) {
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D;
 #pragma unroll
     for (int c = 0; c < MD; c++) {
-        const double *S = sch + c * U::SCH, *v = S + NX * NX;
+        const P S = sch + c * U::SCH, v = S + NX * NX;
         const int r = lane - c * NX;
         if (lane < D && r >= 0 && r < NX) {
 #pragma unroll
@@ -210,59 +216,57 @@ __device__ __forceinline__ bool potrf_rows(double (&T)[D], int lane, double regT
     return small != 0;
 }
 
-/* stores of the factorised block + Schur complement for the parent.
- * sdst: where S (NX x NX) and v (NX) go (LDS record inside a tier, global Sbuf at a tier top) */
+/* factor rows, reciprocal diagonal, backward solution and CholUt of block ii to global memory:
+ * ONE store per column with a per-lane base + stride */
 template <int NX, int NU, int MD>
-__device__ __forceinline__ void store_block(const Data &Dt, int ii, int lane, const double (&T)[Uni<NX, NU, MD>::D],
-                                            double myinv, double *lds, double *sdst) {
+__device__ __forceinline__ void store_factor(const Data &Dt, int ii, int lane, const double (&T)[Uni<NX, NU, MD>::D], double myinv) {
+    using U = Uni<NX, NU, MD>;
+    constexpr int D = U::D, R = U::R;
+    const int bo = U::bo(ii);
+    double *dst; int stride;
+    if (lane < D) { dst = Dt.CholW + (size_t)ii * D * D + lane; stride = D; }
+    else if (lane == D) { dst = Dt.ybuf + bo; stride = 1; }
+    else { dst = Dt.CholUt + (size_t)(ii - 1) * NX * D + (lane - D - 1); stride = NX; }
+    if (lane < R) {
+#pragma unroll
+        for (int j = 0; j < D; j++) dst[(size_t)j * stride] = T[j];
+    }
+    if (lane < D) Dt.invd[bo + lane] = myinv;
+}
+
+/* Schur record for the parent: [S | v] = CUt * [CUt' | y] as one f64 MFMA tile (K = D).  Rows
+ * D .. R-1 of T go through the wave's LDS scratch; lane (i, g) feeds row 1+i as A and row 1+i
+ * (i < NX) or row 0 (= y, i == NX) as B.  sdst: LDS record inside a tier or global Sbuf. */
+template <int NX, int NU, int MD, typename PD>
+__device__ __forceinline__ void schur_record(int lane, const double (&T)[Uni<NX, NU, MD>::D], lds_ptr lds, PD sdst) {
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D, R = U::R, LDW = U::LDW;
-    const int bo = U::bo(ii);
-    if (lane < D) {
-        double *L = Dt.CholW + (size_t)ii * D * D + lane;
-#pragma unroll
-        for (int j = 0; j < D; j++) L[(size_t)j * D] = T[j];
-        Dt.invd[bo + lane] = myinv;
-    }
-    if (lane == D) {
-#pragma unroll
-        for (int j = 0; j < D; j++) Dt.ybuf[bo + j] = T[j];
-    }
-    if (lane > D && lane < R) {
-        double *CUt = Dt.CholUt + (size_t)(ii - 1) * NX * D + (lane - D - 1);
-#pragma unroll
-        for (int j = 0; j < D; j++) CUt[(size_t)j * NX] = T[j];
-    }
-    /* S = CUt CUt', v = CUt y through the wave's LDS scratch (rows D .. R-1 of T) */
     if (lane >= D && lane < R) {
 #pragma unroll
         for (int j = 0; j < D; j++) lds[(lane - D) * LDW + j] = T[j];
     }
     lds_fence();
-    /* [S | v] = CUt * [CUt' | y] as one f64 MFMA tile (K = D): lane (i, g) feeds row 1+i of the
-     * scratch as A and row 1+i (i < NX) or row 0 (= y, i == NX) as B */
-    {
-        const int i = lane & 15, g = lane >> 4;
-        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+    const int i = lane & 15, g = lane >> 4;
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int st = 0; st < D / 4; st++) {
-            const int kk = g + 4 * st;
-            const double m = (i <= NX) ? lds[(i < NX ? 1 + i : 0) * LDW + kk] : 0.0;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(i < NX ? m : 0.0, m, acc, 0, 0, 0);
-        }
+    for (int st = 0; st < D / 4; st++) {
+        const int kk = g + 4 * st;
+        const double m = (i <= NX) ? lds[(i < NX ? 1 + i : 0) * LDW + kk] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(i < NX ? m : 0.0, m, acc, 0, 0, 0);
+    }
 #pragma unroll
-        for (int rr = 0; rr < 4; rr++) {
-            const int ip = g + 4 * rr;                 /* acc[rr] = [S | v][ip][i] */
-            if (ip < NX) {
-                if (i < NX) sdst[ip + i * NX] = acc[rr];
-                else if (i == NX) sdst[NX * NX + ip] = acc[rr];
-            }
+    for (int rr = 0; rr < 4; rr++) {
+        const int ip = g + 4 * rr;                 /* acc[rr] = [S | v][ip][i] */
+        if (ip < NX) {
+            if (i < NX) sdst[ip + i * NX] = acc[rr];
+            else if (i == NX) sdst[NX * NX + ip] = acc[rr];
         }
     }
     lds_fence();
 }
 
-/* regularised factorisation of the rows in T (treeqp_dpotrf_l_with_reg_opts, dual_Newton_common.c:36-78) */
+/* regularised factorisation of the rows in T (treeqp_dpotrf_l_with_reg_opts, dual_Newton_common.c:36-78);
+ * ONE copy of the unrolled factorisation in the instruction stream: the on-the-fly retry loops back */
 template <int NX, int NU, int MD>
 __device__ __forceinline__ void factor_rows(const Data &Dt, const Opts &O, int lane, double (&T)[Uni<NX, NU, MD>::D], double &myinv) {
     constexpr int D = Uni<NX, NU, MD>::D;
@@ -270,55 +274,27 @@ __device__ __forceinline__ void factor_rows(const Data &Dt, const Opts &O, int l
 #pragma unroll
         for (int j = 0; j < D; j++) if (lane == j) T[j] += O.regValue;            /* ddiare (ALWAYS) */
     }
-    if (O.regType != 2) {
-        potrf_rows<D>(T, lane, O.regTol, myinv);
-    } else {
-        double K[D];
+    double K[D];
 #pragma unroll
-        for (int j = 0; j < D; j++) K[j] = T[j];
-        if (potrf_rows<D>(T, lane, O.regTol, myinv)) {                           /* rare: shift and refactorise */
+    for (int j = 0; j < D; j++) K[j] = T[j];
+    for (int pass = 0; pass < 2; pass++) {
+        const bool small = potrf_rows<D>(T, lane, O.regTol, myinv);
+        if (O.regType != 2 || !small || pass == 1) break;
 #pragma unroll
-            for (int j = 0; j < D; j++) T[j] = (lane == j) ? K[j] + O.regValue : K[j];
-            potrf_rows<D>(T, lane, O.regTol, myinv);
-            if (lane == 0) atomicAdd(&Dt.ctrl->n_reg, 1);
-        }
+        for (int j = 0; j < D; j++) T[j] = (lane == j) ? K[j] + O.regValue : K[j];   /* rare: shift and refactorise */
+        if (lane == 0) atomicAdd(&Dt.ctrl->n_reg, 1);
     }
 }
 
-/* one complete backward step; `kids_sch` = Schur records of the MD children (LDS or global) or
- * nullptr for blocks of the last level */
-template <int NX, int NU, int MD>
-__device__ __forceinline__ void backward_block(const Data &Dt, const Opts &O, int ii, int lane, double (&T)[Uni<NX, NU, MD>::D],
-                                               const double *kids_sch, double *lds, double *sdst) {
-    double myinv = 0.0;
-#ifdef TQ_FINE_STAMPS
-    int fs = (ii == 8 || ii == 1) ? (ii == 8 ? 0 : 8) : 100;      /* block 8: first of level 3 (tier 1 bottom); block 1 */
-    stamp(Dt, O, 6, fs++);
-#endif
-    if (kids_sch) sub_children<NX, NU, MD>(kids_sch, lane, T);
-#ifdef TQ_FINE_STAMPS
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    stamp(Dt, O, 6, fs++);
-#endif
-    factor_rows<NX, NU, MD>(Dt, O, lane, T, myinv);
-#ifdef TQ_FINE_STAMPS
-    stamp(Dt, O, 6, fs++);
-#endif
-    store_block<NX, NU, MD>(Dt, ii, lane, T, myinv, lds, sdst);
-#ifdef TQ_FINE_STAMPS
-    stamp(Dt, O, 6, fs++);
-#endif
-}
-
-/* root: factor [W_0 ; resMod_0'], then dlam_0 = L^-T y (k descending), dot-product partial */
+/* root: T holds [W_0 ; resMod_0'] minus the children's records; factor, then dlam_0 = L^-T y (k
+ * descending) with lane i owning column i of L after a transpose through LDS; dot-product partial */
 template <int NX, int NU, int MD>
 __device__ __forceinline__ void root_block(const Data &Dt, const Opts &O, int lane, double (&T)[Uni<NX, NU, MD>::D],
-                                           const double *kids_sch, double *lds, double *dl_out) {
+                                           lds_ptr lds, lds_ptr dl_out) {
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D;
     const int bo = U::bo(0);
     double myinv = 0.0;
-    if (kids_sch) sub_children<NX, NU, MD>(kids_sch, lane, T);
     factor_rows<NX, NU, MD>(Dt, O, lane, T, myinv);
     if (lane < D) {
         double *L = Dt.CholW + lane;
@@ -326,7 +302,6 @@ __device__ __forceinline__ void root_block(const Data &Dt, const Opts &O, int la
         for (int j = 0; j < D; j++) L[(size_t)j * D] = T[j];
         Dt.invd[bo + lane] = myinv;
     }
-    /* dlam_0 = L^-T y: transpose through the wave's LDS scratch so that lane i owns column i of L */
     if (lane <= D) {
 #pragma unroll
         for (int j = 0; j < D; j++) lds[lane * U::LDW + j] = T[j];
@@ -380,9 +355,9 @@ __device__ __forceinline__ void load_fwd(const Data &Dt, int ii, int lane, FwdRe
 }
 
 /* delta: the NX entries of the parent's solution that belong to node ii (LDS or global) */
-template <int NX, int NU, int MD>
+template <int NX, int NU, int MD, typename PDelta>
 __device__ __forceinline__ void forward_block(const Data &Dt, int ii, int lane, const FwdRegs<NX, NU, MD> &F,
-                                              const double *delta, double *dl_out) {
+                                              PDelta delta, lds_ptr dl_out) {
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D;
     double acc = 0.0;
@@ -397,7 +372,7 @@ __device__ __forceinline__ void forward_block(const Data &Dt, int ii, int lane, 
         if (lane < k) s = fma(-F.Lcol[k], zk, s);
     }
     double pd = 0.0;
-    if (lane < D) { Dt.dlam[U::bo(ii) + lane] = mine; if (dl_out) dl_out[lane] = mine; pd = F.res * mine; }
+    if (lane < D) { Dt.dlam[U::bo(ii) + lane] = mine; dl_out[lane] = mine; pd = F.res * mine; }
     pd = wave_sum(pd);
     if (lane == 0) Dt.part_dot[ii] = pd;
 }
@@ -406,7 +381,7 @@ __device__ __forceinline__ void forward_block(const Data &Dt, int ii, int lane, 
 /* termination test run by the kernel that comes second in an iteration: every workgroup        */
 /* reduces the per-workgroup partials of the first kernel; workgroup 0 records the decision     */
 /* ------------------------------------------------------------------------------------------ */
-__device__ __forceinline__ bool converged_now(const Data &Dt, const Opts &O, const double *parts, int nparts, int *flag_lds) {
+__device__ __forceinline__ bool converged_now(const Data &Dt, const Opts &O, const double *parts, int nparts, lds_iptr flag_lds) {
     if (threadIdx.x < WAVE) {
         double e = 0.0;
         for (int i = threadIdx.x; i < nparts; i += WAVE) e = (O.termCondition == 2) ? fmax(e, parts[i]) : e + parts[i];
@@ -432,14 +407,14 @@ __device__ __forceinline__ bool converged_now(const Data &Dt, const Opts &O, con
 template <int NX, int NU, int MD>
 struct TierLds {
     using U = Uni<NX, NU, MD>;
-    double *sch;       /* NBT Schur records, heap order inside the tier subtree */
-    double *dl;        /* NBT block solutions (forward sweep)                   */
-    double *wave0;     /* scratch of wave 0                                     */
-    double *wave;      /* this wave's scratch                                   */
-    int *flag;
+    lds_ptr sch;       /* NBT Schur records, heap order inside the tier subtree */
+    lds_ptr dl;        /* NBT block solutions (forward sweep)                   */
+    lds_ptr wave0;     /* scratch of wave 0                                     */
+    lds_ptr wave;      /* this wave's scratch                                   */
+    lds_iptr flag;
     __device__ TierLds(double *base, int wave_id) {
-        sch = base; dl = sch + U::NBT * U::SCH; wave0 = dl + U::NBT * U::D; wave = wave0 + wave_id * U::WAVE_LDS;
-        flag = reinterpret_cast<int *>(wave0 + FW * U::WAVE_LDS);
+        sch = to_lds(base); dl = sch + U::NBT * U::SCH; wave0 = dl + U::NBT * U::D; wave = wave0 + wave_id * U::WAVE_LDS;
+        flag = (lds_iptr)(wave0 + FW * U::WAVE_LDS);
     }
 };
 
@@ -508,11 +483,13 @@ __global__ void __launch_bounds__(FW * WAVE) f_back(Tree T, Data Dt, Opts O, Sha
         if (act) {
             const int ii = U::first(l0 + t) + s * nb + wave;
             const int loc = U::first(t) + wave;                       /* heap index inside the tier subtree */
-            const double *kids = nullptr;
-            if (t < th - 1) kids = L.sch + (U::first(t + 1) + MD * wave) * U::SCH;          /* children in this tier: LDS */
-            else if (l1 < T.Nh) kids = Dt.Sbuf + (size_t)U::kid0(ii) * U::SCH;              /* children in the tier below  */
-            double *sdst = (t > 0) ? L.sch + loc * U::SCH : Dt.Sbuf + (size_t)ii * U::SCH;
-            backward_block<NX, NU, MD>(Dt, O, ii, lane, Tc, kids, L.wave, sdst);
+            if (t < th - 1) sub_children<NX, NU, MD>(L.sch + (U::first(t + 1) + MD * wave) * U::SCH, lane, Tc);     /* children in this tier: LDS */
+            else if (l1 < T.Nh) sub_children<NX, NU, MD>((const double *)(Dt.Sbuf + (size_t)U::kid0(ii) * U::SCH), lane, Tc);   /* tier below */
+            double myinv = 0.0;
+            factor_rows<NX, NU, MD>(Dt, O, lane, Tc, myinv);
+            store_factor<NX, NU, MD>(Dt, ii, lane, Tc, myinv);
+            if (t > 0) schur_record<NX, NU, MD>(lane, Tc, L.wave, L.sch + loc * U::SCH);
+            else schur_record<NX, NU, MD>(lane, Tc, L.wave, Dt.Sbuf + (size_t)ii * U::SCH);
         }
         lds_barrier();
         if (act_next) {
@@ -558,10 +535,12 @@ __global__ void __launch_bounds__(FW * WAVE) f_top(Tree T, Data Dt, Opts O, Shar
         if (act_next) load_rows<NX, NU, MD>(Dt, U::first(t - 1) + wave, lane, t - 1 == 0, Tn);
         if (act) {
             const int ii = U::first(t) + wave;
-            const double *kids = nullptr;
-            if (t < l1 - 1) kids = L.sch + (U::first(t + 1) + MD * wave) * U::SCH;
-            else if (l1 < T.Nh) kids = Dt.Sbuf + (size_t)U::kid0(ii) * U::SCH;
-            backward_block<NX, NU, MD>(Dt, O, ii, lane, Tc, kids, L.wave, L.sch + ii * U::SCH);
+            if (t < l1 - 1) sub_children<NX, NU, MD>(L.sch + (U::first(t + 1) + MD * wave) * U::SCH, lane, Tc);
+            else if (l1 < T.Nh) sub_children<NX, NU, MD>((const double *)(Dt.Sbuf + (size_t)U::kid0(ii) * U::SCH), lane, Tc);
+            double myinv = 0.0;
+            factor_rows<NX, NU, MD>(Dt, O, lane, Tc, myinv);
+            store_factor<NX, NU, MD>(Dt, ii, lane, Tc, myinv);
+            schur_record<NX, NU, MD>(lane, Tc, L.wave, L.sch + ii * U::SCH);
         }
         lds_barrier();
         if (act_next) {
@@ -571,10 +550,9 @@ __global__ void __launch_bounds__(FW * WAVE) f_top(Tree T, Data Dt, Opts O, Shar
         stamp(Dt, O, kern, sl++);
     }
     if (wave == 0) {
-        const double *kids = nullptr;
-        if (l1 > 1) kids = L.sch + 1 * U::SCH;
-        else if (l1 < T.Nh) kids = Dt.Sbuf + (size_t)1 * U::SCH;
-        root_block<NX, NU, MD>(Dt, O, lane, Tc, kids, L.wave, L.dl);
+        if (l1 > 1) sub_children<NX, NU, MD>(L.sch + 1 * U::SCH, lane, Tc);
+        else if (l1 < T.Nh) sub_children<NX, NU, MD>((const double *)(Dt.Sbuf + (size_t)1 * U::SCH), lane, Tc);
+        root_block<NX, NU, MD>(Dt, O, lane, Tc, L.wave, L.dl);
     }
     __syncthreads();                             /* factors written above are re-read below */
     stamp(Dt, O, kern, sl++);
@@ -585,7 +563,7 @@ __global__ void __launch_bounds__(FW * WAVE) f_top(Tree T, Data Dt, Opts O, Shar
             FwdRegs<NX, NU, MD> F;
             load_fwd<NX, NU, MD>(Dt, ii, lane, F);
             const int par = (ii - 1) / MD, pos = ((ii - 1) % MD) * NX;
-            forward_block<NX, NU, MD>(Dt, ii, lane, F, L.dl + par * D + pos, L.dl + ii * D);
+            forward_block<NX, NU, MD>(Dt, ii, lane, F, (lds_cptr)(L.dl + par * D + pos), L.dl + ii * D);
         }
         lds_barrier();
         stamp(Dt, O, kern, sl++);
@@ -614,10 +592,8 @@ __global__ void __launch_bounds__(FW * WAVE) f_fwd(Tree T, Data Dt, Opts O, Shar
         if (act) {
             const int ii = U::first(l0 + t) + s * nb + wave;
             const int loc = U::first(t) + wave;
-            const double *delta;
-            if (t == 0) delta = Dt.dlam + NX * ii;                                   /* parent in the tier above: memory */
-            else delta = L.dl + (U::first(t - 1) + wave / MD) * D + (wave % MD) * NX;   /* parent in this tier: LDS */
-            forward_block<NX, NU, MD>(Dt, ii, lane, Fc, delta, L.dl + loc * D);
+            if (t == 0) forward_block<NX, NU, MD>(Dt, ii, lane, Fc, (const double *)(Dt.dlam + NX * ii), L.dl + loc * D);     /* parent in the tier above: memory */
+            else forward_block<NX, NU, MD>(Dt, ii, lane, Fc, (lds_cptr)(L.dl + (U::first(t - 1) + wave / MD) * D + (wave % MD) * NX), L.dl + loc * D);   /* this tier: LDS */
         }
         lds_barrier();
         if (act_next) Fc = Fn;
