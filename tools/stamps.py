@@ -9,7 +9,7 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
-os.environ["TREEQP_AMD_STAMPS"] = "1"
+os.environ.setdefault("TREEQP_AMD_STAMPS", "2")      # persistent path: the launch-relative iteration to stamp
 from treeqp_amd import capi, problems as P
 
 Nr = int(sys.argv[1]) if len(sys.argv) > 1 else 9
@@ -20,7 +20,7 @@ nu = np.where(nk > 0, p.nu, 0).astype(np.int32)
 qp = capi.TreeQp(nx, nu, nk).fill_lti(p)
 g = capi.TqGpu(nk, nx, nu).upload(qp.flat(), p.lambda0)
 for _ in range(5):
-    r = g.solve(maxIter=1)          # one real iteration so that the stamps belong to a full iteration
+    r = g.solve(maxIter=1) if g.fused != 2 else g.solve()   # tiered: one real iteration; persistent: full solve, iteration $TREEQP_AMD_STAMPS
 print(r)
 buf = np.zeros(8 * 32 * 2, dtype=np.uint64)
 capi.lib().tqgpu_get_stamps(g.h, buf.ctypes.data_as(C.POINTER(C.c_ulonglong)), len(buf))
@@ -33,7 +33,7 @@ for kern in range(8):
     if n < 2:
         continue
     if kern == 7:
-        print('fine stamps (cycles) load_rows / sub_children / factor / store_block:', [int(v) for v in np.diff(s[:5, 0])])
+        print('fine stamps (cycles) load_rows / sub_children / factor / store_block:', [int(v) for v in np.diff(s[:6, 0])])
         continue
     cyc = np.diff(s[:n, 0])
     wall = np.diff(s[:n, 1]) * 10.0          # 100 MHz -> ns

@@ -985,13 +985,14 @@ int setup_persist(tqgpu_solver *s, int device) {
     int wg = 0;
     for (int i = 0; i < s->n_tiers; i++) { G.l0[i] = s->tier_l0[i]; G.l1[i] = s->tier_l1[i]; G.grid[i] = s->tier_grid[i]; G.wg0[i] = wg; wg += s->tier_grid[i]; }
     G.G = wg;
-    int per_cu = 0;
+    int per_cu = 0, parts_cap = 0, err_cap = 0;
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     switch (s->fast) {
 #define X(idx, nx, nu, md)                                                                                                   \
     case idx:                                                                                                                \
         s->lds_persist = PLds<nx, nu, md>::DOUBLES * sizeof(double);                                                         \
+        parts_cap = PLds<nx, nu, md>::PARTS_CAP; err_cap = PLds<nx, nu, md>::ERR_CAP;                                        \
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f_persist<nx, nu, md>, FW * WAVE, s->lds_persist));    \
         break;
         FAST_TABLE(X)
@@ -1001,29 +1002,36 @@ int setup_persist(tqgpu_solver *s, int device) {
     /* every workgroup must be resident at once (they wait for each other); keep one block per CU of
      * margin against the occupancy query over-reporting (MI355X guide, "Residency and cooperative launch") */
     const int capacity = prop.multiProcessorCount * std::max(1, per_cu - 1);
-    if (per_cu < 1 || G.G > capacity) return TQGPU_OK;
-    const size_t nwords = 2 * (size_t)G.G + 8;
-    s->sync_words_bytes = (nwords * sizeof(unsigned) + 255) / 256 * 256;
-    const size_t bytes = s->sync_words_bytes + (2 * (size_t)G.G + (size_t)s->Nn + 16) * sizeof(double);
+    if (per_cu < 1 || G.G > capacity || G.G > parts_cap || G.G > err_cap) return TQGPU_OK;
+    /* words: up_cnt[G], st_cnt[G], down[G], then five single words on their own 128-byte lines */
+    const size_t arrays = (3 * (size_t)G.G + 31) / 32 * 32;
+    const size_t nwords = arrays + 5 * 32;
+    s->sync_words_bytes = nwords * sizeof(unsigned);
+    const size_t bytes = s->sync_words_bytes + (3 * (size_t)G.G + 16) * sizeof(double);
     HIP_TRY(hipMalloc(&s->sync_slab, bytes));
     HIP_TRY(hipMemset(s->sync_slab, 0, bytes));
     unsigned *w = static_cast<unsigned *>(s->sync_slab);
-    s->psync.up_cnt = w; s->psync.down = w + G.G; s->psync.arrive = w + 2 * G.G; s->psync.go = w + 2 * G.G + 1; s->psync.timeout = w + 2 * G.G + 2;
+    s->psync.up_cnt = w; s->psync.st_cnt = w + G.G; s->psync.down = w + 2 * G.G;
+    s->psync.arrive = w + arrays; s->psync.go = w + arrays + 32; s->psync.err_cnt = w + arrays + 64;
+    s->psync.halt = w + arrays + 96; s->psync.timeout = w + arrays + 128;
     double *d = reinterpret_cast<double *>(static_cast<char *>(s->sync_slab) + s->sync_words_bytes);
     s->psync.parts = d; s->psync.errp = d + 2 * G.G;
     s->persist_ok = true;
     return TQGPU_OK;
 }
 
-void launch_persist(tqgpu_solver *s, const Opts &O, int &launches) {
+/* one persistent launch: zero the inter-workgroup words, then the kernel (prologue = first sweep of the solve) */
+int launch_persist(tqgpu_solver *s, const Opts &O, int &launches, int prologue) {
     const Tree &T = s->T; const Data &D = s->D; hipStream_t st = s->stream;
+    HIP_TRY(hipMemsetAsync(s->sync_slab, 0, s->sync_words_bytes, st));
     switch (s->fast) {
-#define X(idx, nx, nu, md) case idx: hipLaunchKernelGGL((f_persist<nx, nu, md>), dim3(s->geom.G), dim3(FW * WAVE), s->lds_persist, st, T, D, O, s->geom, s->psync); break;
+#define X(idx, nx, nu, md) case idx: hipLaunchKernelGGL((f_persist<nx, nu, md>), dim3(s->geom.G), dim3(FW * WAVE), s->lds_persist, st, T, D, O, s->geom, s->psync, (const double *)s->d_lam_init, prologue); break;
         FAST_TABLE(X)
 #undef X
         default: break;
     }
     launches++;
+    return TQGPU_OK;
 }
 
 void launch_generic_iteration(tqgpu_solver *s, const Opts &O, int h, int &launches) {
@@ -1248,7 +1256,7 @@ extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *r
     O.lsMaxIter = o->lineSearchMaxIter; O.lsRestartTrigger = o->lineSearchRestartTrigger;
     O.tol = o->stationarityTolerance; O.regTol = o->regTol; O.regValue = o->regValue;
     O.gamma = o->lineSearchGamma; O.beta = o->lineSearchBeta;
-    O.stamps = getenv("TREEQP_AMD_STAMPS") ? 1 : 0;
+    { const char *e = getenv("TREEQP_AMD_STAMPS"); O.stamps = e ? std::max(1, atoi(e)) : 0; }
     if (O.termCondition < 0 || O.termCondition > 2 || O.regType < 0 || O.regType > 2 || O.regValue < 0)
         return fail(TQGPU_EINVAL, "invalid option value");
 
@@ -1258,35 +1266,33 @@ extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *r
     int launches = 0;
     const int nxu = std::max(s->sum_nx, s->sum_nu);
 
-    Ctrl init;
-    memset(&init, 0, sizeof(init));
-    HIP_TRY(hipMemcpyAsync(D.ctrl, &init, sizeof(Ctrl), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(D.ls_log, 0, sizeof(int) * (size_t)s->ls_log_cap, st));
-    HIP_TRY(hipStreamSynchronize(st));     /* `init` lives on this stack frame */
+    HIP_TRY(hipMemsetAsync(D.ctrl, 0, sizeof(Ctrl), st));      /* ls_log needs no reset: entry i is written by iteration i */
 
     if (o->profile) {
         while ((int)s->iter_ev.size() < o->maxIter + 1) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); s->iter_ev.push_back(ev); }
     }
     s->iter_times.assign((size_t)std::max(o->maxIter, 1), NAN);
 
+    const bool fast = s->fast >= 0 && s->use_fast;
+    const bool persist = fast && s->persist_ok && s->use_persist && s->nranks == 1 && !o->profile && o->maxIter > 0;
     HIP_TRY(hipEventRecord(s->ev0, st));
-    /* the current buffer is lam0 at the start of every solve */
-    HIP_TRY(hipMemcpyAsync(D.lam0, s->d_lam_init, sizeof(double) * (size_t)s->sum_nx, hipMemcpyDeviceToDevice, st));
     if (s->need_init) {
         hipLaunchKernelGGL(k_init, dim3((nxu + 255) / 256), dim3(256), 0, st, s->sum_nx, s->sum_nu, D); launches++;
         s->need_init = false;
     }
-    /* first sweep at lambda0 (phase S of iteration 0 + fval0) */
-    hipLaunchKernelGGL(k_stage, dim3(T.Nn), dim3(WAVE), s->lds_stage, st, T, D, 0, 0, 0); launches++;
-    hipLaunchKernelGGL(k_fval_init, dim3(1), dim3(256), 0, st, T, D); launches++;
+    if (!persist) {
+        /* the current buffer is lam0 at the start of every solve */
+        HIP_TRY(hipMemcpyAsync(D.lam0, s->d_lam_init, sizeof(double) * (size_t)s->sum_nx, hipMemcpyDeviceToDevice, st));
+        /* first sweep at lambda0 (phase S of iteration 0 + fval0); the persistent launch does it as its prologue */
+        hipLaunchKernelGGL(k_stage, dim3(T.Nn), dim3(WAVE), s->lds_stage, st, T, D, 0, 0, 0); launches++;
+        hipLaunchKernelGGL(k_fval_init, dim3(1), dim3(256), 0, st, T, D); launches++;
+    }
 
     /* Newton loop (dual_Newton_tree.c:1166-1228).  The device decides (termination, Armijo);
      * the host enqueues `chunk` tagged iterations ahead and reads the control block once per chunk.
      * Iterations enqueued beyond convergence, or while a line search still needs trials, are
      * no-ops by their phase guards. */
-    const bool fast = s->fast >= 0 && s->use_fast;
-    const bool persist = fast && s->persist_ok && s->use_persist && s->nranks == 1 && !o->profile;
-    if (persist) HIP_TRY(hipMemsetAsync(s->sync_slab, 0, s->sync_words_bytes, st));
+    bool first_launch = true;
     int h = 0, ev_idx = 0;
     bool finished = o->maxIter <= 0;       /* nothing to iterate: reported as "maximum iterations" */
     if (finished) { HIP_TRY(hipStreamSynchronize(st)); memset(s->h_ctrl, 0, sizeof(Ctrl)); s->h_ctrl->status = 1; }
@@ -1294,7 +1300,7 @@ extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *r
     int chunk = s->last_iter > 0 ? std::min(s->last_iter + 1, 16) : s->chunk;
     while (!finished) {
         const int n = persist ? 0 : std::min(chunk, o->maxIter - h);
-        if (persist) launch_persist(s, O, launches);
+        if (persist) { int rcx = launch_persist(s, O, launches, first_launch ? 1 : 0); if (rcx != TQGPU_OK) return rcx; first_launch = false; }
         for (int i = 0; i < n; i++) {
             if (fast) { int rcx = launch_fast_iteration(s, O, h + i, launches); if (rcx != TQGPU_OK) return rcx; }
             else launch_generic_iteration(s, O, h + i, launches);
@@ -1319,7 +1325,7 @@ extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *r
     }
     const int host_iter = ev_idx;
     HIP_TRY(hipEventRecord(s->ev1, st));
-    HIP_TRY(hipMemcpyAsync(s->h_ls_log, D.ls_log, sizeof(int) * (size_t)s->ls_log_cap, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(s->h_ls_log, D.ls_log, sizeof(int) * (size_t)std::min(s->ls_log_cap, std::max(o->maxIter, 1)), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return fail(TQGPU_ENODEVICE, std::string("kernel launch failed: ") + hipGetErrorString(le));

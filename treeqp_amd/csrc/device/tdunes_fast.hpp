@@ -177,23 +177,33 @@ __device__ __forceinline__ void load_rows(const Data &Dt, int ii, int lane, bool
     for (int j = 0; j < D; j++) T[j] = src[(size_t)j * stride];
 }
 
-/* subtract the children's Schur complements; `sch` points at MD consecutive records (S then v) */
-template <int NX, int NU, int MD, typename P>
+/* subtract the children's Schur complements; `sch` points at MD consecutive records (S then v).
+ * Branch-free: every lane issues all MD*NX loads from a valid address (per-lane base + stride) and
+ * masks afterwards, so the loads overlap instead of serialising behind divergent branches.
+ * SC1: records written by another workgroup of the same launch (agent-scope loads). */
+template <int NX, int NU, int MD, bool SC1 = false, typename P>
 __device__ __forceinline__ void sub_children(P sch, int lane, double (&T)[Uni<NX, NU, MD>::D]) {
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D;
+    const bool vrow = lane == D;
+    const int lc = lane < D ? lane / NX : 0;
+    const int r = lane < D ? lane - lc * NX : 0;
+    const int off = vrow ? NX * NX : r, stride = vrow ? 1 : NX;
+    double v[MD][NX];
 #pragma unroll
     for (int c = 0; c < MD; c++) {
-        const P S = sch + c * U::SCH, v = S + NX * NX;
-        const int r = lane - c * NX;
-        if (lane < D && r >= 0 && r < NX) {
+        const P src = sch + c * U::SCH + off;
 #pragma unroll
-            for (int j = 0; j < NX; j++) T[c * NX + j] -= S[r + j * NX];
+        for (int j = 0; j < NX; j++) {
+            if constexpr (SC1) v[c][j] = __hip_atomic_load(src + j * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else v[c][j] = src[j * stride];
         }
-        if (lane == D) {
+    }
 #pragma unroll
-            for (int j = 0; j < NX; j++) T[c * NX + j] -= v[j];
-        }
+    for (int c = 0; c < MD; c++) {
+        const bool act = vrow || (lane < D && lc == c);
+#pragma unroll
+        for (int j = 0; j < NX; j++) T[c * NX + j] -= act ? v[c][j] : 0.0;
     }
 }
 
