@@ -20,7 +20,7 @@ nu = np.where(nk > 0, p.nu, 0).astype(np.int32)
 qp = capi.TreeQp(nx, nu, nk).fill_lti(p)
 g = capi.TqGpu(nk, nx, nu).upload(qp.flat(), p.lambda0)
 for _ in range(5):
-    r = g.solve(maxIter=1) if g.fused != 2 else g.solve()   # tiered: one real iteration; persistent: full solve, iteration $TREEQP_AMD_STAMPS
+    r = g.solve(maxIter=1) if g.path != 2 else g.solve()   # tiered: one real iteration; persistent: full solve, iteration $TREEQP_AMD_STAMPS
 print(r)
 buf = np.zeros(8 * 32 * 2, dtype=np.uint64)
 capi.lib().tqgpu_get_stamps(g.h, buf.ctypes.data_as(C.POINTER(C.c_ulonglong)), len(buf))

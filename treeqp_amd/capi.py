@@ -435,6 +435,11 @@ class TqGpu:
     def fused(self) -> bool:
         return bool(lib().tqgpu_uses_fused_path(self.h))
 
+    @property
+    def path(self) -> int:
+        """0 generic per-level kernels, 1 tiered fused kernels, 2 persistent single launch."""
+        return int(lib().tqgpu_uses_fused_path(self.h))
+
     def _chk(self, rc):
         if rc != 0:
             raise RuntimeError(f"tqgpu call failed ({rc}): {lib().tqgpu_last_error().decode()}")

@@ -70,6 +70,40 @@ __device__ __forceinline__ double rdlane(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
+/* Cross-lane sums without LDS round trips (all 64 lanes must be active):
+ *   dpp_mov<row_ror:n>  rotate inside each row of 16 lanes (one VALU op per 32-bit half),
+ *   v_permlane16/32_swap (gfx950) fold the rows.  Every lane ends with the full sum. */
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_sum(double v) {
+    v += dpp_mov<0x128>(v); v += dpp_mov<0x124>(v); v += dpp_mov<0x122>(v); v += dpp_mov<0x121>(v);
+    return v;
+}
+__device__ __forceinline__ double row16_max(double v) {
+    v = fmax(v, dpp_mov<0x128>(v)); v = fmax(v, dpp_mov<0x124>(v)); v = fmax(v, dpp_mov<0x122>(v)); v = fmax(v, dpp_mov<0x121>(v));
+    return v;
+}
+/* value of lane l combined with lanes l ^ 16, l ^ 32, l ^ 48 */
+template <bool IS_MAX = false>
+__device__ __forceinline__ double rows_fold(double v) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const double x0 = __hiloint2double((int)b[0], (int)a[0]), x1 = __hiloint2double((int)b[1], (int)a[1]);
+    const double x = IS_MAX ? fmax(x0, x1) : x0 + x1;
+    const unsigned xl = (unsigned)__double2loint(x), xh = (unsigned)__double2hiint(x);
+    auto c = __builtin_amdgcn_permlane32_swap(xl, xl, false, false);
+    auto d = __builtin_amdgcn_permlane32_swap(xh, xh, false, false);
+    const double y0 = __hiloint2double((int)d[0], (int)c[0]), y1 = __hiloint2double((int)d[1], (int)c[1]);
+    return IS_MAX ? fmax(y0, y1) : y0 + y1;
+}
+__device__ __forceinline__ double wsum(double v) { return rows_fold<false>(row16_sum(v)); }
+__device__ __forceinline__ double wmax(double v) { return rows_fold<true>(row16_max(v)); }
+
 /* 1/sqrt(p) for p > 0, 0 otherwise (non-positive pivot -> zero column, as dpotrf_l) */
 __device__ __forceinline__ double pivot_rsqrt(double p) {
     double y = __builtin_amdgcn_rsq(p);
@@ -135,8 +169,7 @@ __device__ __forceinline__ double fast_gh(const Data &Dt, int p, int lane, int t
         if (p > 0 && live && cc < NX) Ut[cc + (size_t)row * NX] = -1.0 * ap;      /* Ut = -(A Qcal)' */
     }
     /* residual: reduce the 4 k-groups of a row (lanes row, row+16, row+32, row+48) */
-    part += __shfl_xor(part, 16, 64);
-    part += __shfl_xor(part, 32, 64);
+    part = rows_fold<false>(part);
     double e = 0.0;
     if (live && g == 0) {
         const double rv = fma(-1.0, xk, bk) + part;
@@ -155,7 +188,7 @@ __device__ __forceinline__ double fast_gh(const Data &Dt, int p, int lane, int t
             W[i + (size_t)row * D] = w;
         }
     }
-    return (termCondition == 2) ? wave_max(e) : wave_sum(e);
+    return (termCondition == 2) ? wmax(e) : wsum(e);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -336,7 +369,7 @@ __device__ __forceinline__ void root_block(const Data &Dt, const Opts &O, int la
     lds_fence();
     double pd = 0.0;
     if (lane < D) { Dt.dlam[bo + lane] = mine; dl_out[lane] = mine; pd = Dt.res[bo + lane] * mine; }
-    pd = wave_sum(pd);
+    pd = wsum(pd);
     if (lane == 0) Dt.part_dot[0] = pd;
 }
 
@@ -383,7 +416,7 @@ __device__ __forceinline__ void forward_block(const Data &Dt, int ii, int lane, 
     }
     double pd = 0.0;
     if (lane < D) { Dt.dlam[U::bo(ii) + lane] = mine; dl_out[lane] = mine; pd = F.res * mine; }
-    pd = wave_sum(pd);
+    pd = wsum(pd);
     if (lane == 0) Dt.part_dot[ii] = pd;
 }
 
@@ -395,7 +428,7 @@ __device__ __forceinline__ bool converged_now(const Data &Dt, const Opts &O, con
     if (threadIdx.x < WAVE) {
         double e = 0.0;
         for (int i = threadIdx.x; i < nparts; i += WAVE) e = (O.termCondition == 2) ? fmax(e, parts[i]) : e + parts[i];
-        e = (O.termCondition == 2) ? wave_max(e) : wave_sum(e);
+        e = (O.termCondition == 2) ? wmax(e) : wsum(e);
         if (O.termCondition == 1) e = sqrt(e);
         if (threadIdx.x == 0) {
             *flag_lds = e < O.tol;
@@ -686,9 +719,9 @@ __global__ void __launch_bounds__(FW * WAVE) f_stage(Tree T, Data Dt, Opts O, co
         p_h = v * val;
     }
     /* dual-function term (clipping.c:371-381): x part then u part, summed per part */
-    const double qx = wave_sum(isx ? p_q : 0.0), hx = wave_sum(isx ? p_h : 0.0);
-    const double ru = wave_sum(isx ? 0.0 : p_q), hu = wave_sum(isx ? 0.0 : p_h);
-    p_c = wave_sum(p_c);
+    const double qx = wsum(isx ? p_q : 0.0), hx = wsum(isx ? p_h : 0.0);
+    const double ru = wsum(isx ? 0.0 : p_q), hu = wsum(isx ? 0.0 : p_h);
+    p_c = wsum(p_c);
     if (lane == 0) {
         double f = -0.5 * qx - p_c;
         f += hx;

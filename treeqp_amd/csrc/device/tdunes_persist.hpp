@@ -143,8 +143,7 @@ __device__ __forceinline__ double p_gh_compute(PLds<NX, NU, MD> &L, int loc, int
         part = fma(G.a[s], G.z[s], part);
         if (live && cc < NX) Ut[cc + row * NX] = -1.0 * ap;
     }
-    part += __shfl_xor(part, 16, 64);
-    part += __shfl_xor(part, 32, 64);
+    part = rows_fold<false>(part);
     double e = 0.0;
     if (live && g == 0) {
         const double rv = fma(-1.0, G.xk, G.bk) + part;
@@ -161,7 +160,7 @@ __device__ __forceinline__ double p_gh_compute(PLds<NX, NU, MD> &L, int loc, int
             W[i + row * D] = w;
         }
     }
-    return (termCondition == 2) ? wave_max(e) : wave_sum(e);
+    return (termCondition == 2) ? wmax(e) : wsum(e);
 }
 
 template <int NX, int NU, int MD>
@@ -258,13 +257,7 @@ __device__ __forceinline__ double p_forward(const Data &Dt, PLds<NX, NU, MD> &L,
     }
     double pd = 0.0;
     if (lane < D) { st_sc1(Dt.dlam + U::bo(ii) + lane, mine); L.dl[loc * D + lane] = mine; pd = L.res[loc * D + lane] * mine; }
-    return wave_sum(pd);
-}
-
-/* 16 lanes per node: segmented reductions inside a 16-lane row */
-__device__ __forceinline__ double row16_sum(double v) {
-    v += __shfl_xor(v, 8, 16); v += __shfl_xor(v, 4, 16); v += __shfl_xor(v, 2, 16); v += __shfl_xor(v, 1, 16);
-    return v;
+    return pd;                                            /* per-lane term of res' * dlam: summed once per sweep */
 }
 
 /* stage QP of node k at the trial point lam_cur + step*dlam, by ONE 16-lane group (lanes t of the
@@ -387,11 +380,9 @@ __device__ __forceinline__ double p_stage_owned(const Data &Dt, const Tree &T, P
                 k = U::first(l1) + s * U::width(th) + (q - U::first(th));
             }
         }
-        const double f = p_stage16<NX, NU, MD>(Dt, k, T.Np, t16, gl, step, lamc, lamn, active, init);
-        if (t16 == 0) fsum += f;
+        fsum += p_stage16<NX, NU, MD>(Dt, k, T.Np, t16, gl, step, lamc, lamn, active, init);
     }
-    /* lanes 0,16,32,48 hold the groups' sums */
-    return wave_sum((lane & 15) == 0 ? fsum : 0.0);
+    return rows_fold<false>(fsum);       /* every lane of a 16-lane group holds its group's sum */
 }
 
 /* {fval, dot} partial of this workgroup into parts[], ticket; the LAST workgroup to arrive takes the
@@ -564,6 +555,7 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(Tree T, Data Dt, Opts O, 
             P_LEAVE_IF(leave);
         }
         pstamp(Dt, O, e, tier, s, sl++);                                  /* 3: children arrived */
+        double dotp = 0.0;                                /* per-lane terms of res' * dlam over my blocks */
         {
             double Tc[D];
             for (int t = th - 1; t >= 0; t--) {
@@ -614,10 +606,7 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(Tree T, Data Dt, Opts O, 
                             if (lane == k) mine = zk;
                             if (lane < k) sv = fma(-Lcol[k], zk, sv);
                         }
-                        double pd = 0.0;
-                        if (lane < D) { st_sc1(Dt.dlam + U::bo(0) + lane, mine); L.dl[lane] = mine; pd = L.res[lane] * mine; }
-                        pd = wave_sum(pd);
-                        if (lane == 0) L.wave0[FW * U::WAVE_LDS + 8] = pd;          /* dot partial of the root block */
+                        if (lane < D) { st_sc1(Dt.dlam + U::bo(0) + lane, mine); L.dl[lane] = mine; dotp = L.res[lane] * mine; }
                         lds_fence();
                     }
                 }
@@ -643,8 +632,6 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(Tree T, Data Dt, Opts O, 
         pstamp(Dt, O, e, tier, s, sl++);                                  /* parent forward arrived */
 
         /* ---- forward sweep ---- */
-        double dotp = 0.0;                                /* wave-local sum of res' * dlam over my blocks */
-        if (is_top && wave == 0) dotp = L.wave0[FW * U::WAVE_LDS + 8];
         for (int t = (is_top ? 1 : 0); t < th; t++) {
             const int nb = U::width(t);
             if (wave < nb) {
@@ -655,6 +642,7 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(Tree T, Data Dt, Opts O, 
             lds_barrier();
         }
         drain_stores();                                   /* dlam of my blocks (sc1) has left the wave */
+        dotp = wsum(dotp);
         if (lane == 0) L.wave[1] = dotp;
         __syncthreads();
         if (threadIdx.x == 0 && !is_bottom) __hip_atomic_store(Sy.down + wg, e, RLX, AGENT);
