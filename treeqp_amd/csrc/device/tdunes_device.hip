@@ -618,6 +618,7 @@ struct tqgpu_solver {
     Data D{};
     double *d_mu_x = nullptr, *d_mu_u = nullptr;
     double *d_lam_init = nullptr;   /* starting point of every solve (tqgpu_set_lambda) */
+    size_t sync_noctrl_bytes = 0;   /* inter-workgroup words of the persistent path without the control block behind them */
     /* writable aliases of the const inputs */
     double *A = nullptr, *B = nullptr, *b = nullptr, *Qd = nullptr, *Rd = nullptr, *q = nullptr, *r = nullptr;
     double *xmin = nullptr, *xmax = nullptr, *umin = nullptr, *umax = nullptr;
@@ -985,14 +986,13 @@ int setup_persist(tqgpu_solver *s, int device) {
     int wg = 0;
     for (int i = 0; i < s->n_tiers; i++) { G.l0[i] = s->tier_l0[i]; G.l1[i] = s->tier_l1[i]; G.grid[i] = s->tier_grid[i]; G.wg0[i] = wg; wg += s->tier_grid[i]; }
     G.G = wg;
-    int per_cu = 0, parts_cap = 0, err_cap = 0;
+    int per_cu = 0;
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     switch (s->fast) {
 #define X(idx, nx, nu, md)                                                                                                   \
     case idx:                                                                                                                \
         s->lds_persist = PLds<nx, nu, md>::DOUBLES * sizeof(double);                                                         \
-        parts_cap = PLds<nx, nu, md>::PARTS_CAP; err_cap = PLds<nx, nu, md>::ERR_CAP;                                        \
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f_persist<nx, nu, md>, FW * WAVE, s->lds_persist));    \
         break;
         FAST_TABLE(X)
@@ -1002,18 +1002,21 @@ int setup_persist(tqgpu_solver *s, int device) {
     /* every workgroup must be resident at once (they wait for each other); keep one block per CU of
      * margin against the occupancy query over-reporting (MI355X guide, "Residency and cooperative launch") */
     const int capacity = prop.multiProcessorCount * std::max(1, per_cu - 1);
-    if (per_cu < 1 || G.G > capacity || G.G > parts_cap || G.G > err_cap) return TQGPU_OK;
-    /* words: up_cnt[G], st_cnt[G], down[G], then five single words on their own 128-byte lines */
+    if (per_cu < 1 || G.G > capacity) return TQGPU_OK;
+    /* words: up_cnt[G], st_cnt[G], down[G], then four single words on their own 128-byte lines */
     const size_t arrays = (3 * (size_t)G.G + 31) / 32 * 32;
-    const size_t nwords = arrays + 5 * 32;
+    const size_t ctrl_words = (sizeof(Ctrl) + 127) / 128 * 32;         /* the control block rides along: ONE memset per solve */
+    const size_t nwords = arrays + 4 * 32 + ctrl_words;
     s->sync_words_bytes = nwords * sizeof(unsigned);
+    s->sync_noctrl_bytes = (arrays + 4 * 32) * sizeof(unsigned);
     const size_t bytes = s->sync_words_bytes + (3 * (size_t)G.G + 16) * sizeof(double);
     HIP_TRY(hipMalloc(&s->sync_slab, bytes));
     HIP_TRY(hipMemset(s->sync_slab, 0, bytes));
     unsigned *w = static_cast<unsigned *>(s->sync_slab);
     s->psync.up_cnt = w; s->psync.st_cnt = w + G.G; s->psync.down = w + 2 * G.G;
-    s->psync.arrive = w + arrays; s->psync.go = w + arrays + 32; s->psync.err_cnt = w + arrays + 64;
-    s->psync.halt = w + arrays + 96; s->psync.timeout = w + arrays + 128;
+    s->psync.arrive = w + arrays; s->psync.err_cnt = w + arrays + 32;
+    s->psync.halt = w + arrays + 64; s->psync.timeout = w + arrays + 96;
+    s->D.ctrl = reinterpret_cast<Ctrl *>(w + arrays + 4 * 32);
     double *d = reinterpret_cast<double *>(static_cast<char *>(s->sync_slab) + s->sync_words_bytes);
     s->psync.parts = d; s->psync.errp = d + 2 * G.G;
     s->persist_ok = true;
@@ -1023,7 +1026,8 @@ int setup_persist(tqgpu_solver *s, int device) {
 /* one persistent launch: zero the inter-workgroup words, then the kernel (prologue = first sweep of the solve) */
 int launch_persist(tqgpu_solver *s, const Opts &O, int &launches, int prologue) {
     const Tree &T = s->T; const Data &D = s->D; hipStream_t st = s->stream;
-    HIP_TRY(hipMemsetAsync(s->sync_slab, 0, s->sync_words_bytes, st));
+    /* first launch of a solve: words + control block in one go; relaunch: the control block carries the state */
+    HIP_TRY(hipMemsetAsync(s->sync_slab, 0, prologue ? s->sync_words_bytes : s->sync_noctrl_bytes, st));
     switch (s->fast) {
 #define X(idx, nx, nu, md) case idx: hipLaunchKernelGGL((f_persist<nx, nu, md>), dim3(s->geom.G), dim3(FW * WAVE), s->lds_persist, st, T, D, O, s->geom, s->psync, (const double *)s->d_lam_init, prologue); break;
         FAST_TABLE(X)
@@ -1266,7 +1270,7 @@ extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *r
     int launches = 0;
     const int nxu = std::max(s->sum_nx, s->sum_nu);
 
-    HIP_TRY(hipMemsetAsync(D.ctrl, 0, sizeof(Ctrl), st));      /* ls_log needs no reset: entry i is written by iteration i */
+    /* ls_log needs no reset: entry i is written by iteration i */
 
     if (o->profile) {
         while ((int)s->iter_ev.size() < o->maxIter + 1) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); s->iter_ev.push_back(ev); }
@@ -1276,6 +1280,7 @@ extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *r
     const bool fast = s->fast >= 0 && s->use_fast;
     const bool persist = fast && s->persist_ok && s->use_persist && s->nranks == 1 && !o->profile && o->maxIter > 0;
     HIP_TRY(hipEventRecord(s->ev0, st));
+    if (!persist) HIP_TRY(hipMemsetAsync(D.ctrl, 0, sizeof(Ctrl), st));     /* persistent path: zeroed with its inter-workgroup words */
     if (s->need_init) {
         hipLaunchKernelGGL(k_init, dim3((nxu + 255) / 256), dim3(256), 0, st, s->sum_nx, s->sum_nu, D); launches++;
         s->need_init = false;

@@ -17,8 +17,13 @@
  *       down[wg]        parent -> children, the forward sweep has written the step of my blocks,
  *       st_cnt[parent]  children -> parent, the stage sweep has rewritten the nodes I own,
  *       err_cnt         everybody -> top, termination partial of my blocks is in errp[wg],
- *       arrive / go     ticket of the {fval, dot} reduction and its decision,
+ *       arrive          everybody -> top, my {fval, dot} partial of the last stage sweep is in parts[wg],
  *       halt            top -> everybody, the launch is over;
+ *     all hand-ins are fire-and-forget (no returning atomics): only consumers ever wait;
+ *   - everything a workgroup needs from ITSELF stays in its LDS across iterations: the duals of its
+ *     blocks, x / u / QinvCal / RinvCal of the nodes it owns, the step of its blocks.  The bottom
+ *     tier (the start of every iteration's critical path) therefore goes from the stage sweep to
+ *     G + H of the next iteration without touching global memory for anything but constants;
  *   - the FIRST sweep of a solve (stage QPs at lambda0, fval0) is the launch's prologue;
  *   - an iteration does not wait for the line-search decision of the previous one: the first trial
  *     (tau = 1) is accepted almost always, so every workgroup goes straight on to G + H and the
@@ -29,8 +34,8 @@
  *   - termination is decided from the flat errp[] array as soon as every workgroup has done G + H,
  *     i.e. long before the backward sweep of a converged point would have reached the top;
  *   - the trial stage sweep runs four nodes per wave (16 lanes per node) for the nodes a workgroup
- *     owns; the line-search decision is taken by the LAST workgroup to arrive at the ticket, which
- *     sums the per-workgroup {fval, dot} partials in workgroup order;
+ *     owns; the line-search decision is taken by the top workgroup (which has the most slack), from
+ *     the per-workgroup {fval, dot} partials summed in workgroup order;
  *   - every spin is bounded (wall clock); a timeout ends the launch with status UNKNOWN_ERROR.
  * Extra line-search trials (rare) end the launch: the host runs them with the ordinary trial kernels
  * and relaunches (without prologue); nothing but global memory carries state across launches.
@@ -50,8 +55,7 @@ struct PSync {
     unsigned *up_cnt;       /* [G] backward arrivals of child subtrees at their parent workgroup      */
     unsigned *st_cnt;       /* [G] completed stage sweeps of child subtrees, counted at the parent    */
     unsigned *down;         /* [G] e, published by a workgroup after its forward sweep                */
-    unsigned *arrive;       /* ticket counter of the {fval, dot} reductions                           */
-    unsigned *go;           /* (decision number << 2) | code : 0 continue, 1 done, 2 more trials      */
+    unsigned *arrive;       /* workgroups that have handed in their {fval, dot} partial (monotonic)   */
     unsigned *err_cnt;      /* arrivals of termination partials                                      */
     unsigned *halt;         /* set by the top workgroup: everybody leaves at the next poll            */
     unsigned *timeout;      /* set when a bounded spin gave up                                       */
@@ -77,30 +81,41 @@ template <int NX, int NU, int MD>
 struct PLds {
     using U = Uni<NX, NU, MD>;
     static constexpr int D = U::D, NBT = U::NBT;
-    static constexpr int DOUBLES = NBT * (D * D + NX * D + 4 * D) + NBT * U::SCH + NBT * D + FW * U::WAVE_LDS + 32;
-    /* scratch reuse by the reductions: {fval, dot} partials over the whole block storage (free between
-     * the stage sweep and the next G + H), termination partials over the Schur records (free before
-     * the backward sweep) -- the host checks the grid against both capacities */
-    static constexpr int PARTS_CAP = NBT * (D * D + NX * D + 4 * D + U::SCH) / 2, ERR_CAP = NBT * U::SCH;
-    lds_ptr W, Ut, res, y, inv, dl, sch, wave0, wave;
+    static constexpr int SLOTS = NBT + (MD == 2 ? 8 : MD * MD);      /* nodes a workgroup can own: its blocks' owners + (bottom tier) the leaves */
+    static constexpr int NODE = 2 * (NX + NU);                       /* x, u, QinvCal, RinvCal of one owned node */
+    static constexpr int DOUBLES = NBT * (D * D + NX * D + 4 * D) + NBT * U::SCH + NBT * D + SLOTS * NODE + 2 * NBT * D + 3 * NX + 4 * FW + FW * U::WAVE_LDS + 32;
+    /* scratch of the top workgroup's reductions: the Schur record storage, free before the backward sweep */
+    static constexpr int RED_CAP = NBT * U::SCH / 2;
+    lds_ptr W, Ut, res, y, inv, dl, sch, node, lamb, lamroot, droot, part, wave0, wave;
     lds_iptr flag;
     __device__ PLds(double *base, int wave_id) {
         W = to_lds(base); Ut = W + NBT * D * D; res = Ut + NBT * NX * D; y = res + NBT * D; inv = y + NBT * D;
-        dl = inv + NBT * D; sch = dl + NBT * D; wave0 = sch + NBT * U::SCH; wave = wave0 + wave_id * U::WAVE_LDS;
+        dl = inv + NBT * D; sch = dl + NBT * D; node = sch + NBT * U::SCH; lamb = node + SLOTS * NODE;
+        lamroot = lamb + 2 * NBT * D; droot = lamroot + 2 * NX; part = droot + NX; wave0 = part + 4 * FW; wave = wave0 + wave_id * U::WAVE_LDS;
         flag = (lds_iptr)(wave0 + FW * U::WAVE_LDS);
     }
+    /* part[4 w + i]: wave w's partials -- 0 termination norm, 1 res' * dlam, 2 dual function value */
+    /* owned node `q` (heap order inside the tier subtree): x | u | QinvCal | RinvCal */
+    __device__ __forceinline__ lds_ptr nx_(int q) const { return node + q * NODE; }
+    __device__ __forceinline__ lds_ptr nu_(int q) const { return node + q * NODE + NX; }
+    __device__ __forceinline__ lds_ptr nqc(int q) const { return node + q * NODE + NX + NU; }
+    __device__ __forceinline__ lds_ptr nrc(int q) const { return node + q * NODE + 2 * NX + NU; }
+    /* dual vector of block `loc` (= duals of the owner node's children), double-buffered like lam0 / lam1 */
+    __device__ __forceinline__ lds_ptr lamb_(int buf, int loc) const { return lamb + (buf * NBT + loc) * D; }
 };
 
 /* G + H of block p into LDS slot `loc`, split into a branch-free load half and a compute half so
- * that a wave with two blocks has both blocks' loads in flight at once.  Node data (x, u, QinvCal,
- * RinvCal) through sc1 loads: written by other workgroups' stage sweeps in the previous iteration. */
+ * that a wave with two blocks has both blocks' loads in flight at once.  The owner node's x, u,
+ * QinvCal, RinvCal come from the workgroup's LDS node store (its own stage sweep wrote them); the
+ * children's x and QinvCal likewise unless the children belong to the tier below (`foreign`): then
+ * they were written by the child workgroups' stage sweeps and are read with sc1 loads. */
 template <int NX, int NU, int MD>
 struct GhRegs {
     double a[Uni<NX, NU, MD>::KS], pc[Uni<NX, NU, MD>::KS], z[Uni<NX, NU, MD>::KS], xk, bk, qk;
 };
 
 template <int NX, int NU, int MD>
-__device__ __forceinline__ void p_gh_load(const Data &Dt, int p, int lane, GhRegs<NX, NU, MD> &G) {
+__device__ __forceinline__ void p_gh_load(const Data &Dt, const PLds<NX, NU, MD> &L, int p, int loc, bool foreign, int lane, GhRegs<NX, NU, MD> &G) {
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D, NZ = U::NZ;
     const int row = lane & 15, g = lane >> 4;
@@ -111,18 +126,21 @@ __device__ __forceinline__ void p_gh_load(const Data &Dt, int p, int lane, GhReg
     const double *A = Dt.A + (size_t)(k - 1) * NX * NX + r;
     const double *B = Dt.B + (size_t)(k - 1) * NX * NU + r;
     const int bo = U::bo(p);
+    lds_cptr own = L.nx_(loc);                               /* x | u | QinvCal | RinvCal, NZ apart */
 #pragma unroll
     for (int s = 0; s < U::KS; s++) {
         const int cc = g + 4 * s;
         const bool ok = live && cc < NZ, isx = cc < NX;
         const int cu = (cc < NZ) ? cc - NX : 0;              /* input column (clamped) */
+        const int cz = (cc < NZ) ? cc : 0;
         const double *ap = isx ? A + (size_t)cc * NX : B + (size_t)cu * NX;
-        const double *pp = isx ? Dt.QinvCal + NX * p + cc : Dt.RinvCal + NU * p + cu;
-        const double *zp = isx ? Dt.x + NX * p + cc : Dt.u + NU * p + cu;
-        const double av = *ap, pv = ld_sc1(pp), zv = ld_sc1(zp);
+        const double av = *ap, zv = own[cz], pv = own[NZ + cz];
         G.a[s] = ok ? av : 0.0; G.pc[s] = ok ? pv : 0.0; G.z[s] = ok ? zv : 0.0;
     }
-    const double xv = ld_sc1(Dt.x + bo + rowc), bv = Dt.b[bo + rowc], qv = ld_sc1(Dt.QinvCal + bo + rowc);
+    double xv, qv;
+    if (foreign) { xv = ld_sc1(Dt.x + bo + rowc); qv = ld_sc1(Dt.QinvCal + bo + rowc); }
+    else { lds_cptr kid = L.nx_(MD * loc + 1 + cidx); xv = kid[r]; qv = kid[NZ + r]; }
+    const double bv = Dt.b[bo + rowc];
     G.xk = (live && g == 0) ? xv : 0.0; G.bk = (live && g == 0) ? bv : 0.0; G.qk = live ? qv : 0.0;
 }
 
@@ -236,6 +254,10 @@ __device__ __forceinline__ double p_forward(const Data &Dt, PLds<NX, NU, MD> &L,
     if (delta_glb) {
 #pragma unroll
         for (int r = 0; r < NX; r++) dv[r] = ld_sc1(delta_glb + r);
+        if (lane == 0) {                                  /* the subtree root's own step: the stage sweep reads it from LDS */
+#pragma unroll
+            for (int r = 0; r < NX; r++) L.droot[r] = dv[r];
+        }
     } else {
 #pragma unroll
         for (int r = 0; r < NX; r++) dv[r] = delta_lds[r];
@@ -260,27 +282,32 @@ __device__ __forceinline__ double p_forward(const Data &Dt, PLds<NX, NU, MD> &L,
     return pd;                                            /* per-lane term of res' * dlam: summed once per sweep */
 }
 
-/* stage QP of node k at the trial point lam_cur + step*dlam, by ONE 16-lane group (lanes t of the
- * group: t < NX state entries, NX <= t < NX+NU input entries); all node-level global traffic is sc1.
- * init: first sweep of a solve -- evaluate at lamc itself (the step buffer may hold anything) and copy it to lamn.
+/* stage QP of owned node slot q (= node k) at the trial point lam_cur + step*dlam, by ONE 16-lane
+ * group (lanes t of the group: t < NX state entries, NX <= t < NX+NU input entries).  Duals and steps
+ * come from the workgroup's LDS copies (lamb / lamroot, dl / droot; `cb` = current buffer), constants
+ * from global memory; results go to global memory (sc1 stores, nobody waits for them here) AND to the
+ * LDS node store / the other dual buffer for this workgroup's next G + H.
+ * init: first sweep of a solve -- evaluate at the current duals themselves.
  * Returns the node's dual-function term (valid in every lane of the group). */
 template <int NX, int NU, int MD>
-__device__ __forceinline__ double p_stage16(const Data &Dt, int k, int Np, int t, lds_ptr gl /* group scratch: D + NX */,
-                                            double step, const double *lamc, double *lamn, bool active, bool init = false) {
+__device__ __forceinline__ double p_stage16(const Data &Dt, PLds<NX, NU, MD> &L, int q, int k, int Np, int t, lds_ptr gl /* group scratch: D + NX */,
+                                            double step, int cb, double *lamn, bool active, bool init) {
     using U = Uni<NX, NU, MD>;
-    constexpr int D = U::D;
+    constexpr int D = U::D, NBT = U::NBT;
     static_assert(NX + NU <= 16 && D <= 16, "16-lane stage needs nx+nu <= 16 and d <= 16");
     const bool parent = active && k < Np;
     const int nuk = parent ? NU : 0;
     const int xo = NX * k, uo = NU * k, ko = U::bo(k);
     const bool isx = t < NX, live = active && t < NX + nuk;
     const int j = isx ? t : t - NX;
-    /* branch-free loads: every lane reads from a valid (clamped) address and masks afterwards, so
-     * all of the node's global loads are in flight together */
+    /* branch-free loads: every lane reads from a valid (clamped) address and masks afterwards */
     const bool pk = parent && t < D, ox = active && isx && k > 0;
-    const int ia = pk ? ko + t : 0, ib = ox ? xo + t : 0;
-    const double dla = ld_sc1(Dt.dlam + ia), lca = ld_sc1(lamc + ia), ba = Dt.b[ia];
-    const double dlb = ld_sc1(Dt.dlam + ib), lcb = ld_sc1(lamc + ib);
+    const int qb = pk ? q : 0, tb = pk ? t : 0;                       /* my block's duals / step */
+    const double lca = L.lamb_(cb, qb)[tb], dla = L.dl[qb * D + tb], ba = Dt.b[pk ? ko + t : 0];
+    const int qp = (ox && q > 0) ? (q - 1) / MD : 0, tp = (ox && q > 0) ? ((q - 1) % MD) * NX + t : 0;   /* my own slice in the parent's block */
+    const int tr = ox ? t : 0;
+    const double lcb = (q > 0) ? L.lamb_(cb, qp)[tp] : L.lamroot[cb * NX + tr];
+    const double dlb = (q > 0) ? L.dl[qp * D + tp] : L.droot[tr];
     const bool pl = parent && live;
     double col[MD][NX];
 #pragma unroll
@@ -298,9 +325,9 @@ __device__ __forceinline__ double p_stage16(const Data &Dt, int k, int Np, int t
     double p_c = 0.0;
     {
         const double v = init ? lca : fma(step, dla, lca);
-        if (pk) { gl[t] = v; p_c = ba * v; }
+        if (pk) { gl[t] = v; p_c = ba * v; if (!init) L.lamb_(cb ^ 1, q)[t] = v; }
         const double w = ox ? (init ? lcb : fma(step, dlb, lcb)) : 0.0;
-        if (ox) st_sc1(lamn + xo + t, w);
+        if (ox) { st_sc1(lamn + xo + t, w); if (q == 0 && !init) L.lamroot[(cb ^ 1) * NX + t] = w; }
         if (active && isx) gl[D + t] = w;
     }
     lds_fence();
@@ -321,6 +348,8 @@ __device__ __forceinline__ double p_stage16(const Data &Dt, int k, int Np, int t
         if (unc >= hib) { val = hib; cal = 0.0; } else if (unc <= lob) { val = lob; cal = 0.0; } else { val = unc; cal = winv; }
         if (isx) { st_sc1(Dt.qmod + xo + j, v); st_sc1(Dt.xUnc + xo + j, unc); st_sc1(Dt.x + xo + j, val); st_sc1(Dt.QinvCal + xo + j, cal); }
         else { st_sc1(Dt.rmod + uo + j, v); st_sc1(Dt.uUnc + uo + j, unc); st_sc1(Dt.u + uo + j, val); st_sc1(Dt.RinvCal + uo + j, cal); }
+        lds_ptr ns = L.nx_(q);                            /* x | u | QinvCal | RinvCal: entry t, NX+NU apart */
+        ns[t] = val; ns[NX + NU + t] = cal;
         p_q = (wd * val) * val;
         p_h = v * val;
     }
@@ -356,80 +385,61 @@ __device__ __forceinline__ void pstamp(const Data &Dt, const Opts &O, unsigned e
     }
 }
 
+/* heap slot -> node / block index: slot q of the tier subtree s whose block levels are [l0, l1) */
+template <int NX, int NU, int MD>
+__device__ __forceinline__ int p_slot_node(int q, int l0, int s) {
+    using U = Uni<NX, NU, MD>;
+    int t = 0;
+    while (q >= U::first(t + 1)) t++;
+    return U::first(l0 + t) + s * U::width(t) + (q - U::first(t));
+}
+
 /* stage sweep over the nodes this workgroup owns (the owner nodes of its blocks in heap order, then --
  * bottom tier -- the leaves below), four nodes per wave; returns the wave's sum of the node terms */
 template <int NX, int NU, int MD>
-__device__ __forceinline__ double p_stage_owned(const Data &Dt, const Tree &T, PLds<NX, NU, MD> &L, int l0, int l1, int s, bool is_bottom, int wave, int lane,
-                                                double step, const double *lamc, double *lamn, bool init) {
+__device__ __forceinline__ double p_stage_owned(const Data &Dt, const Tree &T, PLds<NX, NU, MD> &L, int l0, int nown, int s, int wave, int lane,
+                                                double step, int cb, double *lamn, bool init) {
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D;
-    const int th = l1 - l0;
-    const int nown = U::first(th) + (is_bottom ? U::width(th) : 0);
     const int grp = lane >> 4, t16 = lane & 15;
     lds_ptr gl = L.wave + 8 + grp * (D + NX + 2);
     double fsum = 0.0;
     for (int base = 0; base < nown; base += FW * 4) {
         const int q = base + wave * 4 + grp;
         const bool active = q < nown;
-        int k = 0;
-        if (active) {
-            if (q < U::first(th)) {
-                int t = 0; while (q >= U::first(t + 1)) t++;
-                k = U::first(l0 + t) + s * U::width(t) + (q - U::first(t));
-            } else {
-                k = U::first(l1) + s * U::width(th) + (q - U::first(th));
-            }
-        }
-        fsum += p_stage16<NX, NU, MD>(Dt, k, T.Np, t16, gl, step, lamc, lamn, active, init);
+        const int k = active ? p_slot_node<NX, NU, MD>(q, l0, s) : 0;
+        fsum += p_stage16<NX, NU, MD>(Dt, L, active ? q : 0, k, T.Np, t16, gl, step, cb, lamn, active, init);
     }
     return rows_fold<false>(fsum);       /* every lane of a 16-lane group holds its group's sum */
 }
 
-/* {fval, dot} partial of this workgroup into parts[], ticket; the LAST workgroup to arrive takes the
- * decision number `nd` for everybody: nd == 0 with `prologue`: fval0 of the first sweep, otherwise the
- * first line-search trial (direction test + Armijo).  Called by all threads of the workgroup. */
+/* top workgroup: ordered sums (workgroup order) of the per-workgroup {fval, dot} partials and of the
+ * termination partials (sum or maximum), gathered with parallel sc1 loads through the Schur record
+ * scratch in chunks; results valid in thread 0 */
 template <int NX, int NU, int MD>
-__device__ __forceinline__ void p_reduce_and_decide(Ctrl *c, const Data &Dt, const Opts &O, const PGeom &Gm, const PSync &Sy, PLds<NX, NU, MD> &L,
-                                                    int wg, double f_wg, double d_wg, unsigned nd, bool first_sweep) {
-    if (threadIdx.x == 0) {
-        st_sc1(Sy.parts + 2 * wg, f_wg);
-        st_sc1(Sy.parts + 2 * wg + 1, d_wg);
-        drain_stores();
-        const unsigned ticket = __hip_atomic_fetch_add(Sy.arrive, 1u, RLX, AGENT);
-        *L.flag = (ticket == (nd + 1u) * (unsigned)Gm.G - 1u);
-    }
-    __syncthreads();
-    if (*L.flag) {
-        /* all threads fetch the partials in parallel, thread 0 sums them in workgroup order */
-        lds_ptr pf = L.W, pd = L.W + Gm.G;                /* the block storage is free between the sweeps */
-        for (int w = threadIdx.x; w < Gm.G; w += FW * WAVE) { pf[w] = ld_sc1(Sy.parts + 2 * w); pd[w] = ld_sc1(Sy.parts + 2 * w + 1); }
+__device__ __forceinline__ void p_gather3(PLds<NX, NU, MD> &L, const double *parts, const double *errp, int count, bool err_max,
+                                          double &fa, double &da, double &ea) {
+    constexpr int CAP = PLds<NX, NU, MD>::RED_CAP * 2 / 3;
+    fa = 0.0; da = 0.0; ea = 0.0;
+    for (int c0 = 0; c0 < count; c0 += CAP) {
+        const int n = min(CAP, count - c0);
+        for (int w = threadIdx.x; w < n; w += FW * WAVE) {
+            L.sch[3 * w] = ld_sc1(parts + 2 * (size_t)(c0 + w));
+            L.sch[3 * w + 1] = ld_sc1(parts + 2 * (size_t)(c0 + w) + 1);
+            L.sch[3 * w + 2] = ld_sc1(errp + c0 + w);
+        }
         __syncthreads();
         if (threadIdx.x == 0) {
-            double fa = 0.0, da = 0.0;
-            for (int w = 0; w < Gm.G; w++) { fa += pf[w]; da += pd[w]; }
-            /* the control block was last written by another workgroup (or the host) */
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            unsigned code = 0u;
-            if (first_sweep) { c->fval0 = fa; c->fval = fa; }
-            else {
-                c->tau = 1.0; c->tauPrev = 0.0; c->ls_iter = 1; c->ls_pending = 1;
-                if (ls_not_descent(c, -da)) code = 1u;
-                else {
-                    ls_decide_tail(c, Dt, O, fa);
-                    code = c->done ? 1u : (c->ls_pending ? 2u : 0u);
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __hip_atomic_store(Sy.go, ((nd + 1u) << 2) | code, RLX, AGENT);
+            for (int w = 0; w < n; w++) { fa += L.sch[3 * w]; da += L.sch[3 * w + 1]; ea = err_max ? fmax(ea, L.sch[3 * w + 2]) : ea + L.sch[3 * w + 2]; }
         }
+        __syncthreads();
     }
-    __syncthreads();
 }
 
 template <int NX, int NU, int MD>
 __global__ void __launch_bounds__(FW * WAVE) f_persist(Tree T, Data Dt, Opts O, PGeom Gm, PSync Sy, const double *lam_init, int prologue) {
     using U = Uni<NX, NU, MD>;
-    constexpr int D = U::D;
+    constexpr int D = U::D, NBT = U::NBT;
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     Ctrl *c = Dt.ctrl;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -444,53 +454,96 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(Tree T, Data Dt, Opts O, 
     const int root_blk = U::first(l0) + s;                            /* subtree root block (= node) */
     const int parent_wg = is_top ? -1 : Gm.wg0[tier + 1] + ((root_blk - 1) / MD - U::first(l0 - 1)) / U::width(Gm.l1[tier + 1] - 1 - Gm.l0[tier + 1]);
     const unsigned nchild = is_bottom ? 0u : (unsigned)(U::width(th - 1) * MD);   /* child subtrees below my bottom level */
+    const int nbt = U::first(th);                                      /* my blocks */
+    const int nown = nbt + (is_bottom ? U::width(th) : 0);             /* nodes I own */
     if (__hip_atomic_load(&c->done, RLX, AGENT) || __hip_atomic_load(&c->ls_pending, RLX, AGENT)) return;
     int cur = __hip_atomic_load(&c->cur, RLX, AGENT);
-    unsigned nd = 0u;          /* reductions (tickets) I have taken part in = decisions that exist or are under way */
+    unsigned nd = 0u;          /* {fval, dot} reductions handed in so far (by me, hence by everybody who got this far) */
     unsigned ns = 0u;          /* stage sweeps I have completed in this launch */
+    bool unposted = false;     /* a finished stage sweep whose results are not published yet */
 
-    /* the launch is over for this workgroup: leave together (the flag is workgroup-uniform) */
-#define P_LEAVE_IF(cond) do { if (cond) return; } while (0)
+    /* ---- LDS copies of what this workgroup owns: duals of my blocks and of my root, node store ---- */
+    {
+        const double *lsrc = prologue ? lam_init : (cur ? Dt.lam1 : Dt.lam0);
+        for (int i = threadIdx.x; i < nbt * D; i += FW * WAVE) {
+            const int loc = i / D, t = i - loc * D;
+            L.lamb_(cur, loc)[t] = lsrc[U::bo(p_slot_node<NX, NU, MD>(loc, l0, s)) + t];
+        }
+        if (threadIdx.x < NX) L.lamroot[cur * NX + threadIdx.x] = root_blk > 0 ? lsrc[NX * root_blk + threadIdx.x] : 0.0;
+        if (!prologue) {
+            for (int i = threadIdx.x; i < nown * 16; i += FW * WAVE) {
+                const int q = i >> 4, t = i & 15;
+                const int k = p_slot_node<NX, NU, MD>(q, l0, s);
+                if (t < NX) { L.nx_(q)[t] = Dt.x[NX * k + t]; L.nqc(q)[t] = Dt.QinvCal[NX * k + t]; }
+                else if (t < NX + NU && k < T.Np) { L.nu_(q)[t - NX] = Dt.u[NU * k + t - NX]; L.nrc(q)[t - NX] = Dt.RinvCal[NU * k + t - NX]; }
+            }
+        }
+        __syncthreads();
+    }
+
+    /* Hand-ins of this workgroup, by ONE lane, fire-and-forget: (stage) a finished stage sweep -- node data
+     * of my subtree root for the parent (st_cnt) and my {fval, dot} partial for the top workgroup (arrive);
+     * (gh) the termination partial of my blocks (err_cnt).  The caller has made sure that every wave
+     * drained the global stores of its stage sweep (drain_stores + workgroup barrier). */
+    auto post = [&](bool stage, bool gh) {
+        if (stage) {
+            double f = 0.0, d = 0.0;
+            for (int w = 0; w < FW; w++) { f += L.part[4 * w + 2]; d += L.part[4 * w + 1]; }
+            st_sc1(Sy.parts + 2 * wg, f);
+            st_sc1(Sy.parts + 2 * wg + 1, d);
+        }
+        if (gh) {
+            double err = 0.0;
+            for (int w = 0; w < FW; w++) { const double v = L.part[4 * w]; err = (O.termCondition == 2) ? fmax(err, v) : err + v; }
+            st_sc1(Sy.errp + wg, err);
+        }
+        drain_stores();
+        if (stage) {
+            if (!is_top) __hip_atomic_fetch_add(Sy.st_cnt + parent_wg, 1u, RLX, AGENT);
+            __hip_atomic_fetch_add(Sy.arrive, 1u, RLX, AGENT);
+        }
+        if (gh) __hip_atomic_fetch_add(Sy.err_cnt, 1u, RLX, AGENT);
+    };
 
     if (prologue) {
         /* ---- first sweep of the solve: stage QPs at lambda0 (copied into the current buffer), fval0 ---- */
         double *lam0 = cur ? Dt.lam1 : Dt.lam0;
-        const double fsum = p_stage_owned<NX, NU, MD>(Dt, T, L, l0, l1, s, is_bottom, wave, lane, 0.0, lam_init, lam0, true);
-        if (lane == 0) L.wave[2] = fsum;
-        drain_stores();
+        const double fsum = p_stage_owned<NX, NU, MD>(Dt, T, L, l0, nown, s, wave, lane, 0.0, cur, lam0, true);
+        if (lane == 0) { L.part[4 * wave + 2] = fsum; L.part[4 * wave + 1] = 0.0; }
         __syncthreads();
-        double f = 0.0;
-        for (int w = 0; w < FW; w++) f += L.wave0[w * U::WAVE_LDS + 2];
-        if (threadIdx.x == 0 && !is_top) __hip_atomic_fetch_add(Sy.st_cnt + parent_wg, 1u, RLX, AGENT);
         ns = 1u;
-        p_reduce_and_decide<NX, NU, MD>(c, Dt, O, Gm, Sy, L, wg, f, 0.0, nd, true);
-        nd = 1u;
+        unposted = true;
     }
 
     for (unsigned e = 1u;; e++) {
-        const double *lamc = cur ? Dt.lam1 : Dt.lam0;
         double *lamn = cur ? Dt.lam0 : Dt.lam1;
 
         int sl = 0;
         pstamp(Dt, O, e, tier, s, sl++);                                  /* 0: iteration start */
         /* ---- the nodes my bottom-level blocks read are staged by the child workgroups ---- */
         if (!is_bottom) {
+            if (unposted) {
+                drain_stores();
+                __syncthreads();
+                if (threadIdx.x == 0) post(true, false);
+                nd += 1u;
+                unposted = false;
+            }
             if (threadIdx.x == 0) *L.flag = poll_ge(Sy.st_cnt + wg, ns * nchild, Sy) ? 0 : 1;
             __syncthreads();
             const int leave = *L.flag;
             __syncthreads();
-            P_LEAVE_IF(leave);
+            if (leave) return;
         }
         /* ---- G + H for my blocks (heap order inside the subtree), two blocks per wave in flight ---- */
         double err = 0.0;
         {
-            const int nbt = U::first(th);
-            auto blk = [&](int loc) { int t = 0; while (loc >= U::first(t + 1)) t++; return U::first(l0 + t) + s * U::width(t) + (loc - U::first(t)); };
+            const int nint = U::first(th - 1);                         /* blocks above my bottom level: children are mine */
             for (int loc0 = wave; loc0 < nbt; loc0 += 2 * FW) {
                 const int loc1 = loc0 + FW;
                 GhRegs<NX, NU, MD> g0, g1;
-                p_gh_load<NX, NU, MD>(Dt, blk(loc0), lane, g0);
-                if (loc1 < nbt) p_gh_load<NX, NU, MD>(Dt, blk(loc1), lane, g1);
+                p_gh_load<NX, NU, MD>(Dt, L, p_slot_node<NX, NU, MD>(loc0, l0, s), loc0, !is_bottom && loc0 >= nint, lane, g0);
+                if (loc1 < nbt) p_gh_load<NX, NU, MD>(Dt, L, p_slot_node<NX, NU, MD>(loc1, l0, s), loc1, !is_bottom && loc1 >= nint, lane, g1);
                 double v = p_gh_compute<NX, NU, MD>(L, loc0, lane, g0, O.termCondition);
                 err = (O.termCondition == 2) ? fmax(err, v) : err + v;
                 if (loc1 < nbt) {
@@ -498,43 +551,58 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(Tree T, Data Dt, Opts O, 
                     err = (O.termCondition == 2) ? fmax(err, v) : err + v;
                 }
             }
-            if (lane == 0) L.wave[0] = err;
+            if (lane == 0) L.part[4 * wave] = err;
+            drain_stores();                               /* my stage sweep's global stores (long gone by now) */
             __syncthreads();
-            if (threadIdx.x == 0) {
-                err = 0.0;
-                for (int w = 0; w < FW; w++) { const double v = L.wave0[w * U::WAVE_LDS]; err = (O.termCondition == 2) ? fmax(err, v) : err + v; }
-                /* termination partial of my blocks to the top workgroup */
-                st_sc1(Sy.errp + wg, err);
-                drain_stores();
-                __hip_atomic_fetch_add(Sy.err_cnt, 1u, RLX, AGENT);
-            }
+        }
+        /* Bottom tier (the head of the critical path): the hand-ins wait for a wave that has no block in
+         * the backward sweep (below); every other tier has slack and hands in right away. */
+        bool post_gh = true, post_st = false;
+        if (is_bottom && unposted) { post_st = true; nd += 1u; unposted = false; }
+        if (!is_bottom || is_top || th == 1) {
+            if (threadIdx.x == 0) post(post_st, true);
+            post_gh = false; post_st = false;
         }
         pstamp(Dt, O, e, tier, s, sl++);                                  /* 1: G+H done */
 
         if (is_top) {
-            /* ---- verdicts: was the previous trial accepted?  has the (then current) point converged? ---- */
+            /* ---- verdicts: the outstanding {fval, dot} reduction (fval0 of the first sweep, or the first
+             * trial of the previous iteration), then the termination test of the (then current) point ---- */
             if (threadIdx.x == 0) {
-                int leave = 0;
-                unsigned gv = 0u;
-                if (nd > 0u) { if (!poll_ge(Sy.go, nd << 2, Sy, &gv)) leave = 1; else if (gv & 3u) leave = 1; }
-                if (!leave && !poll_ge(Sy.err_cnt, e * (unsigned)Gm.G, Sy)) leave = 1;
-                *L.flag = leave;
+                int lv = 0;
+                if (nd > 0u && !poll_ge(Sy.arrive, nd * (unsigned)Gm.G, Sy)) lv = 1;
+                if (!lv && !poll_ge(Sy.err_cnt, e * (unsigned)Gm.G, Sy)) lv = 1;
+                *L.flag = lv;
             }
             __syncthreads();
             int leave = *L.flag;
+            __syncthreads();
             if (!leave) {
-                lds_ptr pe = L.sch;
-                for (int w = threadIdx.x; w < Gm.G; w += FW * WAVE) pe[w] = ld_sc1(Sy.errp + w);
-                __syncthreads();
+                double fa, da, ea;
+                p_gather3<NX, NU, MD>(L, Sy.parts, Sy.errp, Gm.G, O.termCondition == 2, fa, da, ea);
                 if (threadIdx.x == 0) {
-                    double ea = 0.0;
-                    for (int w = 0; w < Gm.G; w++) ea = (O.termCondition == 2) ? fmax(ea, pe[w]) : ea + pe[w];
-                    if (O.termCondition == 1) ea = sqrt(ea);
-                    c->err = ea;
-                    if (ea < O.tol) { c->status = 0; __hip_atomic_store(&c->done, 1, RLX, AGENT); *L.flag = 1; }
+                    int code = 0;
+                    if (nd > 0u) {
+                        if (prologue && nd == 1u) { c->fval0 = fa; c->fval = fa; }
+                        else {
+                            c->tau = 1.0; c->tauPrev = 0.0; c->ls_iter = 1; c->ls_pending = 1;
+                            if (ls_not_descent(c, -da)) code = 1;
+                            else {
+                                ls_decide_tail(c, Dt, O, fa);
+                                code = (c->done || c->ls_pending) ? 1 : 0;      /* finished, or more trials: the host takes over */
+                            }
+                        }
+                    }
+                    if (!code) {
+                        if (O.termCondition == 1) ea = sqrt(ea);
+                        c->err = ea;
+                        if (ea < O.tol) { c->status = 0; c->done = 1; code = 1; }
+                    }
+                    *L.flag = code;
                 }
                 __syncthreads();
                 leave = *L.flag;
+                __syncthreads();
             }
             if (leave) {
                 drain_stores();
@@ -542,7 +610,6 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(Tree T, Data Dt, Opts O, 
                 if (threadIdx.x == 0) __hip_atomic_store(Sy.halt, 1u, RLX, AGENT);
                 return;
             }
-            __syncthreads();
         }
         pstamp(Dt, O, e, tier, s, sl++);                                  /* 2: verdicts (top) */
 
@@ -552,7 +619,7 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(Tree T, Data Dt, Opts O, 
             __syncthreads();
             const int leave = *L.flag;
             __syncthreads();
-            P_LEAVE_IF(leave);
+            if (leave) return;
         }
         pstamp(Dt, O, e, tier, s, sl++);                                  /* 3: children arrived */
         double dotp = 0.0;                                /* per-lane terms of res' * dlam over my blocks */
@@ -560,6 +627,14 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(Tree T, Data Dt, Opts O, 
             double Tc[D];
             for (int t = th - 1; t >= 0; t--) {
                 const int nb = U::width(t);
+                /* the launch may be over (converged, line search needs the host): look once per level, the
+                 * load is in flight while the level factors */
+                unsigned halted = 0u;
+#ifdef TQ_LEVEL_HALT
+                if (threadIdx.x == 0) halted = __hip_atomic_load(Sy.halt, RLX, AGENT);
+#endif
+                if (post_gh && (t < th - 1 || nb < FW) && wave == FW - 1 && lane == 0) post(post_st, true);
+                if (t < th - 1 || nb < FW) post_gh = false;
                 if (wave < nb) {
                     const int ii = U::first(l0 + t) + s * nb + wave, loc = U::first(t) + wave;
                     const bool is_root = is_top && t == 0;
@@ -610,11 +685,17 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(Tree T, Data Dt, Opts O, 
                         lds_fence();
                     }
                 }
+#ifdef TQ_LEVEL_HALT
+                if (threadIdx.x == 0) *L.flag = (int)halted;
+#endif
                 lds_barrier();
 #ifdef TQ_FINE_STAMPS
                 if (is_top && t == 1) pstamp(Dt, O, e, 7, 0, 5);
 #endif
                 pstamp(Dt, O, e, tier, s, sl++);                          /* 4.. : one per backward level */
+#ifdef TQ_LEVEL_HALT
+                if (*L.flag) return;
+#endif
             }
         }
         if (!is_top) {
@@ -627,7 +708,7 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(Tree T, Data Dt, Opts O, 
             __syncthreads();
             const int leave = *L.flag;
             __syncthreads();
-            P_LEAVE_IF(leave);
+            if (leave) return;
         }
         pstamp(Dt, O, e, tier, s, sl++);                                  /* parent forward arrived */
 
@@ -641,28 +722,23 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(Tree T, Data Dt, Opts O, 
             }
             lds_barrier();
         }
-        drain_stores();                                   /* dlam of my blocks (sc1) has left the wave */
+        if (!is_bottom) {
+            drain_stores();                               /* the step of my bottom-level blocks (sc1) has left the wave */
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_store(Sy.down + wg, e, RLX, AGENT);
+        }
         dotp = wsum(dotp);
-        if (lane == 0) L.wave[1] = dotp;
-        __syncthreads();
-        if (threadIdx.x == 0 && !is_bottom) __hip_atomic_store(Sy.down + wg, e, RLX, AGENT);
+        if (lane == 0) L.part[4 * wave + 1] = dotp;
         pstamp(Dt, O, e, tier, s, sl++);                                  /* forward done + published */
 
-        /* ---- first trial (tau = 1) on the nodes this workgroup owns ---- */
-        const double fsum = p_stage_owned<NX, NU, MD>(Dt, T, L, l0, l1, s, is_bottom, wave, lane, 1.0, lamc, lamn, false);
-        if (lane == 0) L.wave[2] = fsum;
-        drain_stores();
+        /* ---- first trial (tau = 1) on the nodes this workgroup owns; then straight on to the next
+         * iteration at the trial point: the top workgroup checks that it was accepted ---- */
+        const double fsum = p_stage_owned<NX, NU, MD>(Dt, T, L, l0, nown, s, wave, lane, 1.0, cur, lamn, false);
+        if (lane == 0) L.part[4 * wave + 2] = fsum;
         __syncthreads();
-        if (threadIdx.x == 0 && !is_top) __hip_atomic_fetch_add(Sy.st_cnt + parent_wg, 1u, RLX, AGENT);
         ns += 1u;
-        pstamp(Dt, O, e, tier, s, sl++);                                  /* stage done */
-        double f = 0.0, d = 0.0;
-        for (int w = 0; w < FW; w++) { f += L.wave0[w * U::WAVE_LDS + 2]; d += L.wave0[w * U::WAVE_LDS + 1]; }
-        p_reduce_and_decide<NX, NU, MD>(c, Dt, O, Gm, Sy, L, wg, f, d, nd, false);
-        nd += 1u;
-        pstamp(Dt, O, e, tier, s, sl++);                                  /* reduction handed in */
-        /* go straight on at the trial point: the top workgroup checks that it was accepted */
+        unposted = true;
         cur ^= 1;
+        pstamp(Dt, O, e, tier, s, sl++);                                  /* stage done */
     }
-#undef P_LEAVE_IF
 }
