@@ -618,7 +618,7 @@ struct tqgpu_solver {
     Data D{};
     double *d_mu_x = nullptr, *d_mu_u = nullptr;
     double *d_lam_init = nullptr;   /* starting point of every solve (tqgpu_set_lambda) */
-    size_t sync_noctrl_bytes = 0;   /* inter-workgroup words of the persistent path without the control block behind them */
+    unsigned launch_no = 0;         /* persistent launches so far (16 bits, never 0): tags of the hand-over words */
     /* writable aliases of the const inputs */
     double *A = nullptr, *B = nullptr, *b = nullptr, *Qd = nullptr, *Rd = nullptr, *q = nullptr, *r = nullptr;
     double *xmin = nullptr, *xmax = nullptr, *umin = nullptr, *umax = nullptr;
@@ -1003,31 +1003,30 @@ int setup_persist(tqgpu_solver *s, int device) {
      * margin against the occupancy query over-reporting (MI355X guide, "Residency and cooperative launch") */
     const int capacity = prop.multiProcessorCount * std::max(1, per_cu - 1);
     if (per_cu < 1 || G.G > capacity) return TQGPU_OK;
-    /* words: up_cnt[G], st_cnt[G], down[G], then four single words on their own 128-byte lines */
-    const size_t arrays = (3 * (size_t)G.G + 31) / 32 * 32;
-    const size_t ctrl_words = (sizeof(Ctrl) + 127) / 128 * 32;         /* the control block rides along: ONE memset per solve */
-    const size_t nwords = arrays + 4 * 32 + ctrl_words;
-    s->sync_words_bytes = nwords * sizeof(unsigned);
-    s->sync_noctrl_bytes = (arrays + 4 * 32) * sizeof(unsigned);
-    const size_t bytes = s->sync_words_bytes + (3 * (size_t)G.G + 16) * sizeof(double);
+    /* hand-over buffers (tagged 64-bit words, see tdunes_persist.hpp); zeroed once, never reset */
+    const int nx0 = s->nx[0];
+    const size_t n_sch = (size_t)s->Nn * (nx0 * nx0 + nx0) * 2, n_dlt = (size_t)s->sum_nx * 2, n_ndt = (size_t)s->Nn * 2 * nx0 * 2;
+    const size_t n_parts = (size_t)G.G * 4, n_errs = (size_t)G.G * 2;
+    const size_t bytes = (n_sch + n_dlt + n_ndt + n_parts + n_errs + 32) * sizeof(unsigned long long);
     HIP_TRY(hipMalloc(&s->sync_slab, bytes));
     HIP_TRY(hipMemset(s->sync_slab, 0, bytes));
-    unsigned *w = static_cast<unsigned *>(s->sync_slab);
-    s->psync.up_cnt = w; s->psync.st_cnt = w + G.G; s->psync.down = w + 2 * G.G;
-    s->psync.arrive = w + arrays; s->psync.err_cnt = w + arrays + 32;
-    s->psync.halt = w + arrays + 64; s->psync.timeout = w + arrays + 96;
-    s->D.ctrl = reinterpret_cast<Ctrl *>(w + arrays + 4 * 32);
-    double *d = reinterpret_cast<double *>(static_cast<char *>(s->sync_slab) + s->sync_words_bytes);
-    s->psync.parts = d; s->psync.errp = d + 2 * G.G;
+    unsigned long long *w = static_cast<unsigned long long *>(s->sync_slab);
+    s->psync.sch = w; s->psync.dlt = w + n_sch; s->psync.ndt = s->psync.dlt + n_dlt; s->psync.parts = s->psync.ndt + n_ndt;
+    s->psync.errs = s->psync.parts + n_parts;
+    s->psync.halt = reinterpret_cast<unsigned *>(s->psync.errs + n_errs);
+    s->psync.timeout = s->psync.halt + 32;
+    s->psync.seq = 0;
     s->persist_ok = true;
     return TQGPU_OK;
 }
 
-/* one persistent launch: zero the inter-workgroup words, then the kernel (prologue = first sweep of the solve) */
+/* one persistent launch (prologue = first sweep of the solve + control block reset): no memset, the
+ * hand-over words are told apart by the launch number in their tags */
 int launch_persist(tqgpu_solver *s, const Opts &O, int &launches, int prologue) {
     const Tree &T = s->T; const Data &D = s->D; hipStream_t st = s->stream;
-    /* first launch of a solve: words + control block in one go; relaunch: the control block carries the state */
-    HIP_TRY(hipMemsetAsync(s->sync_slab, 0, prologue ? s->sync_words_bytes : s->sync_noctrl_bytes, st));
+    s->launch_no = (s->launch_no + 1) & 0xFFFFu;
+    if (s->launch_no == 0) s->launch_no = 1;
+    s->psync.seq = s->launch_no << 16;
     switch (s->fast) {
 #define X(idx, nx, nu, md) case idx: hipLaunchKernelGGL((f_persist<nx, nu, md>), dim3(s->geom.G), dim3(FW * WAVE), s->lds_persist, st, T, D, O, s->geom, s->psync, (const double *)s->d_lam_init, prologue); break;
         FAST_TABLE(X)

@@ -8,34 +8,34 @@
  * tier subtree keeps its workgroup for the whole solve:
  *   - grid = one 4-wave workgroup per tier subtree (C2: 64 + 8 + 1 = 73), all co-resident;
  *   - a block's W / L, Ut / CholUt, residual, backward solution and reciprocal diagonal live in
- *     the workgroup's LDS (25 KB per tier subtree) -- global memory only carries what crosses
- *     workgroups or must survive the launch (x, u, multipliers, step, boundary Schur records);
- *   - workgroups hand over through agent-scope words (MI355X guide, Guideline 16, recipe R1: payload
- *     with sc1 stores, every storing wave drains vmcnt, workgroup barrier, ONE relaxed agent atomic;
- *     the consumer polls relaxed with s_sleep and reads the payload with sc1 loads only):
- *       up_cnt[parent]  children -> parent, Schur records of the subtree roots are in Sbuf,
- *       down[wg]        parent -> children, the forward sweep has written the step of my blocks,
- *       st_cnt[parent]  children -> parent, the stage sweep has rewritten the nodes I own,
- *       err_cnt         everybody -> top, termination partial of my blocks is in errp[wg],
- *       arrive          everybody -> top, my {fval, dot} partial of the last stage sweep is in parts[wg],
- *       halt            top -> everybody, the launch is over;
- *     all hand-ins are fire-and-forget (no returning atomics): only consumers ever wait;
- *   - everything a workgroup needs from ITSELF stays in its LDS across iterations: the duals of its
- *     blocks, x / u / QinvCal / RinvCal of the nodes it owns, the step of its blocks.  The bottom
- *     tier (the start of every iteration's critical path) therefore goes from the stage sweep to
- *     G + H of the next iteration without touching global memory for anything but constants;
- *   - the FIRST sweep of a solve (stage QPs at lambda0, fval0) is the launch's prologue;
+ *     the workgroup's LDS -- and so does everything else a workgroup needs from ITSELF across
+ *     iterations: the duals of its blocks, x / u / QinvCal / RinvCal of the nodes it owns, the step
+ *     of its blocks.  Global memory carries the results (x, u, multipliers, step) and what crosses
+ *     workgroups;
+ *   - what crosses workgroups travels as TAGGED WORDS: a double is written as two 64-bit relaxed
+ *     agent-scope atomic stores, each (tag << 32) | 32-bit half, tag = launch number and sequence
+ *     number of the hand-over.  The consumer polls the payload itself until every word carries the
+ *     tag it expects.  No flag, no counter, no store drain, no returning atomic: a hand-over costs
+ *     one store latency plus one load latency, and producers never wait.  (64-bit atomicity is all
+ *     this relies on: a torn double shows a stale tag in one half and is simply read again.)
+ *       sch    child -> parent     Schur record of the subtree root           (tag: iteration)
+ *       dlt    parent -> child     step of the subtree root's own duals       (tag: iteration)
+ *       ndt    child -> parent     x, QinvCal of the subtree root node        (tag: stage sweep)
+ *       parts  everybody -> top    {fval, dot} partial of a stage sweep       (tag: stage sweep)
+ *       errs   everybody -> top    termination partial of G + H               (tag: iteration)
+ *       halt   top -> everybody    the launch is over (word == launch number)
+ *     Buffers are never reset: a stale word carries another launch's number;
+ *   - the FIRST sweep of a solve (stage QPs at lambda0, fval0) is the launch's prologue, which also
+ *     initialises the control block: a solve is ONE kernel launch and nothing else;
  *   - an iteration does not wait for the line-search decision of the previous one: the first trial
  *     (tau = 1) is accepted almost always, so every workgroup goes straight on to G + H and the
- *     backward sweep of the next iteration at the trial point.  Only the top workgroup looks at
- *     the decision, before anything irreversible (termination verdict, forward sweep, next trial);
- *     if the trial was NOT accepted it halts the launch and the speculative work is simply dropped
- *     (it only touched LDS, Sbuf and errp, which every iteration rebuilds);
- *   - termination is decided from the flat errp[] array as soon as every workgroup has done G + H,
+ *     backward sweep of the next iteration at the trial point.  Only the top workgroup (which has
+ *     the most slack) takes the decision, before anything irreversible (termination verdict, forward
+ *     sweep, next trial); if the trial was NOT accepted it halts the launch and the speculative work
+ *     is simply dropped (it only touched LDS and hand-over buffers, which every iteration rebuilds);
+ *   - termination is decided from the errs[] partials as soon as every workgroup has done G + H,
  *     i.e. long before the backward sweep of a converged point would have reached the top;
- *   - the trial stage sweep runs four nodes per wave (16 lanes per node) for the nodes a workgroup
- *     owns; the line-search decision is taken by the top workgroup (which has the most slack), from
- *     the per-workgroup {fval, dot} partials summed in workgroup order;
+ *   - the trial stage sweep runs four nodes per wave (16 lanes per node) for the nodes a workgroup owns;
  *   - every spin is bounded (wall clock); a timeout ends the launch with status UNKNOWN_ERROR.
  * Extra line-search trials (rare) end the launch: the host runs them with the ordinary trial kernels
  * and relaunches (without prologue); nothing but global memory carries state across launches.
@@ -45,36 +45,39 @@
 #define RLX __ATOMIC_RELAXED
 #define AGENT __HIP_MEMORY_SCOPE_AGENT
 
+typedef unsigned long long u64;
+
 __device__ __forceinline__ double ld_sc1(const double *p) { return __hip_atomic_load(p, RLX, AGENT); }
 __device__ __forceinline__ void st_sc1(double *p, double v) { __hip_atomic_store(p, v, RLX, AGENT); }
-__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-/* inter-workgroup words of one persistent launch (zeroed by the host before every launch; all
- * counters are monotonic within a launch, `e` below is the launch-relative iteration number + 1) */
+/* hand-over buffers of the persistent path (zeroed once at creation, never reset) */
 struct PSync {
-    unsigned *up_cnt;       /* [G] backward arrivals of child subtrees at their parent workgroup      */
-    unsigned *st_cnt;       /* [G] completed stage sweeps of child subtrees, counted at the parent    */
-    unsigned *down;         /* [G] e, published by a workgroup after its forward sweep                */
-    unsigned *arrive;       /* workgroups that have handed in their {fval, dot} partial (monotonic)   */
-    unsigned *err_cnt;      /* arrivals of termination partials                                      */
-    unsigned *halt;         /* set by the top workgroup: everybody leaves at the next poll            */
-    unsigned *timeout;      /* set when a bounded spin gave up                                       */
-    double *parts;          /* [G][2] per-workgroup {fval, dot} partials                             */
-    double *errp;           /* [G] per-workgroup termination partial                                 */
+    u64 *sch;               /* [nodes][SCH][2]   Schur record of a tier subtree root                   */
+    u64 *dlt;               /* [sum_nx][2]       step, indexed like dlam (only tier roots' slices used) */
+    u64 *ndt;               /* [nodes][2 NX][2]  x then QinvCal of a tier subtree root node            */
+    u64 *parts;             /* [G][2][2]         per-workgroup {fval, dot}                             */
+    u64 *errs;              /* [G][2]            per-workgroup termination partial                     */
+    unsigned *halt;         /* == seq: the top workgroup ended this launch                            */
+    unsigned *timeout;      /* sticky: a bounded spin gave up                                         */
+    unsigned seq;           /* launch number << 16 (low 16 bits of the number are never 0)            */
 };
 
-/* bounded poll by ONE lane until *w >= target; returns false when the launch is over instead
- * (halt or timeout), true when the target was reached */
-__device__ __forceinline__ bool poll_ge(const unsigned *w, unsigned target, const PSync &Sy, unsigned *val = nullptr) {
-    const unsigned long long t0 = wall_clock64();
-    for (;;) {
-        const unsigned v = __hip_atomic_load(w, RLX, AGENT);
-        const unsigned h = __hip_atomic_load(Sy.halt, RLX, AGENT) | __hip_atomic_load(Sy.timeout, RLX, AGENT);
-        if (v >= target) { if (val) *val = v; return true; }
-        if (h) return false;
-        if (wall_clock64() - t0 > 50000000ull) { __hip_atomic_store(Sy.timeout, 1u, RLX, AGENT); return false; }   /* 0.5 s at 100 MHz */
-        __builtin_amdgcn_s_sleep(2);
-    }
+__device__ __forceinline__ void st_tag(u64 *p, double v, unsigned tag) {
+    const u64 t = (u64)tag << 32;
+    __hip_atomic_store(p, t | (unsigned)__double2loint(v), RLX, AGENT);
+    __hip_atomic_store(p + 1, t | (unsigned)__double2hiint(v), RLX, AGENT);
+}
+__device__ __forceinline__ double ld_tag(const u64 *p, unsigned tag, bool &ok) {
+    const u64 a = __hip_atomic_load(p, RLX, AGENT), b = __hip_atomic_load(p + 1, RLX, AGENT);
+    ok = ok && (unsigned)(a >> 32) == tag && (unsigned)(b >> 32) == tag;
+    return __hiloint2double((int)(unsigned)b, (int)(unsigned)a);
+}
+/* between two polls: false when the launch is over (halt / timeout) and the poller must give up */
+__device__ __forceinline__ bool spin_on(const PSync &Sy, u64 t0) {
+    if (__hip_atomic_load(Sy.halt, RLX, AGENT) == Sy.seq || __hip_atomic_load(Sy.timeout, RLX, AGENT)) return false;
+    if (wall_clock64() - t0 > 50000000ull) { __hip_atomic_store(Sy.timeout, 1u, RLX, AGENT); return false; }   /* 0.5 s at 100 MHz */
+    __builtin_amdgcn_s_sleep(1);
+    return true;
 }
 
 template <int NX, int NU, int MD>
@@ -87,12 +90,12 @@ struct PLds {
     /* scratch of the top workgroup's reductions: the Schur record storage, free before the backward sweep */
     static constexpr int RED_CAP = NBT * U::SCH / 2;
     lds_ptr W, Ut, res, y, inv, dl, sch, node, lamb, lamroot, droot, part, wave0, wave;
-    lds_iptr flag;
+    lds_iptr flag, abort;                                            /* abort: a poll gave up (launch over), leave at the next uniform point */
     __device__ PLds(double *base, int wave_id) {
         W = to_lds(base); Ut = W + NBT * D * D; res = Ut + NBT * NX * D; y = res + NBT * D; inv = y + NBT * D;
         dl = inv + NBT * D; sch = dl + NBT * D; node = sch + NBT * U::SCH; lamb = node + SLOTS * NODE;
         lamroot = lamb + 2 * NBT * D; droot = lamroot + 2 * NX; part = droot + NX; wave0 = part + 4 * FW; wave = wave0 + wave_id * U::WAVE_LDS;
-        flag = (lds_iptr)(wave0 + FW * U::WAVE_LDS);
+        flag = (lds_iptr)(wave0 + FW * U::WAVE_LDS); abort = flag + 1;
     }
     /* part[4 w + i]: wave w's partials -- 0 termination norm, 1 res' * dlam, 2 dual function value */
     /* owned node `q` (heap order inside the tier subtree): x | u | QinvCal | RinvCal */
@@ -115,7 +118,7 @@ struct GhRegs {
 };
 
 template <int NX, int NU, int MD>
-__device__ __forceinline__ void p_gh_load(const Data &Dt, const PLds<NX, NU, MD> &L, int p, int loc, bool foreign, int lane, GhRegs<NX, NU, MD> &G) {
+__device__ __forceinline__ void p_gh_load(const Data &Dt, const PSync &Sy, const PLds<NX, NU, MD> &L, int p, int loc, bool foreign, unsigned ns, int lane, GhRegs<NX, NU, MD> &G) {
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D, NZ = U::NZ;
     const int row = lane & 15, g = lane >> 4;
@@ -138,7 +141,19 @@ __device__ __forceinline__ void p_gh_load(const Data &Dt, const PLds<NX, NU, MD>
         G.a[s] = ok ? av : 0.0; G.pc[s] = ok ? pv : 0.0; G.z[s] = ok ? zv : 0.0;
     }
     double xv, qv;
-    if (foreign) { xv = ld_sc1(Dt.x + bo + rowc); qv = ld_sc1(Dt.QinvCal + bo + rowc); }
+    if (foreign && ns > 0u) {
+        /* staged by the child workgroup in this launch: poll its tagged copy */
+        const u64 *src = Sy.ndt + ((size_t)k * 2 * NX + r) * 2;
+        const unsigned tag = Sy.seq | ns;
+        const u64 t0 = wall_clock64();
+        bool ok;
+        for (;;) {
+            ok = true;
+            xv = ld_tag(src, tag, ok); qv = ld_tag(src + 2 * NX, tag, ok);
+            if (ok || !spin_on(Sy, t0)) break;
+        }
+        if (!ok) *L.abort = 1;
+    } else if (foreign) { xv = Dt.x[bo + rowc]; qv = Dt.QinvCal[bo + rowc]; }       /* relaunch: staged by earlier kernels */
     else { lds_cptr kid = L.nx_(MD * loc + 1 + cidx); xv = kid[r]; qv = kid[NZ + r]; }
     const double bv = Dt.b[bo + rowc];
     G.xk = (live && g == 0) ? xv : 0.0; G.bk = (live && g == 0) ? bv : 0.0; G.qk = live ? qv : 0.0;
@@ -213,9 +228,9 @@ __device__ __forceinline__ void p_store_factor(PLds<NX, NU, MD> &L, int loc, int
 
 /* Schur record [S | v] = CUt * [CUt' | y] (one f64 MFMA tile, K = D) straight from the CholUt / y just
  * stored in LDS: lane (i, g) feeds CUt[i][g + 4 st] as A and the same (i < NX) or y (i == NX) as B.
- * GLOBAL: destination is global Sbuf (sc1 stores, another workgroup reads it), else an LDS record. */
+ * GLOBAL: destination is the parent workgroup (tagged words), else an LDS record. */
 template <int NX, int NU, int MD, bool GLOBAL>
-__device__ __forceinline__ void p_schur(PLds<NX, NU, MD> &L, int loc, int lane, lds_ptr sdst_lds, double *sdst_glb) {
+__device__ __forceinline__ void p_schur(PLds<NX, NU, MD> &L, int loc, int lane, lds_ptr sdst_lds, u64 *sdst_glb, unsigned tag) {
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D;
     lds_fence();
@@ -237,23 +252,36 @@ __device__ __forceinline__ void p_schur(PLds<NX, NU, MD> &L, int loc, int lane, 
         const int ip = g + 4 * rr;
         if (ip < NX && i <= NX) {
             const int off = (i < NX) ? ip + i * NX : NX * NX + ip;
-            if (GLOBAL) st_sc1(sdst_glb + off, acc[rr]); else sdst_lds[off] = acc[rr];
+            if (GLOBAL) st_tag(sdst_glb + 2 * off, acc[rr], tag); else sdst_lds[off] = acc[rr];
         }
     }
 }
 
-/* forward step of block `loc` from LDS; writes the solution to LDS (dl) and to global dlam (sc1) */
+/* forward step of block `loc` from LDS; writes the solution to LDS (dl) and to global dlam.
+ * from_parent: the block is my subtree root, the step of its owner node's duals comes from the parent
+ * workgroup (tagged words, polled).  to_children: the block's children are tier subtree roots of the
+ * tier below: they get a tagged copy of the solution. */
 template <int NX, int NU, int MD>
-__device__ __forceinline__ double p_forward(const Data &Dt, PLds<NX, NU, MD> &L, int ii, int loc, int lane, lds_cptr delta_lds, const double *delta_glb) {
+__device__ __forceinline__ double p_forward(const Data &Dt, const PSync &Sy, PLds<NX, NU, MD> &L, int ii, int loc, int lane, lds_cptr delta_lds,
+                                            bool from_parent, bool to_children, unsigned tag) {
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D;
     const int li = lane < D ? lane : 0;
     lds_cptr Lc = L.W + loc * D * D + li * D;
     lds_cptr Cc = L.Ut + loc * NX * D + li * NX;
     double dv[NX];
-    if (delta_glb) {
+    bool ok = true;
+    if (from_parent) {
+        const u64 *src = Sy.dlt + (size_t)NX * ii * 2;
+        const u64 t0 = wall_clock64();
+        for (;;) {
+            ok = true;
 #pragma unroll
-        for (int r = 0; r < NX; r++) dv[r] = ld_sc1(delta_glb + r);
+            for (int r = 0; r < NX; r++) dv[r] = ld_tag(src + 2 * r, tag, ok);
+            if (ok || !spin_on(Sy, t0)) break;
+        }
+        ok = __all(ok);
+        if (!ok) *L.abort = 1;                            /* the launch is over: nothing below may reach global memory */
         if (lane == 0) {                                  /* the subtree root's own step: the stage sweep reads it from LDS */
 #pragma unroll
             for (int r = 0; r < NX; r++) L.droot[r] = dv[r];
@@ -278,20 +306,26 @@ __device__ __forceinline__ double p_forward(const Data &Dt, PLds<NX, NU, MD> &L,
         if (lane < k) s = fma(-Lcol[k], zk, s);
     }
     double pd = 0.0;
-    if (lane < D) { st_sc1(Dt.dlam + U::bo(ii) + lane, mine); L.dl[loc * D + lane] = mine; pd = L.res[loc * D + lane] * mine; }
+    if (lane < D) {
+        if (ok) st_sc1(Dt.dlam + U::bo(ii) + lane, mine);
+        if (to_children && ok) st_tag(Sy.dlt + (size_t)(U::bo(ii) + lane) * 2, mine, tag);
+        L.dl[loc * D + lane] = mine;
+        pd = L.res[loc * D + lane] * mine;
+    }
     return pd;                                            /* per-lane term of res' * dlam: summed once per sweep */
 }
 
 /* stage QP of owned node slot q (= node k) at the trial point lam_cur + step*dlam, by ONE 16-lane
  * group (lanes t of the group: t < NX state entries, NX <= t < NX+NU input entries).  Duals and steps
  * come from the workgroup's LDS copies (lamb / lamroot, dl / droot; `cb` = current buffer), constants
- * from global memory; results go to global memory (sc1 stores, nobody waits for them here) AND to the
- * LDS node store / the other dual buffer for this workgroup's next G + H.
+ * from global memory; results go to global memory (nobody waits for them) AND to the LDS node store /
+ * the other dual buffer for this workgroup's next G + H; the subtree root's x and QinvCal also go to
+ * the parent workgroup as tagged words (to_parent).
  * init: first sweep of a solve -- evaluate at the current duals themselves.
  * Returns the node's dual-function term (valid in every lane of the group). */
 template <int NX, int NU, int MD>
-__device__ __forceinline__ double p_stage16(const Data &Dt, PLds<NX, NU, MD> &L, int q, int k, int Np, int t, lds_ptr gl /* group scratch: D + NX */,
-                                            double step, int cb, double *lamn, bool active, bool init) {
+__device__ __forceinline__ double p_stage16(const Data &Dt, const PSync &Sy, PLds<NX, NU, MD> &L, int q, int k, int Np, int t, lds_ptr gl /* group scratch: D + NX */,
+                                            double step, int cb, double *lamn, bool active, bool init, bool to_parent, unsigned tag) {
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D, NBT = U::NBT;
     static_assert(NX + NU <= 16 && D <= 16, "16-lane stage needs nx+nu <= 16 and d <= 16");
@@ -350,6 +384,10 @@ __device__ __forceinline__ double p_stage16(const Data &Dt, PLds<NX, NU, MD> &L,
         else { st_sc1(Dt.rmod + uo + j, v); st_sc1(Dt.uUnc + uo + j, unc); st_sc1(Dt.u + uo + j, val); st_sc1(Dt.RinvCal + uo + j, cal); }
         lds_ptr ns = L.nx_(q);                            /* x | u | QinvCal | RinvCal: entry t, NX+NU apart */
         ns[t] = val; ns[NX + NU + t] = cal;
+        if (to_parent && q == 0 && isx) {                 /* my subtree root: the parent workgroup's G + H reads x and QinvCal */
+            u64 *dst = Sy.ndt + ((size_t)k * 2 * NX + j) * 2;
+            st_tag(dst, val, tag); st_tag(dst + 2 * NX, cal, tag);
+        }
         p_q = (wd * val) * val;
         p_h = v * val;
     }
@@ -394,11 +432,44 @@ __device__ __forceinline__ int p_slot_node(int q, int l0, int s) {
     return U::first(l0 + t) + s * U::width(t) + (q - U::first(t));
 }
 
+/* subtract the Schur records of the children in the tier below: tagged words written by the child
+ * workgroups, polled until every word of this lane's rows carries `tag`; false when the poll gave up */
+template <int NX, int NU, int MD>
+__device__ __forceinline__ bool p_sub_children_tagged(const PSync &Sy, const u64 *sch, unsigned tag, int lane, double (&T)[Uni<NX, NU, MD>::D]) {
+    using U = Uni<NX, NU, MD>;
+    constexpr int D = U::D;
+    const bool vrow = lane == D, need = lane <= D;
+    const int lc = lane < D ? lane / NX : 0;
+    const int r = lane < D ? lane - lc * NX : 0;
+    const int off = vrow ? NX * NX : r, stride = vrow ? 1 : NX;
+    double v[MD][NX];
+    const u64 t0 = wall_clock64();
+    bool ok;
+    for (;;) {
+        ok = true;
+#pragma unroll
+        for (int c = 0; c < MD; c++) {
+            const u64 *src = sch + ((size_t)c * U::SCH + off) * 2;
+#pragma unroll
+            for (int j = 0; j < NX; j++) v[c][j] = ld_tag(src + (size_t)j * stride * 2, tag, ok);
+        }
+        ok = ok || !need;
+        if (ok || !spin_on(Sy, t0)) break;
+    }
+#pragma unroll
+    for (int c = 0; c < MD; c++) {
+        const bool act = vrow || (lane < D && lc == c);
+#pragma unroll
+        for (int j = 0; j < NX; j++) T[c * NX + j] -= act ? v[c][j] : 0.0;
+    }
+    return ok;
+}
+
 /* stage sweep over the nodes this workgroup owns (the owner nodes of its blocks in heap order, then --
  * bottom tier -- the leaves below), four nodes per wave; returns the wave's sum of the node terms */
 template <int NX, int NU, int MD>
-__device__ __forceinline__ double p_stage_owned(const Data &Dt, const Tree &T, PLds<NX, NU, MD> &L, int l0, int nown, int s, int wave, int lane,
-                                                double step, int cb, double *lamn, bool init) {
+__device__ __forceinline__ double p_stage_owned(const Data &Dt, const PSync &Sy, const Tree &T, PLds<NX, NU, MD> &L, int l0, int nown, int s, int wave, int lane,
+                                                double step, int cb, double *lamn, bool init, bool to_parent, unsigned tag) {
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D;
     const int grp = lane >> 4, t16 = lane & 15;
@@ -408,38 +479,50 @@ __device__ __forceinline__ double p_stage_owned(const Data &Dt, const Tree &T, P
         const int q = base + wave * 4 + grp;
         const bool active = q < nown;
         const int k = active ? p_slot_node<NX, NU, MD>(q, l0, s) : 0;
-        fsum += p_stage16<NX, NU, MD>(Dt, L, active ? q : 0, k, T.Np, t16, gl, step, cb, lamn, active, init);
+        fsum += p_stage16<NX, NU, MD>(Dt, Sy, L, active ? q : 0, k, T.Np, t16, gl, step, cb, lamn, active, init, to_parent, tag);
     }
     return rows_fold<false>(fsum);       /* every lane of a 16-lane group holds its group's sum */
 }
 
-/* top workgroup: ordered sums (workgroup order) of the per-workgroup {fval, dot} partials and of the
- * termination partials (sum or maximum), gathered with parallel sc1 loads through the Schur record
- * scratch in chunks; results valid in thread 0 */
+/* top workgroup: ordered sums (workgroup order) of the per-workgroup {fval, dot} partials (tag tag_p;
+ * skipped when want_parts is false) and of the termination partials (tag tag_e; sum or maximum), polled
+ * in parallel through the Schur record scratch in chunks; results valid in thread 0.  Returns false in
+ * every thread when a poll gave up. */
 template <int NX, int NU, int MD>
-__device__ __forceinline__ void p_gather3(PLds<NX, NU, MD> &L, const double *parts, const double *errp, int count, bool err_max,
+__device__ __forceinline__ bool p_gather3(const PSync &Sy, PLds<NX, NU, MD> &L, int count, bool want_parts, unsigned tag_p, unsigned tag_e, bool err_max,
                                           double &fa, double &da, double &ea) {
     constexpr int CAP = PLds<NX, NU, MD>::RED_CAP * 2 / 3;
     fa = 0.0; da = 0.0; ea = 0.0;
     for (int c0 = 0; c0 < count; c0 += CAP) {
         const int n = min(CAP, count - c0);
         for (int w = threadIdx.x; w < n; w += FW * WAVE) {
-            L.sch[3 * w] = ld_sc1(parts + 2 * (size_t)(c0 + w));
-            L.sch[3 * w + 1] = ld_sc1(parts + 2 * (size_t)(c0 + w) + 1);
-            L.sch[3 * w + 2] = ld_sc1(errp + c0 + w);
+            const u64 *pp = Sy.parts + (size_t)(c0 + w) * 4, *pe = Sy.errs + (size_t)(c0 + w) * 2;
+            const u64 t0 = wall_clock64();
+            double f = 0.0, d = 0.0, er;
+            bool ok;
+            for (;;) {
+                ok = true;
+                if (want_parts) { f = ld_tag(pp, tag_p, ok); d = ld_tag(pp + 2, tag_p, ok); }
+                er = ld_tag(pe, tag_e, ok);
+                if (ok || !spin_on(Sy, t0)) break;
+            }
+            if (!ok) *L.abort = 1;
+            L.sch[3 * w] = f; L.sch[3 * w + 1] = d; L.sch[3 * w + 2] = er;
         }
         __syncthreads();
+        if (*L.abort) return false;
         if (threadIdx.x == 0) {
             for (int w = 0; w < n; w++) { fa += L.sch[3 * w]; da += L.sch[3 * w + 1]; ea = err_max ? fmax(ea, L.sch[3 * w + 2]) : ea + L.sch[3 * w + 2]; }
         }
         __syncthreads();
     }
+    return true;
 }
 
 template <int NX, int NU, int MD>
 __global__ void __launch_bounds__(FW * WAVE) f_persist(Tree T, Data Dt, Opts O, PGeom Gm, PSync Sy, const double *lam_init, int prologue) {
     using U = Uni<NX, NU, MD>;
-    constexpr int D = U::D, NBT = U::NBT;
+    constexpr int D = U::D;
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     Ctrl *c = Dt.ctrl;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -451,19 +534,25 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(Tree T, Data Dt, Opts O, 
     const int s = wg - Gm.wg0[tier];
     const int l0 = Gm.l0[tier], l1 = Gm.l1[tier], th = l1 - l0;
     const bool is_top = tier == Gm.n_tiers - 1, is_bottom = tier == 0;
-    const int root_blk = U::first(l0) + s;                            /* subtree root block (= node) */
-    const int parent_wg = is_top ? -1 : Gm.wg0[tier + 1] + ((root_blk - 1) / MD - U::first(l0 - 1)) / U::width(Gm.l1[tier + 1] - 1 - Gm.l0[tier + 1]);
-    const unsigned nchild = is_bottom ? 0u : (unsigned)(U::width(th - 1) * MD);   /* child subtrees below my bottom level */
     const int nbt = U::first(th);                                      /* my blocks */
     const int nown = nbt + (is_bottom ? U::width(th) : 0);             /* nodes I own */
-    if (__hip_atomic_load(&c->done, RLX, AGENT) || __hip_atomic_load(&c->ls_pending, RLX, AGENT)) return;
-    int cur = __hip_atomic_load(&c->cur, RLX, AGENT);
-    unsigned nd = 0u;          /* {fval, dot} reductions handed in so far (by me, hence by everybody who got this far) */
-    unsigned ns = 0u;          /* stage sweeps I have completed in this launch */
-    bool unposted = false;     /* a finished stage sweep whose results are not published yet */
+    const int root_blk = U::first(l0) + s;                             /* subtree root block (= node) */
+    int cur = 0;
+    if (prologue) {
+        /* a fresh solve: the control block starts from zero (nobody else reads it during the launch) */
+        if (is_top && threadIdx.x == 0) {
+            c->done = 0; c->status = 0; c->iter = 0; c->cur = 0; c->ls_pending = 0; c->ls_iter = 0; c->ls_total = 0; c->ls_last = 0;
+            c->restart_counter = 0; c->n_reg = 0; c->tau = 0.0; c->tauPrev = 0.0; c->fval0 = 0.0; c->fval = 0.0; c->dot = 0.0; c->err = 0.0;
+        }
+    } else {
+        if (__hip_atomic_load(&c->done, RLX, AGENT) || __hip_atomic_load(&c->ls_pending, RLX, AGENT)) return;
+        cur = __hip_atomic_load(&c->cur, RLX, AGENT);
+    }
+    unsigned nd = 0u;          /* {fval, dot} reductions handed in so far (= stage sweeps of this launch) */
 
     /* ---- LDS copies of what this workgroup owns: duals of my blocks and of my root, node store ---- */
     {
+        if (threadIdx.x == 0) *L.abort = 0;
         const double *lsrc = prologue ? lam_init : (cur ? Dt.lam1 : Dt.lam0);
         for (int i = threadIdx.x; i < nbt * D; i += FW * WAVE) {
             const int loc = i / D, t = i - loc * D;
@@ -481,69 +570,40 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(Tree T, Data Dt, Opts O, 
         __syncthreads();
     }
 
-    /* Hand-ins of this workgroup, by ONE lane, fire-and-forget: (stage) a finished stage sweep -- node data
-     * of my subtree root for the parent (st_cnt) and my {fval, dot} partial for the top workgroup (arrive);
-     * (gh) the termination partial of my blocks (err_cnt).  The caller has made sure that every wave
-     * drained the global stores of its stage sweep (drain_stores + workgroup barrier). */
-    auto post = [&](bool stage, bool gh) {
-        if (stage) {
-            double f = 0.0, d = 0.0;
-            for (int w = 0; w < FW; w++) { f += L.part[4 * w + 2]; d += L.part[4 * w + 1]; }
-            st_sc1(Sy.parts + 2 * wg, f);
-            st_sc1(Sy.parts + 2 * wg + 1, d);
-        }
-        if (gh) {
-            double err = 0.0;
-            for (int w = 0; w < FW; w++) { const double v = L.part[4 * w]; err = (O.termCondition == 2) ? fmax(err, v) : err + v; }
-            st_sc1(Sy.errp + wg, err);
-        }
-        drain_stores();
-        if (stage) {
-            if (!is_top) __hip_atomic_fetch_add(Sy.st_cnt + parent_wg, 1u, RLX, AGENT);
-            __hip_atomic_fetch_add(Sy.arrive, 1u, RLX, AGENT);
-        }
-        if (gh) __hip_atomic_fetch_add(Sy.err_cnt, 1u, RLX, AGENT);
+    /* my {fval, dot} partial of stage sweep number nd to the top workgroup (thread 0, after the sweep's barrier) */
+    auto post_parts = [&]() {
+        double f = 0.0, d = 0.0;
+        for (int w = 0; w < FW; w++) { f += L.part[4 * w + 2]; d += L.part[4 * w + 1]; }
+        st_tag(Sy.parts + (size_t)wg * 4, f, Sy.seq | nd);
+        st_tag(Sy.parts + (size_t)wg * 4 + 2, d, Sy.seq | nd);
     };
 
     if (prologue) {
         /* ---- first sweep of the solve: stage QPs at lambda0 (copied into the current buffer), fval0 ---- */
         double *lam0 = cur ? Dt.lam1 : Dt.lam0;
-        const double fsum = p_stage_owned<NX, NU, MD>(Dt, T, L, l0, nown, s, wave, lane, 0.0, cur, lam0, true);
+        const double fsum = p_stage_owned<NX, NU, MD>(Dt, Sy, T, L, l0, nown, s, wave, lane, 0.0, cur, lam0, true, !is_top, Sy.seq | 1u);
         if (lane == 0) { L.part[4 * wave + 2] = fsum; L.part[4 * wave + 1] = 0.0; }
         __syncthreads();
-        ns = 1u;
-        unposted = true;
+        nd = 1u;
+        if (threadIdx.x == 0) post_parts();
     }
 
     for (unsigned e = 1u;; e++) {
+        const unsigned tag_e = Sy.seq | e;
         double *lamn = cur ? Dt.lam0 : Dt.lam1;
 
         int sl = 0;
         pstamp(Dt, O, e, tier, s, sl++);                                  /* 0: iteration start */
-        /* ---- the nodes my bottom-level blocks read are staged by the child workgroups ---- */
-        if (!is_bottom) {
-            if (unposted) {
-                drain_stores();
-                __syncthreads();
-                if (threadIdx.x == 0) post(true, false);
-                nd += 1u;
-                unposted = false;
-            }
-            if (threadIdx.x == 0) *L.flag = poll_ge(Sy.st_cnt + wg, ns * nchild, Sy) ? 0 : 1;
-            __syncthreads();
-            const int leave = *L.flag;
-            __syncthreads();
-            if (leave) return;
-        }
-        /* ---- G + H for my blocks (heap order inside the subtree), two blocks per wave in flight ---- */
-        double err = 0.0;
+        /* ---- G + H for my blocks (heap order inside the subtree), two blocks per wave in flight; the
+         * children of my bottom-level blocks were staged by the child workgroups (polled) ---- */
         {
+            double err = 0.0;
             const int nint = U::first(th - 1);                         /* blocks above my bottom level: children are mine */
             for (int loc0 = wave; loc0 < nbt; loc0 += 2 * FW) {
                 const int loc1 = loc0 + FW;
                 GhRegs<NX, NU, MD> g0, g1;
-                p_gh_load<NX, NU, MD>(Dt, L, p_slot_node<NX, NU, MD>(loc0, l0, s), loc0, !is_bottom && loc0 >= nint, lane, g0);
-                if (loc1 < nbt) p_gh_load<NX, NU, MD>(Dt, L, p_slot_node<NX, NU, MD>(loc1, l0, s), loc1, !is_bottom && loc1 >= nint, lane, g1);
+                p_gh_load<NX, NU, MD>(Dt, Sy, L, p_slot_node<NX, NU, MD>(loc0, l0, s), loc0, !is_bottom && loc0 >= nint, nd, lane, g0);
+                if (loc1 < nbt) p_gh_load<NX, NU, MD>(Dt, Sy, L, p_slot_node<NX, NU, MD>(loc1, l0, s), loc1, !is_bottom && loc1 >= nint, nd, lane, g1);
                 double v = p_gh_compute<NX, NU, MD>(L, loc0, lane, g0, O.termCondition);
                 err = (O.termCondition == 2) ? fmax(err, v) : err + v;
                 if (loc1 < nbt) {
@@ -552,34 +612,23 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(Tree T, Data Dt, Opts O, 
                 }
             }
             if (lane == 0) L.part[4 * wave] = err;
-            drain_stores();                               /* my stage sweep's global stores (long gone by now) */
             __syncthreads();
-        }
-        /* Bottom tier (the head of the critical path): the hand-ins wait for a wave that has no block in
-         * the backward sweep (below); every other tier has slack and hands in right away. */
-        bool post_gh = true, post_st = false;
-        if (is_bottom && unposted) { post_st = true; nd += 1u; unposted = false; }
-        if (!is_bottom || is_top || th == 1) {
-            if (threadIdx.x == 0) post(post_st, true);
-            post_gh = false; post_st = false;
+            if (!is_bottom && *L.abort) return;
+            if (threadIdx.x == 0) {
+                /* termination partial of my blocks to the top workgroup */
+                err = 0.0;
+                for (int w = 0; w < FW; w++) { const double v = L.part[4 * w]; err = (O.termCondition == 2) ? fmax(err, v) : err + v; }
+                st_tag(Sy.errs + (size_t)wg * 2, err, tag_e);
+            }
         }
         pstamp(Dt, O, e, tier, s, sl++);                                  /* 1: G+H done */
 
         if (is_top) {
             /* ---- verdicts: the outstanding {fval, dot} reduction (fval0 of the first sweep, or the first
              * trial of the previous iteration), then the termination test of the (then current) point ---- */
-            if (threadIdx.x == 0) {
-                int lv = 0;
-                if (nd > 0u && !poll_ge(Sy.arrive, nd * (unsigned)Gm.G, Sy)) lv = 1;
-                if (!lv && !poll_ge(Sy.err_cnt, e * (unsigned)Gm.G, Sy)) lv = 1;
-                *L.flag = lv;
-            }
-            __syncthreads();
-            int leave = *L.flag;
-            __syncthreads();
+            double fa, da, ea;
+            int leave = p_gather3<NX, NU, MD>(Sy, L, Gm.G, nd > 0u, Sy.seq | nd, tag_e, O.termCondition == 2, fa, da, ea) ? 0 : 1;
             if (!leave) {
-                double fa, da, ea;
-                p_gather3<NX, NU, MD>(L, Sy.parts, Sy.errp, Gm.G, O.termCondition == 2, fa, da, ea);
                 if (threadIdx.x == 0) {
                     int code = 0;
                     if (nd > 0u) {
@@ -597,6 +646,7 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(Tree T, Data Dt, Opts O, 
                         if (O.termCondition == 1) ea = sqrt(ea);
                         c->err = ea;
                         if (ea < O.tol) { c->status = 0; c->done = 1; code = 1; }
+                        else if (e >= 60000u) code = 1;                         /* tags carry 16 bits of sequence: relaunch */
                     }
                     *L.flag = code;
                 }
@@ -605,64 +655,35 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(Tree T, Data Dt, Opts O, 
                 __syncthreads();
             }
             if (leave) {
-                drain_stores();
-                __syncthreads();
-                if (threadIdx.x == 0) __hip_atomic_store(Sy.halt, 1u, RLX, AGENT);
+                if (threadIdx.x == 0) __hip_atomic_store(Sy.halt, Sy.seq, RLX, AGENT);
                 return;
             }
         }
         pstamp(Dt, O, e, tier, s, sl++);                                  /* 2: verdicts (top) */
 
         /* ---- backward sweep ---- */
-        if (!is_bottom) {
-            if (threadIdx.x == 0) *L.flag = poll_ge(Sy.up_cnt + wg, e * nchild, Sy) ? 0 : 1;
-            __syncthreads();
-            const int leave = *L.flag;
-            __syncthreads();
-            if (leave) return;
-        }
-        pstamp(Dt, O, e, tier, s, sl++);                                  /* 3: children arrived */
         double dotp = 0.0;                                /* per-lane terms of res' * dlam over my blocks */
         {
             double Tc[D];
             for (int t = th - 1; t >= 0; t--) {
                 const int nb = U::width(t);
-                /* the launch may be over (converged, line search needs the host): look once per level, the
-                 * load is in flight while the level factors */
-                unsigned halted = 0u;
-#ifdef TQ_LEVEL_HALT
-                if (threadIdx.x == 0) halted = __hip_atomic_load(Sy.halt, RLX, AGENT);
-#endif
-                if (post_gh && (t < th - 1 || nb < FW) && wave == FW - 1 && lane == 0) post(post_st, true);
-                if (t < th - 1 || nb < FW) post_gh = false;
                 if (wave < nb) {
                     const int ii = U::first(l0 + t) + s * nb + wave, loc = U::first(t) + wave;
                     const bool is_root = is_top && t == 0;
-#ifdef TQ_FINE_STAMPS
-                    const bool fs = is_top && t == 1 && wave == 0;
-                    if (fs) pstamp(Dt, O, e, 7, 0, 0);
-#endif
+                    bool ok = true;
                     p_load_rows<NX, NU, MD>(L, loc, lane, is_root, Tc);
-#ifdef TQ_FINE_STAMPS
-                    if (fs) { lds_fence(); pstamp(Dt, O, e, 7, 0, 1); }
-#endif
                     if (t < th - 1) sub_children<NX, NU, MD>((lds_cptr)(L.sch + (U::first(t + 1) + MD * wave) * U::SCH), lane, Tc);
-                    else if (!is_bottom) sub_children<NX, NU, MD, true>((const double *)(Dt.Sbuf + (size_t)U::kid0(ii) * U::SCH), lane, Tc);
-#ifdef TQ_FINE_STAMPS
-                    if (fs) { lds_fence(); pstamp(Dt, O, e, 7, 0, 2); }
-#endif
+                    else if (!is_bottom) {
+                        ok = p_sub_children_tagged<NX, NU, MD>(Sy, Sy.sch + (size_t)U::kid0(ii) * U::SCH * 2, tag_e, lane, Tc);
+                        ok = __all(ok);
+                        if (!ok && lane == 0) *L.abort = 1;
+                    }
                     double myinv = 0.0;
                     factor_rows<NX, NU, MD>(Dt, O, lane, Tc, myinv);
-#ifdef TQ_FINE_STAMPS
-                    if (fs) pstamp(Dt, O, e, 7, 0, 3);
-#endif
                     if (!is_root) {
                         p_store_factor<NX, NU, MD>(L, loc, lane, Tc, myinv);
-                        if (t == 0) p_schur<NX, NU, MD, true>(L, loc, lane, L.sch, Dt.Sbuf + (size_t)ii * U::SCH);
-                        else p_schur<NX, NU, MD, false>(L, loc, lane, L.sch + loc * U::SCH, nullptr);
-#ifdef TQ_FINE_STAMPS
-                        if (fs) pstamp(Dt, O, e, 7, 0, 4);
-#endif
+                        if (t == 0) { if (ok) p_schur<NX, NU, MD, true>(L, loc, lane, L.sch, Sy.sch + (size_t)ii * U::SCH * 2, tag_e); }
+                        else p_schur<NX, NU, MD, false>(L, loc, lane, L.sch + loc * U::SCH, nullptr, 0u);
                     } else {
                         /* root: keep L and 1/diag, then dlam_0 = L^-T (L^-1 res) */
                         if (lane <= D) {
@@ -681,63 +702,45 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(Tree T, Data Dt, Opts O, 
                             if (lane == k) mine = zk;
                             if (lane < k) sv = fma(-Lcol[k], zk, sv);
                         }
-                        if (lane < D) { st_sc1(Dt.dlam + U::bo(0) + lane, mine); L.dl[lane] = mine; dotp = L.res[lane] * mine; }
+                        if (lane < D) {
+                            if (ok) st_sc1(Dt.dlam + U::bo(0) + lane, mine);
+                            if (th == 1 && !is_bottom && ok) st_tag(Sy.dlt + (size_t)(U::bo(0) + lane) * 2, mine, tag_e);
+                            L.dl[lane] = mine; dotp = L.res[lane] * mine;
+                        }
                         lds_fence();
                     }
                 }
-#ifdef TQ_LEVEL_HALT
-                if (threadIdx.x == 0) *L.flag = (int)halted;
-#endif
                 lds_barrier();
-#ifdef TQ_FINE_STAMPS
-                if (is_top && t == 1) pstamp(Dt, O, e, 7, 0, 5);
-#endif
-                pstamp(Dt, O, e, tier, s, sl++);                          /* 4.. : one per backward level */
-#ifdef TQ_LEVEL_HALT
-                if (*L.flag) return;
-#endif
+                if (t == th - 1 && !is_bottom && *L.abort) return;         /* a child never delivered: the launch is over */
+                pstamp(Dt, O, e, tier, s, sl++);                          /* 3.. : one per backward level */
             }
         }
-        if (!is_top) {
-            /* publish my subtree root's Schur record (written by wave 0 with sc1 stores) */
-            drain_stores();
-            __syncthreads();
-            if (threadIdx.x == 0) __hip_atomic_fetch_add(Sy.up_cnt + parent_wg, 1u, RLX, AGENT);
-            /* ---- wait for the parent's forward sweep ---- */
-            if (threadIdx.x == 0) *L.flag = poll_ge(Sy.down + parent_wg, e, Sy) ? 0 : 1;
-            __syncthreads();
-            const int leave = *L.flag;
-            __syncthreads();
-            if (leave) return;
-        }
-        pstamp(Dt, O, e, tier, s, sl++);                                  /* parent forward arrived */
+        pstamp(Dt, O, e, tier, s, sl++);                                  /* backward done */
 
-        /* ---- forward sweep ---- */
+        /* ---- forward sweep (my subtree root first waits for the parent workgroup's step) ---- */
         for (int t = (is_top ? 1 : 0); t < th; t++) {
             const int nb = U::width(t);
             if (wave < nb) {
                 const int ii = U::first(l0 + t) + s * nb + wave, loc = U::first(t) + wave;
-                if (t == 0) dotp += p_forward<NX, NU, MD>(Dt, L, ii, loc, lane, (lds_cptr)L.dl, Dt.dlam + NX * ii);
-                else dotp += p_forward<NX, NU, MD>(Dt, L, ii, loc, lane, (lds_cptr)(L.dl + (U::first(t - 1) + wave / MD) * D + (wave % MD) * NX), nullptr);
+                const bool to_children = !is_bottom && t == th - 1;
+                if (t == 0) dotp += p_forward<NX, NU, MD>(Dt, Sy, L, ii, loc, lane, (lds_cptr)L.dl, true, to_children, tag_e);
+                else dotp += p_forward<NX, NU, MD>(Dt, Sy, L, ii, loc, lane, (lds_cptr)(L.dl + (U::first(t - 1) + wave / MD) * D + (wave % MD) * NX), false, to_children, tag_e);
             }
             lds_barrier();
-        }
-        if (!is_bottom) {
-            drain_stores();                               /* the step of my bottom-level blocks (sc1) has left the wave */
-            __syncthreads();
-            if (threadIdx.x == 0) __hip_atomic_store(Sy.down + wg, e, RLX, AGENT);
+            if (t == 0 && *L.abort) return;                           /* the parent never delivered: the launch is over */
+            if (t == 0) pstamp(Dt, O, e, tier, s, sl++);                  /* parent's step arrived + first level */
         }
         dotp = wsum(dotp);
         if (lane == 0) L.part[4 * wave + 1] = dotp;
-        pstamp(Dt, O, e, tier, s, sl++);                                  /* forward done + published */
+        pstamp(Dt, O, e, tier, s, sl++);                                  /* forward done */
 
         /* ---- first trial (tau = 1) on the nodes this workgroup owns; then straight on to the next
          * iteration at the trial point: the top workgroup checks that it was accepted ---- */
-        const double fsum = p_stage_owned<NX, NU, MD>(Dt, T, L, l0, nown, s, wave, lane, 1.0, cur, lamn, false);
+        const double fsum = p_stage_owned<NX, NU, MD>(Dt, Sy, T, L, l0, nown, s, wave, lane, 1.0, cur, lamn, false, !is_top, Sy.seq | (nd + 1u));
         if (lane == 0) L.part[4 * wave + 2] = fsum;
         __syncthreads();
-        ns += 1u;
-        unposted = true;
+        nd += 1u;
+        if (threadIdx.x == 0) post_parts();
         cur ^= 1;
         pstamp(Dt, O, e, tier, s, sl++);                                  /* stage done */
     }
