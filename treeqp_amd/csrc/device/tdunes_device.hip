@@ -501,7 +501,7 @@ __global__ void __launch_bounds__(256) k_ls_begin(Tree T, Data D, int h) {
 }
 
 /* Armijo test and iteration bookkeeping for the trial whose dual value is f (line_search :973-1000) */
-__device__ void ls_decide_tail(Ctrl *c, const Data &D, const Opts &O, double f) {
+__device__ void ls_decide_tail(Ctrl *c, int *ls_log, int ls_log_cap, const Opts &O, double f) {
     c->cur ^= 1;                       /* the trial point is now the current point */
     c->fval = f;
     int finished = 0, lsIter = c->ls_iter;
@@ -518,12 +518,14 @@ __device__ void ls_decide_tail(Ctrl *c, const Data &D, const Opts &O, double f) 
         c->ls_pending = 0;
         c->ls_last = lsIter;
         c->ls_total += lsIter;
-        if (c->iter < D.ls_log_cap) D.ls_log[c->iter] = lsIter;
+        if (c->iter < ls_log_cap) ls_log[c->iter] = lsIter;
         c->iter += 1;
         c->fval0 = f;                  /* same point, same sweep => identical to a re-evaluation */
         if (c->iter >= O.maxIter) { c->done = 1; c->status = 1; }                      /* MAXIMUM_ITERATIONS */
     }
 }
+
+__device__ void ls_decide_tail(Ctrl *c, const Data &D, const Opts &O, double f) { ls_decide_tail(c, D.ls_log, D.ls_log_cap, O, f); }
 
 /* direction test (:944-954); returns true when the solve must stop with NOT_DESCENT_DIRECTION */
 __device__ bool ls_not_descent(Ctrl *c, double dotp) {
@@ -619,6 +621,9 @@ struct tqgpu_solver {
     double *d_mu_x = nullptr, *d_mu_u = nullptr;
     double *d_lam_init = nullptr;   /* starting point of every solve (tqgpu_set_lambda) */
     unsigned launch_no = 0;         /* persistent launches so far (16 bits, never 0): tags of the hand-over words */
+    void *pconst_slab = nullptr;    /* packed constants of the persistent path + its PDump */
+    double *pab = nullptr, *pcst = nullptr;
+    bool need_pack = true;          /* QP data changed since the constants were packed */
     /* writable aliases of the const inputs */
     double *A = nullptr, *B = nullptr, *b = nullptr, *Qd = nullptr, *Rd = nullptr, *q = nullptr, *r = nullptr;
     double *xmin = nullptr, *xmax = nullptr, *umin = nullptr, *umax = nullptr;
@@ -642,6 +647,7 @@ struct tqgpu_solver {
     bool persist_ok = false;
     PGeom geom{};
     PSync psync{};
+    PConst pconst{};
     void *sync_slab = nullptr;
     size_t sync_words_bytes = 0, lds_persist = 0;
     /* sharded mode */
@@ -1016,6 +1022,20 @@ int setup_persist(tqgpu_solver *s, int device) {
     s->psync.halt = reinterpret_cast<unsigned *>(s->psync.errs + n_errs);
     s->psync.timeout = s->psync.halt + 32;
     s->psync.seq = 0;
+    /* packed constants + the start/end view of the mirror */
+    const int nz = nx0 + s->nu[0];
+    const size_t n_ab = (size_t)(s->Nn - 1) * nx0 * nz, n_cst = (size_t)s->Nn * 16 * 5;
+    HIP_TRY(hipMalloc(&s->pconst_slab, (n_ab + n_cst) * sizeof(double) + sizeof(PDump) + 256));
+    double *pc = static_cast<double *>(s->pconst_slab);
+    s->pab = pc; s->pcst = pc + n_ab;
+    PDump hd;
+    const Data &D = s->D;
+    hd.x = D.x; hd.u = D.u; hd.xUnc = D.xUnc; hd.uUnc = D.uUnc; hd.qmod = D.qmod; hd.rmod = D.rmod; hd.QinvCal = D.QinvCal; hd.RinvCal = D.RinvCal;
+    hd.lam0 = D.lam0; hd.lam1 = D.lam1; hd.dlam = D.dlam; hd.lam_init = s->d_lam_init; hd.stamps = D.stamps; hd.ls_log = D.ls_log; hd.ls_log_cap = D.ls_log_cap;
+    PDump *dd = reinterpret_cast<PDump *>(pc + n_ab + n_cst);
+    HIP_TRY(hipMemcpy(dd, &hd, sizeof(PDump), hipMemcpyHostToDevice));
+    s->pconst.AB = s->pab; s->pconst.b = D.b; s->pconst.cst = s->pcst; s->pconst.ctrl = D.ctrl; s->pconst.dump = dd; s->pconst.Np = s->Np;
+    s->need_pack = true;
     s->persist_ok = true;
     return TQGPU_OK;
 }
@@ -1023,12 +1043,17 @@ int setup_persist(tqgpu_solver *s, int device) {
 /* one persistent launch (prologue = first sweep of the solve + control block reset): no memset, the
  * hand-over words are told apart by the launch number in their tags */
 int launch_persist(tqgpu_solver *s, const Opts &O, int &launches, int prologue) {
-    const Tree &T = s->T; const Data &D = s->D; hipStream_t st = s->stream;
+    const Data &D = s->D; hipStream_t st = s->stream;
     s->launch_no = (s->launch_no + 1) & 0xFFFFu;
     if (s->launch_no == 0) s->launch_no = 1;
     s->psync.seq = s->launch_no << 16;
+    if (s->need_pack) {
+        const int n = std::max(s->Nn * 16, (s->Nn - 1) * s->nx[0] * (s->nx[0] + s->nu[0]));
+        hipLaunchKernelGGL(k_pack_persist, dim3((n + 255) / 256), dim3(256), 0, st, s->Nn, s->Np, s->nx[0], s->nu[0], D, s->pab, s->pcst); launches++;
+        s->need_pack = false;
+    }
     switch (s->fast) {
-#define X(idx, nx, nu, md) case idx: hipLaunchKernelGGL((f_persist<nx, nu, md>), dim3(s->geom.G), dim3(FW * WAVE), s->lds_persist, st, T, D, O, s->geom, s->psync, (const double *)s->d_lam_init, prologue); break;
+#define X(idx, nx, nu, md) case idx: hipLaunchKernelGGL((f_persist<nx, nu, md>), dim3(s->geom.G), dim3(FW * WAVE), s->lds_persist, st, s->pconst, O, s->geom, s->psync, prologue); break;
         FAST_TABLE(X)
 #undef X
         default: break;
@@ -1172,6 +1197,7 @@ extern "C" void tqgpu_destroy(tqgpu_solver *s) {
     if (s->h_ls_log) (void)hipHostFree(s->h_ls_log);
     if (s->shard_slab) (void)hipFree(s->shard_slab);
     if (s->sync_slab) (void)hipFree(s->sync_slab);
+    if (s->pconst_slab) (void)hipFree(s->pconst_slab);
     if (s->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(s->comm);
     if (s->slab) (void)hipFree(s->slab);
     delete s;
@@ -1210,6 +1236,7 @@ extern "C" int tqgpu_set_dynamics(tqgpu_solver *s, const double *A, const double
     H2D(s->A, A, s->sum_A); H2D(s->B, B, s->sum_B);
     H2D(s->b + s->nx0, b, s->sum_lam);              /* node-indexed on the device: root slot unused */
     HIP_TRY(hipStreamSynchronize(s->stream));       /* the caller may reuse its buffers */
+    s->need_pack = true;
     return TQGPU_OK;
 }
 
@@ -1219,6 +1246,7 @@ extern "C" int tqgpu_set_objective_diag(tqgpu_solver *s, const double *Qd, const
     H2D(s->Qd, Qd, s->sum_nx); H2D(s->Rd, Rd, s->sum_nu); H2D(s->q, q, s->sum_nx); H2D(s->r, r, s->sum_nu);
     HIP_TRY(hipStreamSynchronize(s->stream));
     s->need_init = true;
+    s->need_pack = true;
     return TQGPU_OK;
 }
 
@@ -1227,6 +1255,7 @@ extern "C" int tqgpu_set_bounds(tqgpu_solver *s, const double *xmin, const doubl
     HIP_TRY(hipSetDevice(s->device));
     H2D(s->xmin, xmin, s->sum_nx); H2D(s->xmax, xmax, s->sum_nx); H2D(s->umin, umin, s->sum_nu); H2D(s->umax, umax, s->sum_nu);
     HIP_TRY(hipStreamSynchronize(s->stream));
+    s->need_pack = true;
     return TQGPU_OK;
 }
 

@@ -311,7 +311,7 @@ __device__ __forceinline__ void schur_record(int lane, const double (&T)[Uni<NX,
 /* regularised factorisation of the rows in T (treeqp_dpotrf_l_with_reg_opts, dual_Newton_common.c:36-78);
  * ONE copy of the unrolled factorisation in the instruction stream: the on-the-fly retry loops back */
 template <int NX, int NU, int MD>
-__device__ __forceinline__ void factor_rows(const Data &Dt, const Opts &O, int lane, double (&T)[Uni<NX, NU, MD>::D], double &myinv) {
+__device__ __forceinline__ void factor_rows(Ctrl *ctrl, const Opts &O, int lane, double (&T)[Uni<NX, NU, MD>::D], double &myinv) {
     constexpr int D = Uni<NX, NU, MD>::D;
     if (O.regType == 1) {
 #pragma unroll
@@ -325,7 +325,7 @@ __device__ __forceinline__ void factor_rows(const Data &Dt, const Opts &O, int l
         if (O.regType != 2 || !small || pass == 1) break;
 #pragma unroll
         for (int j = 0; j < D; j++) T[j] = (lane == j) ? K[j] + O.regValue : K[j];   /* rare: shift and refactorise */
-        if (lane == 0) atomicAdd(&Dt.ctrl->n_reg, 1);
+        if (lane == 0) atomicAdd(&ctrl->n_reg, 1);
     }
 }
 
@@ -338,7 +338,7 @@ __device__ __forceinline__ void root_block(const Data &Dt, const Opts &O, int la
     constexpr int D = U::D;
     const int bo = U::bo(0);
     double myinv = 0.0;
-    factor_rows<NX, NU, MD>(Dt, O, lane, T, myinv);
+    factor_rows<NX, NU, MD>(Dt.ctrl, O, lane, T, myinv);
     if (lane < D) {
         double *L = Dt.CholW + lane;
 #pragma unroll
@@ -529,7 +529,7 @@ __global__ void __launch_bounds__(FW * WAVE) f_back(Tree T, Data Dt, Opts O, Sha
             if (t < th - 1) sub_children<NX, NU, MD>(L.sch + (U::first(t + 1) + MD * wave) * U::SCH, lane, Tc);     /* children in this tier: LDS */
             else if (l1 < T.Nh) sub_children<NX, NU, MD>((const double *)(Dt.Sbuf + (size_t)U::kid0(ii) * U::SCH), lane, Tc);   /* tier below */
             double myinv = 0.0;
-            factor_rows<NX, NU, MD>(Dt, O, lane, Tc, myinv);
+            factor_rows<NX, NU, MD>(Dt.ctrl, O, lane, Tc, myinv);
             store_factor<NX, NU, MD>(Dt, ii, lane, Tc, myinv);
             if (t > 0) schur_record<NX, NU, MD>(lane, Tc, L.wave, L.sch + loc * U::SCH);
             else schur_record<NX, NU, MD>(lane, Tc, L.wave, Dt.Sbuf + (size_t)ii * U::SCH);
@@ -581,7 +581,7 @@ __global__ void __launch_bounds__(FW * WAVE) f_top(Tree T, Data Dt, Opts O, Shar
             if (t < l1 - 1) sub_children<NX, NU, MD>(L.sch + (U::first(t + 1) + MD * wave) * U::SCH, lane, Tc);
             else if (l1 < T.Nh) sub_children<NX, NU, MD>((const double *)(Dt.Sbuf + (size_t)U::kid0(ii) * U::SCH), lane, Tc);
             double myinv = 0.0;
-            factor_rows<NX, NU, MD>(Dt, O, lane, Tc, myinv);
+            factor_rows<NX, NU, MD>(Dt.ctrl, O, lane, Tc, myinv);
             store_factor<NX, NU, MD>(Dt, ii, lane, Tc, myinv);
             schur_record<NX, NU, MD>(lane, Tc, L.wave, L.sch + ii * U::SCH);
         }

@@ -7,11 +7,13 @@
  * ~2.3 us plus ~2.5 us of cold global loads per boundary, 7 boundaries per iteration.  Here every
  * tier subtree keeps its workgroup for the whole solve:
  *   - grid = one 4-wave workgroup per tier subtree (C2: 64 + 8 + 1 = 73), all co-resident;
- *   - a block's W / L, Ut / CholUt, residual, backward solution and reciprocal diagonal live in
- *     the workgroup's LDS -- and so does everything else a workgroup needs from ITSELF across
- *     iterations: the duals of its blocks, x / u / QinvCal / RinvCal of the nodes it owns, the step
- *     of its blocks.  Global memory carries the results (x, u, multipliers, step) and what crosses
- *     workgroups;
+ *   - the STATE of the solve lives in LDS for the whole launch: a block's W / L, Ut / CholUt,
+ *     residual, backward solution, reciprocal diagonal and step; the duals of the workgroup's blocks
+ *     (double-buffered like lam0 / lam1); x, u, their unclipped values, the modified gradients and the
+ *     clipped inverse Hessians of the nodes the workgroup owns.  It is loaded once (first sweep of a
+ *     solve: from lambda0; relaunch: from global memory) and written back to global memory once,
+ *     when the workgroup leaves.  An iteration reads only constants from global memory (packed per
+ *     edge / per node by k_pack_persist: [A | B], {q, 1/Q, Q, lower, upper});
  *   - what crosses workgroups travels as TAGGED WORDS: a double is written as two 64-bit relaxed
  *     agent-scope atomic stores, each (tag << 32) | 32-bit half, tag = launch number and sequence
  *     number of the hand-over.  The consumer polls the payload itself until every word carries the
@@ -32,7 +34,7 @@
  *     backward sweep of the next iteration at the trial point.  Only the top workgroup (which has
  *     the most slack) takes the decision, before anything irreversible (termination verdict, forward
  *     sweep, next trial); if the trial was NOT accepted it halts the launch and the speculative work
- *     is simply dropped (it only touched LDS and hand-over buffers, which every iteration rebuilds);
+ *     is simply dropped (it only touched per-iteration LDS data and hand-over buffers);
  *   - termination is decided from the errs[] partials as soon as every workgroup has done G + H,
  *     i.e. long before the backward sweep of a converged point would have reached the top;
  *   - the trial stage sweep runs four nodes per wave (16 lanes per node) for the nodes a workgroup owns;
@@ -47,8 +49,25 @@
 
 typedef unsigned long long u64;
 
-__device__ __forceinline__ double ld_sc1(const double *p) { return __hip_atomic_load(p, RLX, AGENT); }
-__device__ __forceinline__ void st_sc1(double *p, double v) { __hip_atomic_store(p, v, RLX, AGENT); }
+/* what only the start and the end of a launch touch; lives in device memory so that the kernel
+ * holds ONE pointer during the loop (scalar register pressure) */
+struct PDump {
+    double *x, *u, *xUnc, *uUnc, *qmod, *rmod, *QinvCal, *RinvCal, *lam0, *lam1, *dlam;
+    const double *lam_init;
+    unsigned long long *stamps;
+    int *ls_log;
+    int ls_log_cap;
+};
+
+/* what the loop touches in global memory besides the hand-over buffers */
+struct PConst {
+    const double *AB;       /* [edges][NX * (NX+NU)]  column-major [A | B] of edge k-1 (k = child node)           */
+    const double *b;        /* [sum_nx]                                                                            */
+    const double *cst;      /* [nodes][16][5]  {linear term, 1/weight, weight, lower, upper} of entry t of node k  */
+    Ctrl *ctrl;
+    const PDump *dump;
+    int Np;                 /* number of parent nodes                                                              */
+};
 
 /* hand-over buffers of the persistent path (zeroed once at creation, never reset) */
 struct PSync {
@@ -83,9 +102,9 @@ __device__ __forceinline__ bool spin_on(const PSync &Sy, u64 t0) {
 template <int NX, int NU, int MD>
 struct PLds {
     using U = Uni<NX, NU, MD>;
-    static constexpr int D = U::D, NBT = U::NBT;
+    static constexpr int D = U::D, NBT = U::NBT, NZ = U::NZ;
     static constexpr int SLOTS = NBT + (MD == 2 ? 8 : MD * MD);      /* nodes a workgroup can own: its blocks' owners + (bottom tier) the leaves */
-    static constexpr int NODE = 2 * (NX + NU);                       /* x, u, QinvCal, RinvCal of one owned node */
+    static constexpr int NODE = 4 * NZ;                              /* per owned node: [x | u], clipped inverse Hessian, unclipped [x | u], modified gradient */
     static constexpr int DOUBLES = NBT * (D * D + NX * D + 4 * D) + NBT * U::SCH + NBT * D + SLOTS * NODE + 2 * NBT * D + 3 * NX + 4 * FW + FW * U::WAVE_LDS + 32;
     /* scratch of the top workgroup's reductions: the Schur record storage, free before the backward sweep */
     static constexpr int RED_CAP = NBT * U::SCH / 2;
@@ -98,27 +117,34 @@ struct PLds {
         flag = (lds_iptr)(wave0 + FW * U::WAVE_LDS); abort = flag + 1;
     }
     /* part[4 w + i]: wave w's partials -- 0 termination norm, 1 res' * dlam, 2 dual function value */
-    /* owned node `q` (heap order inside the tier subtree): x | u | QinvCal | RinvCal */
-    __device__ __forceinline__ lds_ptr nx_(int q) const { return node + q * NODE; }
-    __device__ __forceinline__ lds_ptr nu_(int q) const { return node + q * NODE + NX; }
-    __device__ __forceinline__ lds_ptr nqc(int q) const { return node + q * NODE + NX + NU; }
-    __device__ __forceinline__ lds_ptr nrc(int q) const { return node + q * NODE + 2 * NX + NU; }
+    /* owned node `q` (heap order inside the tier subtree): entry t < NZ of [x | u] at +t, of the clipped
+     * inverse Hessian at NZ + t, of the unclipped value at 2 NZ + t, of the modified gradient at 3 NZ + t */
+    __device__ __forceinline__ lds_ptr node_(int q) const { return node + q * NODE; }
     /* dual vector of block `loc` (= duals of the owner node's children), double-buffered like lam0 / lam1 */
     __device__ __forceinline__ lds_ptr lamb_(int buf, int loc) const { return lamb + (buf * NBT + loc) * D; }
 };
+
+/* heap slot -> node / block index: slot q of the tier subtree s whose first block level is l0 */
+template <int NX, int NU, int MD>
+__device__ __forceinline__ int p_slot_node(int q, int l0, int s) {
+    using U = Uni<NX, NU, MD>;
+    int t = 0;
+    while (q >= U::first(t + 1)) t++;
+    return U::first(l0 + t) + s * U::width(t) + (q - U::first(t));
+}
 
 /* G + H of block p into LDS slot `loc`, split into a branch-free load half and a compute half so
  * that a wave with two blocks has both blocks' loads in flight at once.  The owner node's x, u,
  * QinvCal, RinvCal come from the workgroup's LDS node store (its own stage sweep wrote them); the
  * children's x and QinvCal likewise unless the children belong to the tier below (`foreign`): then
- * they were written by the child workgroups' stage sweeps and are read with sc1 loads. */
+ * they were written by the child workgroups' stage sweeps (tagged words, polled). */
 template <int NX, int NU, int MD>
 struct GhRegs {
     double a[Uni<NX, NU, MD>::KS], pc[Uni<NX, NU, MD>::KS], z[Uni<NX, NU, MD>::KS], xk, bk, qk;
 };
 
 template <int NX, int NU, int MD>
-__device__ __forceinline__ void p_gh_load(const Data &Dt, const PSync &Sy, const PLds<NX, NU, MD> &L, int p, int loc, bool foreign, unsigned ns, int lane, GhRegs<NX, NU, MD> &G) {
+__device__ __forceinline__ void p_gh_load(const PConst &C, const PSync &Sy, const PLds<NX, NU, MD> &L, int p, int loc, bool foreign, unsigned ns, int lane, GhRegs<NX, NU, MD> &G) {
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D, NZ = U::NZ;
     const int row = lane & 15, g = lane >> 4;
@@ -126,18 +152,15 @@ __device__ __forceinline__ void p_gh_load(const Data &Dt, const PSync &Sy, const
     const int rowc = live ? row : 0;                         /* dead rows load row 0 and are masked */
     const int cidx = rowc / NX, r = rowc - cidx * NX;
     const int k = U::kid0(p) + cidx;
-    const double *A = Dt.A + (size_t)(k - 1) * NX * NX + r;
-    const double *B = Dt.B + (size_t)(k - 1) * NX * NU + r;
+    const double *AB = C.AB + (size_t)(k - 1) * NX * NZ + r;
     const int bo = U::bo(p);
-    lds_cptr own = L.nx_(loc);                               /* x | u | QinvCal | RinvCal, NZ apart */
+    lds_cptr own = L.node_(loc);                             /* [x | u] then the clipped inverse Hessian, NZ apart */
 #pragma unroll
     for (int s = 0; s < U::KS; s++) {
         const int cc = g + 4 * s;
-        const bool ok = live && cc < NZ, isx = cc < NX;
-        const int cu = (cc < NZ) ? cc - NX : 0;              /* input column (clamped) */
+        const bool ok = live && cc < NZ;
         const int cz = (cc < NZ) ? cc : 0;
-        const double *ap = isx ? A + (size_t)cc * NX : B + (size_t)cu * NX;
-        const double av = *ap, zv = own[cz], pv = own[NZ + cz];
+        const double av = AB[(size_t)cz * NX], zv = own[cz], pv = own[NZ + cz];
         G.a[s] = ok ? av : 0.0; G.pc[s] = ok ? pv : 0.0; G.z[s] = ok ? zv : 0.0;
     }
     double xv, qv;
@@ -153,9 +176,9 @@ __device__ __forceinline__ void p_gh_load(const Data &Dt, const PSync &Sy, const
             if (ok || !spin_on(Sy, t0)) break;
         }
         if (!ok) *L.abort = 1;
-    } else if (foreign) { xv = Dt.x[bo + rowc]; qv = Dt.QinvCal[bo + rowc]; }       /* relaunch: staged by earlier kernels */
-    else { lds_cptr kid = L.nx_(MD * loc + 1 + cidx); xv = kid[r]; qv = kid[NZ + r]; }
-    const double bv = Dt.b[bo + rowc];
+    } else if (foreign) { const PDump *dp = C.dump; xv = dp->x[bo + rowc]; qv = dp->QinvCal[bo + rowc]; }   /* relaunch: staged by earlier kernels */
+    else { lds_cptr kid = L.node_(MD * loc + 1 + cidx); xv = kid[r]; qv = kid[NZ + r]; }
+    const double bv = C.b[bo + rowc];
     G.xk = (live && g == 0) ? xv : 0.0; G.bk = (live && g == 0) ? bv : 0.0; G.qk = live ? qv : 0.0;
 }
 
@@ -257,12 +280,12 @@ __device__ __forceinline__ void p_schur(PLds<NX, NU, MD> &L, int loc, int lane, 
     }
 }
 
-/* forward step of block `loc` from LDS; writes the solution to LDS (dl) and to global dlam.
+/* forward step of block `loc` from LDS; the solution stays in LDS (dl).
  * from_parent: the block is my subtree root, the step of its owner node's duals comes from the parent
  * workgroup (tagged words, polled).  to_children: the block's children are tier subtree roots of the
  * tier below: they get a tagged copy of the solution. */
 template <int NX, int NU, int MD>
-__device__ __forceinline__ double p_forward(const Data &Dt, const PSync &Sy, PLds<NX, NU, MD> &L, int ii, int loc, int lane, lds_cptr delta_lds,
+__device__ __forceinline__ double p_forward(const PSync &Sy, PLds<NX, NU, MD> &L, int ii, int loc, int lane, lds_cptr delta_lds,
                                             bool from_parent, bool to_children, unsigned tag) {
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D;
@@ -281,8 +304,8 @@ __device__ __forceinline__ double p_forward(const Data &Dt, const PSync &Sy, PLd
             if (ok || !spin_on(Sy, t0)) break;
         }
         ok = __all(ok);
-        if (!ok) *L.abort = 1;                            /* the launch is over: nothing below may reach global memory */
-        if (lane == 0) {                                  /* the subtree root's own step: the stage sweep reads it from LDS */
+        if (!ok) *L.abort = 1;                            /* the launch is over: nothing below may leave the workgroup */
+        if (lane == 0 && ok) {                            /* the subtree root's own step: the stage sweep reads it from LDS */
 #pragma unroll
             for (int r = 0; r < NX; r++) L.droot[r] = dv[r];
         }
@@ -307,9 +330,8 @@ __device__ __forceinline__ double p_forward(const Data &Dt, const PSync &Sy, PLd
     }
     double pd = 0.0;
     if (lane < D) {
-        if (ok) st_sc1(Dt.dlam + U::bo(ii) + lane, mine);
         if (to_children && ok) st_tag(Sy.dlt + (size_t)(U::bo(ii) + lane) * 2, mine, tag);
-        L.dl[loc * D + lane] = mine;
+        if (ok) L.dl[loc * D + lane] = mine;              /* a step computed from a failed poll must not replace the last good one (it is written back on leaving) */
         pd = L.res[loc * D + lane] * mine;
     }
     return pd;                                            /* per-lane term of res' * dlam: summed once per sweep */
@@ -318,26 +340,24 @@ __device__ __forceinline__ double p_forward(const Data &Dt, const PSync &Sy, PLd
 /* stage QP of owned node slot q (= node k) at the trial point lam_cur + step*dlam, by ONE 16-lane
  * group (lanes t of the group: t < NX state entries, NX <= t < NX+NU input entries).  Duals and steps
  * come from the workgroup's LDS copies (lamb / lamroot, dl / droot; `cb` = current buffer), constants
- * from global memory; results go to global memory (nobody waits for them) AND to the LDS node store /
- * the other dual buffer for this workgroup's next G + H; the subtree root's x and QinvCal also go to
- * the parent workgroup as tagged words (to_parent).
+ * from global memory (packed); results go to the LDS node store and the other dual buffer; the
+ * subtree root's x and QinvCal also go to the parent workgroup as tagged words (to_parent).
  * init: first sweep of a solve -- evaluate at the current duals themselves.
  * Returns the node's dual-function term (valid in every lane of the group). */
 template <int NX, int NU, int MD>
-__device__ __forceinline__ double p_stage16(const Data &Dt, const PSync &Sy, PLds<NX, NU, MD> &L, int q, int k, int Np, int t, lds_ptr gl /* group scratch: D + NX */,
-                                            double step, int cb, double *lamn, bool active, bool init, bool to_parent, unsigned tag) {
+__device__ __forceinline__ double p_stage16(const PConst &C, const PSync &Sy, PLds<NX, NU, MD> &L, int q, int k, int t, lds_ptr gl /* group scratch: D + NX */,
+                                            double step, int cb, bool active, bool init, bool to_parent, unsigned tag) {
     using U = Uni<NX, NU, MD>;
-    constexpr int D = U::D, NBT = U::NBT;
+    constexpr int D = U::D, NZ = U::NZ;
     static_assert(NX + NU <= 16 && D <= 16, "16-lane stage needs nx+nu <= 16 and d <= 16");
-    const bool parent = active && k < Np;
+    const bool parent = active && k < C.Np;
     const int nuk = parent ? NU : 0;
-    const int xo = NX * k, uo = NU * k, ko = U::bo(k);
+    const int ko = U::bo(k);
     const bool isx = t < NX, live = active && t < NX + nuk;
-    const int j = isx ? t : t - NX;
     /* branch-free loads: every lane reads from a valid (clamped) address and masks afterwards */
     const bool pk = parent && t < D, ox = active && isx && k > 0;
     const int qb = pk ? q : 0, tb = pk ? t : 0;                       /* my block's duals / step */
-    const double lca = L.lamb_(cb, qb)[tb], dla = L.dl[qb * D + tb], ba = Dt.b[pk ? ko + t : 0];
+    const double lca = L.lamb_(cb, qb)[tb], dla = L.dl[qb * D + tb], ba = C.b[pk ? ko + t : 0];
     const int qp = (ox && q > 0) ? (q - 1) / MD : 0, tp = (ox && q > 0) ? ((q - 1) % MD) * NX + t : 0;   /* my own slice in the parent's block */
     const int tr = ox ? t : 0;
     const double lcb = (q > 0) ? L.lamb_(cb, qp)[tp] : L.lamroot[cb * NX + tr];
@@ -347,27 +367,24 @@ __device__ __forceinline__ double p_stage16(const Data &Dt, const PSync &Sy, PLd
 #pragma unroll
     for (int cc = 0; cc < MD; cc++) {
         const int kid = pl ? U::kid0(k) + cc : 1;
-        const double *cp = (isx || !pl) ? Dt.A + (size_t)(kid - 1) * NX * NX + (size_t)(pl ? j : 0) * NX
-                                        : Dt.B + (size_t)(kid - 1) * NX * NU + (size_t)j * NX;
+        const double *cp = C.AB + (size_t)(kid - 1) * NX * NZ + (size_t)(pl ? t : 0) * NX;      /* column t of [A | B] */
 #pragma unroll
         for (int i = 0; i < NX; i++) col[cc][i] = cp[i];
     }
-    const bool lx = isx || !live;
-    const int jo = live ? (isx ? xo + j : uo + j) : 0;
-    double lin = (lx ? Dt.q : Dt.r)[jo], winv = (lx ? Dt.Qinv : Dt.Rinv)[jo], wd = (lx ? Dt.Qd : Dt.Rd)[jo];
-    double lob = (lx ? Dt.xmin : Dt.umin)[jo], hib = (lx ? Dt.xmax : Dt.umax)[jo];
+    const double *cs = C.cst + ((size_t)(active ? k : 0) * 16 + t) * 5;
+    const double lin = cs[0], winv = cs[1], wd = cs[2], lob = cs[3], hib = cs[4];
     double p_c = 0.0;
     {
         const double v = init ? lca : fma(step, dla, lca);
         if (pk) { gl[t] = v; p_c = ba * v; if (!init) L.lamb_(cb ^ 1, q)[t] = v; }
         const double w = ox ? (init ? lcb : fma(step, dlb, lcb)) : 0.0;
-        if (ox) { st_sc1(lamn + xo + t, w); if (q == 0 && !init) L.lamroot[(cb ^ 1) * NX + t] = w; }
+        if (ox && q == 0 && !init) L.lamroot[(cb ^ 1) * NX + t] = w;
         if (active && isx) gl[D + t] = w;
     }
     lds_fence();
     double p_q = 0.0, p_h = 0.0;
     if (live) {
-        double v = isx ? fma(-1.0, lin, gl[D + j]) : -1.0 * lin;
+        double v = isx ? fma(-1.0, lin, gl[D + t]) : -1.0 * lin;
         if (parent) {
 #pragma unroll
             for (int cc = 0; cc < MD; cc++) {
@@ -380,12 +397,10 @@ __device__ __forceinline__ double p_stage16(const Data &Dt, const PSync &Sy, PLd
         const double unc = winv * v;
         double val, cal;
         if (unc >= hib) { val = hib; cal = 0.0; } else if (unc <= lob) { val = lob; cal = 0.0; } else { val = unc; cal = winv; }
-        if (isx) { st_sc1(Dt.qmod + xo + j, v); st_sc1(Dt.xUnc + xo + j, unc); st_sc1(Dt.x + xo + j, val); st_sc1(Dt.QinvCal + xo + j, cal); }
-        else { st_sc1(Dt.rmod + uo + j, v); st_sc1(Dt.uUnc + uo + j, unc); st_sc1(Dt.u + uo + j, val); st_sc1(Dt.RinvCal + uo + j, cal); }
-        lds_ptr ns = L.nx_(q);                            /* x | u | QinvCal | RinvCal: entry t, NX+NU apart */
-        ns[t] = val; ns[NX + NU + t] = cal;
+        lds_ptr ns = L.node_(q);
+        ns[t] = val; ns[NZ + t] = cal; ns[2 * NZ + t] = unc; ns[3 * NZ + t] = v;
         if (to_parent && q == 0 && isx) {                 /* my subtree root: the parent workgroup's G + H reads x and QinvCal */
-            u64 *dst = Sy.ndt + ((size_t)k * 2 * NX + j) * 2;
+            u64 *dst = Sy.ndt + ((size_t)k * 2 * NX + t) * 2;
             st_tag(dst, val, tag); st_tag(dst + 2 * NX, cal, tag);
         }
         p_q = (wd * val) * val;
@@ -398,7 +413,6 @@ __device__ __forceinline__ double p_stage16(const Data &Dt, const PSync &Sy, PLd
     f += hx;
     f -= 0.5 * ru;
     f += hu;
-    if (active && t == 0) st_sc1(Dt.fval + k, f);
     lds_fence();
     return active ? f : 0.0;
 }
@@ -416,20 +430,12 @@ struct PGeom {
 };
 
 /* diagnostic stamps of the persistent kernel: first workgroup of every tier, thread 0, iteration O.stamps of the launch */
-__device__ __forceinline__ void pstamp(const Data &Dt, const Opts &O, unsigned e, int tier, int s, int slot) {
+__device__ __forceinline__ void pstamp(const PConst &C, const Opts &O, unsigned e, int tier, int s, int slot) {
     if (O.stamps == (int)e && threadIdx.x == 0 && s == 0 && slot < 32 && tier < 8) {
-        Dt.stamps[(tier * 32 + slot) * 2 + 0] = clock64();
-        Dt.stamps[(tier * 32 + slot) * 2 + 1] = wall_clock64();
+        unsigned long long *st = C.dump->stamps;
+        st[(tier * 32 + slot) * 2 + 0] = clock64();
+        st[(tier * 32 + slot) * 2 + 1] = wall_clock64();
     }
-}
-
-/* heap slot -> node / block index: slot q of the tier subtree s whose block levels are [l0, l1) */
-template <int NX, int NU, int MD>
-__device__ __forceinline__ int p_slot_node(int q, int l0, int s) {
-    using U = Uni<NX, NU, MD>;
-    int t = 0;
-    while (q >= U::first(t + 1)) t++;
-    return U::first(l0 + t) + s * U::width(t) + (q - U::first(t));
 }
 
 /* subtract the Schur records of the children in the tier below: tagged words written by the child
@@ -468,8 +474,8 @@ __device__ __forceinline__ bool p_sub_children_tagged(const PSync &Sy, const u64
 /* stage sweep over the nodes this workgroup owns (the owner nodes of its blocks in heap order, then --
  * bottom tier -- the leaves below), four nodes per wave; returns the wave's sum of the node terms */
 template <int NX, int NU, int MD>
-__device__ __forceinline__ double p_stage_owned(const Data &Dt, const PSync &Sy, const Tree &T, PLds<NX, NU, MD> &L, int l0, int nown, int s, int wave, int lane,
-                                                double step, int cb, double *lamn, bool init, bool to_parent, unsigned tag) {
+__device__ __forceinline__ double p_stage_owned(const PConst &C, const PSync &Sy, PLds<NX, NU, MD> &L, int l0, int nown, int s, int wave, int lane,
+                                                double step, int cb, bool init, bool to_parent, unsigned tag) {
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D;
     const int grp = lane >> 4, t16 = lane & 15;
@@ -479,7 +485,7 @@ __device__ __forceinline__ double p_stage_owned(const Data &Dt, const PSync &Sy,
         const int q = base + wave * 4 + grp;
         const bool active = q < nown;
         const int k = active ? p_slot_node<NX, NU, MD>(q, l0, s) : 0;
-        fsum += p_stage16<NX, NU, MD>(Dt, Sy, L, active ? q : 0, k, T.Np, t16, gl, step, cb, lamn, active, init, to_parent, tag);
+        fsum += p_stage16<NX, NU, MD>(C, Sy, L, active ? q : 0, k, t16, gl, step, cb, active, init, to_parent, tag);
     }
     return rows_fold<false>(fsum);       /* every lane of a 16-lane group holds its group's sum */
 }
@@ -520,11 +526,11 @@ __device__ __forceinline__ bool p_gather3(const PSync &Sy, PLds<NX, NU, MD> &L, 
 }
 
 template <int NX, int NU, int MD>
-__global__ void __launch_bounds__(FW * WAVE) f_persist(Tree T, Data Dt, Opts O, PGeom Gm, PSync Sy, const double *lam_init, int prologue) {
+__global__ void __launch_bounds__(FW * WAVE) f_persist(PConst C, Opts O, PGeom Gm, PSync Sy, int prologue) {
     using U = Uni<NX, NU, MD>;
-    constexpr int D = U::D;
+    constexpr int D = U::D, NZ = U::NZ;
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
-    Ctrl *c = Dt.ctrl;
+    Ctrl *c = C.ctrl;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     PLds<NX, NU, MD> L(lds_all, wave);
     const int wg = blockIdx.x;
@@ -532,12 +538,14 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(Tree T, Data Dt, Opts O, 
     int tier = 0;
     for (int i = 0; i < Gm.n_tiers; i++) if (wg >= Gm.wg0[i]) tier = i;
     const int s = wg - Gm.wg0[tier];
-    const int l0 = Gm.l0[tier], l1 = Gm.l1[tier], th = l1 - l0;
+    const int l0 = Gm.l0[tier], th = Gm.l1[tier] - l0;
     const bool is_top = tier == Gm.n_tiers - 1, is_bottom = tier == 0;
     const int nbt = U::first(th);                                      /* my blocks */
     const int nown = nbt + (is_bottom ? U::width(th) : 0);             /* nodes I own */
     const int root_blk = U::first(l0) + s;                             /* subtree root block (= node) */
     int cur = 0;
+    unsigned nd = 0u;          /* stage sweeps (= {fval, dot} reductions) of this launch so far */
+    bool have_dl = false;      /* a forward sweep of this launch has filled the step of my blocks */
     if (prologue) {
         /* a fresh solve: the control block starts from zero (nobody else reads it during the launch) */
         if (is_top && threadIdx.x == 0) {
@@ -548,12 +556,12 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(Tree T, Data Dt, Opts O, 
         if (__hip_atomic_load(&c->done, RLX, AGENT) || __hip_atomic_load(&c->ls_pending, RLX, AGENT)) return;
         cur = __hip_atomic_load(&c->cur, RLX, AGENT);
     }
-    unsigned nd = 0u;          /* {fval, dot} reductions handed in so far (= stage sweeps of this launch) */
 
-    /* ---- LDS copies of what this workgroup owns: duals of my blocks and of my root, node store ---- */
+    /* ---- load the state this workgroup owns: duals of my blocks and of my root, node store ---- */
     {
+        const PDump *dp = C.dump;
         if (threadIdx.x == 0) *L.abort = 0;
-        const double *lsrc = prologue ? lam_init : (cur ? Dt.lam1 : Dt.lam0);
+        const double *lsrc = prologue ? dp->lam_init : (cur ? dp->lam1 : dp->lam0);
         for (int i = threadIdx.x; i < nbt * D; i += FW * WAVE) {
             const int loc = i / D, t = i - loc * D;
             L.lamb_(cur, loc)[t] = lsrc[U::bo(p_slot_node<NX, NU, MD>(loc, l0, s)) + t];
@@ -563,8 +571,9 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(Tree T, Data Dt, Opts O, 
             for (int i = threadIdx.x; i < nown * 16; i += FW * WAVE) {
                 const int q = i >> 4, t = i & 15;
                 const int k = p_slot_node<NX, NU, MD>(q, l0, s);
-                if (t < NX) { L.nx_(q)[t] = Dt.x[NX * k + t]; L.nqc(q)[t] = Dt.QinvCal[NX * k + t]; }
-                else if (t < NX + NU && k < T.Np) { L.nu_(q)[t - NX] = Dt.u[NU * k + t - NX]; L.nrc(q)[t - NX] = Dt.RinvCal[NU * k + t - NX]; }
+                lds_ptr ns = L.node_(q);
+                if (t < NX) { ns[t] = dp->x[NX * k + t]; ns[NZ + t] = dp->QinvCal[NX * k + t]; }
+                else if (t < NZ && k < C.Np) { ns[t] = dp->u[NU * k + t - NX]; ns[NZ + t] = dp->RinvCal[NU * k + t - NX]; }
             }
         }
         __syncthreads();
@@ -579,9 +588,8 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(Tree T, Data Dt, Opts O, 
     };
 
     if (prologue) {
-        /* ---- first sweep of the solve: stage QPs at lambda0 (copied into the current buffer), fval0 ---- */
-        double *lam0 = cur ? Dt.lam1 : Dt.lam0;
-        const double fsum = p_stage_owned<NX, NU, MD>(Dt, Sy, T, L, l0, nown, s, wave, lane, 0.0, cur, lam0, true, !is_top, Sy.seq | 1u);
+        /* ---- first sweep of the solve: stage QPs at lambda0, fval0 ---- */
+        const double fsum = p_stage_owned<NX, NU, MD>(C, Sy, L, l0, nown, s, wave, lane, 0.0, cur, true, !is_top, Sy.seq | 1u);
         if (lane == 0) { L.part[4 * wave + 2] = fsum; L.part[4 * wave + 1] = 0.0; }
         __syncthreads();
         nd = 1u;
@@ -590,10 +598,9 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(Tree T, Data Dt, Opts O, 
 
     for (unsigned e = 1u;; e++) {
         const unsigned tag_e = Sy.seq | e;
-        double *lamn = cur ? Dt.lam0 : Dt.lam1;
 
         int sl = 0;
-        pstamp(Dt, O, e, tier, s, sl++);                                  /* 0: iteration start */
+        pstamp(C, O, e, tier, s, sl++);                                   /* 0: iteration start */
         /* ---- G + H for my blocks (heap order inside the subtree), two blocks per wave in flight; the
          * children of my bottom-level blocks were staged by the child workgroups (polled) ---- */
         {
@@ -602,8 +609,8 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(Tree T, Data Dt, Opts O, 
             for (int loc0 = wave; loc0 < nbt; loc0 += 2 * FW) {
                 const int loc1 = loc0 + FW;
                 GhRegs<NX, NU, MD> g0, g1;
-                p_gh_load<NX, NU, MD>(Dt, Sy, L, p_slot_node<NX, NU, MD>(loc0, l0, s), loc0, !is_bottom && loc0 >= nint, nd, lane, g0);
-                if (loc1 < nbt) p_gh_load<NX, NU, MD>(Dt, Sy, L, p_slot_node<NX, NU, MD>(loc1, l0, s), loc1, !is_bottom && loc1 >= nint, nd, lane, g1);
+                p_gh_load<NX, NU, MD>(C, Sy, L, p_slot_node<NX, NU, MD>(loc0, l0, s), loc0, !is_bottom && loc0 >= nint, nd, lane, g0);
+                if (loc1 < nbt) p_gh_load<NX, NU, MD>(C, Sy, L, p_slot_node<NX, NU, MD>(loc1, l0, s), loc1, !is_bottom && loc1 >= nint, nd, lane, g1);
                 double v = p_gh_compute<NX, NU, MD>(L, loc0, lane, g0, O.termCondition);
                 err = (O.termCondition == 2) ? fmax(err, v) : err + v;
                 if (loc1 < nbt) {
@@ -613,7 +620,7 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(Tree T, Data Dt, Opts O, 
             }
             if (lane == 0) L.part[4 * wave] = err;
             __syncthreads();
-            if (!is_bottom && *L.abort) return;
+            if (!is_bottom && *L.abort) break;
             if (threadIdx.x == 0) {
                 /* termination partial of my blocks to the top workgroup */
                 err = 0.0;
@@ -621,7 +628,7 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(Tree T, Data Dt, Opts O, 
                 st_tag(Sy.errs + (size_t)wg * 2, err, tag_e);
             }
         }
-        pstamp(Dt, O, e, tier, s, sl++);                                  /* 1: G+H done */
+        pstamp(C, O, e, tier, s, sl++);                                   /* 1: G+H done */
 
         if (is_top) {
             /* ---- verdicts: the outstanding {fval, dot} reduction (fval0 of the first sweep, or the first
@@ -637,7 +644,8 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(Tree T, Data Dt, Opts O, 
                             c->tau = 1.0; c->tauPrev = 0.0; c->ls_iter = 1; c->ls_pending = 1;
                             if (ls_not_descent(c, -da)) code = 1;
                             else {
-                                ls_decide_tail(c, Dt, O, fa);
+                                const PDump *dp = C.dump;
+                                ls_decide_tail(c, dp->ls_log, dp->ls_log_cap, O, fa);
                                 code = (c->done || c->ls_pending) ? 1 : 0;      /* finished, or more trials: the host takes over */
                             }
                         }
@@ -656,12 +664,13 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(Tree T, Data Dt, Opts O, 
             }
             if (leave) {
                 if (threadIdx.x == 0) __hip_atomic_store(Sy.halt, Sy.seq, RLX, AGENT);
-                return;
+                break;
             }
         }
-        pstamp(Dt, O, e, tier, s, sl++);                                  /* 2: verdicts (top) */
+        pstamp(C, O, e, tier, s, sl++);                                   /* 2: verdicts (top) */
 
         /* ---- backward sweep ---- */
+        bool gone = false;
         double dotp = 0.0;                                /* per-lane terms of res' * dlam over my blocks */
         {
             double Tc[D];
@@ -679,7 +688,7 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(Tree T, Data Dt, Opts O, 
                         if (!ok && lane == 0) *L.abort = 1;
                     }
                     double myinv = 0.0;
-                    factor_rows<NX, NU, MD>(Dt, O, lane, Tc, myinv);
+                    factor_rows<NX, NU, MD>(c, O, lane, Tc, myinv);
                     if (!is_root) {
                         p_store_factor<NX, NU, MD>(L, loc, lane, Tc, myinv);
                         if (t == 0) { if (ok) p_schur<NX, NU, MD, true>(L, loc, lane, L.sch, Sy.sch + (size_t)ii * U::SCH * 2, tag_e); }
@@ -703,7 +712,6 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(Tree T, Data Dt, Opts O, 
                             if (lane < k) sv = fma(-Lcol[k], zk, sv);
                         }
                         if (lane < D) {
-                            if (ok) st_sc1(Dt.dlam + U::bo(0) + lane, mine);
                             if (th == 1 && !is_bottom && ok) st_tag(Sy.dlt + (size_t)(U::bo(0) + lane) * 2, mine, tag_e);
                             L.dl[lane] = mine; dotp = L.res[lane] * mine;
                         }
@@ -711,11 +719,12 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(Tree T, Data Dt, Opts O, 
                     }
                 }
                 lds_barrier();
-                if (t == th - 1 && !is_bottom && *L.abort) return;         /* a child never delivered: the launch is over */
-                pstamp(Dt, O, e, tier, s, sl++);                          /* 3.. : one per backward level */
+                if (t == th - 1 && !is_bottom && *L.abort) { gone = true; break; }    /* a child never delivered: the launch is over */
+                pstamp(C, O, e, tier, s, sl++);                           /* 3.. : one per backward level */
             }
         }
-        pstamp(Dt, O, e, tier, s, sl++);                                  /* backward done */
+        if (gone) break;
+        pstamp(C, O, e, tier, s, sl++);                                   /* backward done */
 
         /* ---- forward sweep (my subtree root first waits for the parent workgroup's step) ---- */
         for (int t = (is_top ? 1 : 0); t < th; t++) {
@@ -723,25 +732,79 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(Tree T, Data Dt, Opts O, 
             if (wave < nb) {
                 const int ii = U::first(l0 + t) + s * nb + wave, loc = U::first(t) + wave;
                 const bool to_children = !is_bottom && t == th - 1;
-                if (t == 0) dotp += p_forward<NX, NU, MD>(Dt, Sy, L, ii, loc, lane, (lds_cptr)L.dl, true, to_children, tag_e);
-                else dotp += p_forward<NX, NU, MD>(Dt, Sy, L, ii, loc, lane, (lds_cptr)(L.dl + (U::first(t - 1) + wave / MD) * D + (wave % MD) * NX), false, to_children, tag_e);
+                if (t == 0) dotp += p_forward<NX, NU, MD>(Sy, L, ii, loc, lane, (lds_cptr)L.dl, true, to_children, tag_e);
+                else dotp += p_forward<NX, NU, MD>(Sy, L, ii, loc, lane, (lds_cptr)(L.dl + (U::first(t - 1) + wave / MD) * D + (wave % MD) * NX), false, to_children, tag_e);
             }
             lds_barrier();
-            if (t == 0 && *L.abort) return;                           /* the parent never delivered: the launch is over */
-            if (t == 0) pstamp(Dt, O, e, tier, s, sl++);                  /* parent's step arrived + first level */
+            if (t == 0 && *L.abort) { gone = true; break; }            /* the parent never delivered: the launch is over */
+            if (t == 0) pstamp(C, O, e, tier, s, sl++);                   /* parent's step arrived + first level */
         }
+        if (gone) break;
+        have_dl = true;
         dotp = wsum(dotp);
         if (lane == 0) L.part[4 * wave + 1] = dotp;
-        pstamp(Dt, O, e, tier, s, sl++);                                  /* forward done */
+        pstamp(C, O, e, tier, s, sl++);                                   /* forward done */
 
         /* ---- first trial (tau = 1) on the nodes this workgroup owns; then straight on to the next
          * iteration at the trial point: the top workgroup checks that it was accepted ---- */
-        const double fsum = p_stage_owned<NX, NU, MD>(Dt, Sy, T, L, l0, nown, s, wave, lane, 1.0, cur, lamn, false, !is_top, Sy.seq | (nd + 1u));
+        const double fsum = p_stage_owned<NX, NU, MD>(C, Sy, L, l0, nown, s, wave, lane, 1.0, cur, false, !is_top, Sy.seq | (nd + 1u));
         if (lane == 0) L.part[4 * wave + 2] = fsum;
         __syncthreads();
         nd += 1u;
         if (threadIdx.x == 0) post_parts();
         cur ^= 1;
-        pstamp(Dt, O, e, tier, s, sl++);                                  /* stage done */
+        pstamp(C, O, e, tier, s, sl++);                                   /* stage done */
+    }
+
+    /* ---- leaving: the state goes back to global memory.  When the top workgroup halts, every
+     * workgroup has finished the same number of stage sweeps and none has started the next forward
+     * sweep, so what LDS holds is the point the control block describes. ---- */
+    __syncthreads();
+    {
+        const PDump *dp = C.dump;
+        if (nd > 0u) {
+            for (int i = threadIdx.x; i < nown * 16; i += FW * WAVE) {
+                const int q = i >> 4, t = i & 15;
+                const int k = p_slot_node<NX, NU, MD>(q, l0, s);
+                lds_cptr ns = L.node_(q);
+                if (t < NX) {
+                    const int o = NX * k + t;
+                    dp->x[o] = ns[t]; dp->QinvCal[o] = ns[NZ + t]; dp->xUnc[o] = ns[2 * NZ + t]; dp->qmod[o] = ns[3 * NZ + t];
+                } else if (t < NZ && k < C.Np) {
+                    const int o = NU * k + t - NX;
+                    dp->u[o] = ns[t]; dp->RinvCal[o] = ns[NZ + t]; dp->uUnc[o] = ns[2 * NZ + t]; dp->rmod[o] = ns[3 * NZ + t];
+                }
+            }
+            double *ldst = cur ? dp->lam1 : dp->lam0;
+            for (int i = threadIdx.x; i < nbt * D; i += FW * WAVE) {
+                const int loc = i / D, t = i - loc * D;
+                ldst[U::bo(p_slot_node<NX, NU, MD>(loc, l0, s)) + t] = L.lamb_(cur, loc)[t];
+            }
+        }
+        if (have_dl) {
+            for (int i = threadIdx.x; i < nbt * D; i += FW * WAVE) {
+                const int loc = i / D, t = i - loc * D;
+                dp->dlam[U::bo(p_slot_node<NX, NU, MD>(loc, l0, s)) + t] = L.dl[loc * D + t];
+            }
+        }
+    }
+}
+
+/* packed constants of the persistent path (run whenever the QP data changed): [A | B] per edge and
+ * {linear term, 1/weight, weight, lower, upper} per node entry */
+__global__ void k_pack_persist(int Nn, int Np, int NX, int NU, Data D, double *AB, double *cst) {
+    const int NZ = NX + NU;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid < Nn * 16) {
+        const int k = tid >> 4, t = tid & 15;
+        double *o = cst + (size_t)tid * 5;
+        if (t < NX) { const int i = NX * k + t; o[0] = D.q[i]; o[1] = 1.0 / D.Qd[i]; o[2] = D.Qd[i]; o[3] = D.xmin[i]; o[4] = D.xmax[i]; }
+        else if (t < NZ && k < Np) { const int i = NU * k + t - NX; o[0] = D.r[i]; o[1] = 1.0 / D.Rd[i]; o[2] = D.Rd[i]; o[3] = D.umin[i]; o[4] = D.umax[i]; }
+        else { o[0] = 0.0; o[1] = 0.0; o[2] = 0.0; o[3] = 0.0; o[4] = 0.0; }
+    }
+    const int ne = (Nn - 1) * NX * NZ;
+    for (int i = tid; i < ne; i += gridDim.x * blockDim.x) {
+        const int edge = i / (NX * NZ), w = i - edge * NX * NZ, col = w / NX, r = w - col * NX;
+        AB[i] = col < NX ? D.A[(size_t)edge * NX * NX + (size_t)col * NX + r] : D.B[(size_t)edge * NX * NU + (size_t)(col - NX) * NX + r];
     }
 }
