@@ -15,7 +15,7 @@ For N > 1 it is launched under torch.distributed.run (one rank per GPU, RCCL).
               iteration (strong scaling, latency-bound by construction).
 * roofline  = algorithmic bytes of the Newton iterations (closed form of SURVEY.md §8d, evaluated
               by tqgpu_iteration_cost) / device time between HIP events recorded on the solver's own
-              stream around the iteration kernels, against the 8 TB/s HBM3E peak.
+              stream around each solve (tqgpu_get_device_times), against the 8 TB/s HBM3E peak.
 * cpu_baseline = the CPU oracle ("port": restatement of the reference algorithm, NOT BLASFEO
               HIGH_PERFORMANCE) on the same workload, min over repetitions, rank 0 at N=1 only.
 """
@@ -130,12 +130,17 @@ def main():
     iters = 0
     ls = 0
     launches = 0
+    pending = 0
     for _ in range(args.steps):
-        r = g.solve()               # blocking: returns after the last kernel + status read-back
-        dev_time += r["device_time"]
+        r = g.solve()               # returns when the verdict (status, iteration count) is on the host
         iters += r["iter"]
         ls += r["ls_total"]
         launches += r["n_launches"]
+        pending += 1
+        if pending == 256:          # HIP-event times of the solves, fetched in batches (each fetch synchronises the stream)
+            dev_time += float(g.device_times(pending).sum())
+            pending = 0
+    dev_time += float(g.device_times(pending).sum()) if pending else 0.0      # synchronises: all K solves are complete
     barrier()
     elapsed = time.perf_counter() - t0
     if r["status"] != 0:
@@ -188,7 +193,7 @@ def main():
                                        "1 tree per GPU (independent scenario trees), no collective") if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "one Newton iteration = f_back x tiers, f_top, f_fwd x tiers, f_stage, k_ls_decide (fused path)" if g.fused else
+                         "kernel": ("f_persist: the whole solve in one launch (first sweep + all Newton iterations)" if g.path == 2 else "one Newton iteration = f_back x tiers, f_top, f_fwd x tiers, f_stage, k_ls_decide (tiered path)") if g.fused else
                                    "one Newton iteration = k_grad,k_check,k_hess,k_factor x levels,k_forward x levels,k_ls_*,k_stage (generic path)",
                          "traffic_note": "HBM-side bytes per Newton iteration (FETCH_SIZE raw + WRITE_SIZE) from profiles/traffic_<workload>.json",
                          "algorithmic_bytes_per_iteration": bytes_it, "algorithmic_flops_per_iteration": flops_it,

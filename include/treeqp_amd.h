@@ -111,6 +111,13 @@ int tqgpu_shard_gather_solution(tqgpu_solver *s);
 /* test / diagnostic: n virtual ranks of one tree in one process on one device, lock-step */
 int tqgpu_solve_virtual_ranks(tqgpu_solver **ranks, int n, const tqgpu_opts *opts, tqgpu_result *res);
 
+/* Device times [s] of the last n solves (oldest first), measured with HIP events on the solver's
+ * stream around everything a solve enqueues; synchronises the stream; returns the number written
+ * (at most 512 solves back) or -1.  tqgpu_result.device_time of a single-launch (persistent) solve is
+ * the kernel's own clock from launch start to verdict instead, so that tqgpu_solve can return as soon
+ * as the verdict is in pinned host memory. */
+int tqgpu_get_device_times(tqgpu_solver *s, double *out, int n);
+
 /* diagnostic in-kernel time stamps of the last fused iteration (TREEQP_AMD_STAMPS=1) */
 int tqgpu_get_stamps(tqgpu_solver *s, unsigned long long *out, int cap);
 

@@ -33,7 +33,7 @@ for kern in range(8):
     if n < 2:
         continue
     if kern == 7:
-        print('fine stamps (cycles) load_rows / sub_children / factor / store_block:', [int(v) for v in np.diff(s[:6, 0])])
+        print('fine stamps (cycles) load_rows / sub_children / factor / store_factor / schur:', [int(v) for v in np.diff(s[:6, 0])])
         continue
     cyc = np.diff(s[:n, 0])
     wall = np.diff(s[:n, 1]) * 10.0          # 100 MHz -> ns

@@ -435,6 +435,14 @@ class TqGpu:
     def fused(self) -> bool:
         return bool(lib().tqgpu_uses_fused_path(self.h))
 
+    def device_times(self, n: int) -> np.ndarray:
+        """HIP-event device times [s] of the last n solves (oldest first); synchronises the stream."""
+        out = np.zeros(int(n), dtype=np.float64)
+        got = lib().tqgpu_get_device_times(self.h, _dp(out), int(n))
+        if got < 0:
+            raise RuntimeError("tqgpu_get_device_times failed")
+        return out[:got]
+
     @property
     def path(self) -> int:
         """0 generic per-level kernels, 1 tiered fused kernels, 2 persistent single launch."""

@@ -31,6 +31,8 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -627,7 +629,10 @@ struct tqgpu_solver {
     /* writable aliases of the const inputs */
     double *A = nullptr, *B = nullptr, *b = nullptr, *Qd = nullptr, *Rd = nullptr, *q = nullptr, *r = nullptr;
     double *xmin = nullptr, *xmax = nullptr, *umin = nullptr, *umax = nullptr;
-    Ctrl *h_ctrl = nullptr;      /* pinned */
+    HostRes *h_res = nullptr;    /* pinned; the persistent kernel writes it directly */
+    Ctrl *h_ctrl = nullptr;      /* = &h_res->c */
+    std::vector<hipEvent_t> ring_ev0, ring_ev1;   /* events of the last solves (device times on request) */
+    long solve_no = 0;
     int *h_ls_log = nullptr;     /* pinned */
     int ls_log_cap = 0;
     hipStream_t stream = nullptr;
@@ -671,6 +676,8 @@ extern "C" int tqgpu_device_count(void) {
 }
 
 namespace {
+
+constexpr int EV_RING = 512;     /* solves whose device times can still be asked for */
 
 struct Carver {
     size_t off = 0;
@@ -1032,6 +1039,7 @@ int setup_persist(tqgpu_solver *s, int device) {
     const Data &D = s->D;
     hd.x = D.x; hd.u = D.u; hd.xUnc = D.xUnc; hd.uUnc = D.uUnc; hd.qmod = D.qmod; hd.rmod = D.rmod; hd.QinvCal = D.QinvCal; hd.RinvCal = D.RinvCal;
     hd.lam0 = D.lam0; hd.lam1 = D.lam1; hd.dlam = D.dlam; hd.lam_init = s->d_lam_init; hd.stamps = D.stamps; hd.ls_log = D.ls_log; hd.ls_log_cap = D.ls_log_cap;
+    hd.hres = s->h_res;
     PDump *dd = reinterpret_cast<PDump *>(pc + n_ab + n_cst);
     HIP_TRY(hipMemcpy(dd, &hd, sizeof(PDump), hipMemcpyHostToDevice));
     s->pconst.AB = s->pab; s->pconst.b = D.b; s->pconst.cst = s->pcst; s->pconst.ctrl = D.ctrl; s->pconst.dump = dd; s->pconst.Np = s->Np;
@@ -1138,8 +1146,12 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
     if (hipMalloc(&s->slab, s->slab_bytes) != hipSuccess) { delete s; return fail(TQGPU_ENOMEM, "hipMalloc failed for the device mirror"); }
     if (hipMemset(s->slab, 0, s->slab_bytes) != hipSuccess) return cleanup_fail(fail(TQGPU_ENODEVICE, "hipMemset failed"));
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) return cleanup_fail(fail(TQGPU_ENODEVICE, "hipStreamCreate failed"));
-    if (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) return cleanup_fail(fail(TQGPU_ENODEVICE, "hipEventCreate failed"));
-    if (hipHostMalloc((void **)&s->h_ctrl, sizeof(Ctrl), hipHostMallocDefault) != hipSuccess) return cleanup_fail(fail(TQGPU_ENOMEM, "hipHostMalloc failed"));
+    s->ring_ev0.assign(EV_RING, nullptr); s->ring_ev1.assign(EV_RING, nullptr);
+    for (int i = 0; i < EV_RING; i++)
+        if (hipEventCreate(&s->ring_ev0[i]) != hipSuccess || hipEventCreate(&s->ring_ev1[i]) != hipSuccess) return cleanup_fail(fail(TQGPU_ENODEVICE, "hipEventCreate failed"));
+    if (hipHostMalloc((void **)&s->h_res, sizeof(HostRes), hipHostMallocDefault) != hipSuccess) return cleanup_fail(fail(TQGPU_ENOMEM, "hipHostMalloc failed"));
+    memset(s->h_res, 0, sizeof(HostRes));
+    s->h_ctrl = &s->h_res->c;
     if (hipHostMalloc((void **)&s->h_ls_log, s->ls_log_cap * I, hipHostMallocDefault) != hipSuccess) return cleanup_fail(fail(TQGPU_ENOMEM, "hipHostMalloc failed"));
 
     void *base = s->slab;
@@ -1190,10 +1202,10 @@ extern "C" void tqgpu_destroy(tqgpu_solver *s) {
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (auto &ev : s->iter_ev) (void)hipEventDestroy(ev);
-    if (s->ev0) (void)hipEventDestroy(s->ev0);
-    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    for (auto &ev : s->ring_ev0) if (ev) (void)hipEventDestroy(ev);
+    for (auto &ev : s->ring_ev1) if (ev) (void)hipEventDestroy(ev);
     if (s->stream) (void)hipStreamDestroy(s->stream);
-    if (s->h_ctrl) (void)hipHostFree(s->h_ctrl);
+    if (s->h_res) (void)hipHostFree(s->h_res);
     if (s->h_ls_log) (void)hipHostFree(s->h_ls_log);
     if (s->shard_slab) (void)hipFree(s->shard_slab);
     if (s->sync_slab) (void)hipFree(s->sync_slab);
@@ -1278,10 +1290,37 @@ int read_ctrl(tqgpu_solver *s) {
     return TQGPU_OK;
 }
 
+/* persistent launch: wait for the result block the top workgroup writes into pinned host memory (the
+ * kernel may still be writing the state back -- everything else the host does is stream-ordered behind it) */
+int wait_result_block(tqgpu_solver *s) {
+    volatile unsigned *seq = &s->h_res->seq;
+    const unsigned want = s->psync.seq;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (long spins = 0; *seq != want; spins++) {
+        __builtin_ia32_pause();
+        if ((spins & 0xFFFF) == 0xFFFF && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+            /* no verdict (a wait inside the kernel timed out, or the launch failed): fall back to the stream */
+            return read_ctrl(s);
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return TQGPU_OK;
+}
+
 }  // namespace
+
+#ifdef TQ_HOSTPROF
+#include <chrono>
+static double hp_acc[4] = {0, 0, 0, 0}; static long hp_n = 0;
+#define HP_NOW() std::chrono::steady_clock::now()
+#define HP_US(a, b) std::chrono::duration<double, std::micro>((b) - (a)).count()
+#endif
 
 extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *res) {
     if (!s || !o || !res) return fail(TQGPU_EINVAL, "tqgpu_solve: bad arguments");
+#ifdef TQ_HOSTPROF
+    auto hp0 = HP_NOW();
+#endif
     HIP_TRY(hipSetDevice(s->device));
     Opts O;
     O.maxIter = o->maxIter; O.termCondition = o->termCondition; O.regType = o->regType;
@@ -1307,7 +1346,10 @@ extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *r
 
     const bool fast = s->fast >= 0 && s->use_fast;
     const bool persist = fast && s->persist_ok && s->use_persist && s->nranks == 1 && !o->profile && o->maxIter > 0;
-    HIP_TRY(hipEventRecord(s->ev0, st));
+    const int ring = (int)(s->solve_no % EV_RING);
+    hipEvent_t ev0 = s->ring_ev0[ring], ev1 = s->ring_ev1[ring];
+    s->solve_no++;
+    HIP_TRY(hipEventRecord(ev0, st));
     if (!persist) HIP_TRY(hipMemsetAsync(D.ctrl, 0, sizeof(Ctrl), st));     /* persistent path: zeroed with its inter-workgroup words */
     if (s->need_init) {
         hipLaunchKernelGGL(k_init, dim3((nxu + 255) / 256), dim3(256), 0, st, s->sum_nx, s->sum_nu, D); launches++;
@@ -1325,7 +1367,7 @@ extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *r
      * the host enqueues `chunk` tagged iterations ahead and reads the control block once per chunk.
      * Iterations enqueued beyond convergence, or while a line search still needs trials, are
      * no-ops by their phase guards. */
-    bool first_launch = true;
+    bool first_launch = true, tail_done = false;
     int h = 0, ev_idx = 0;
     bool finished = o->maxIter <= 0;       /* nothing to iterate: reported as "maximum iterations" */
     if (finished) { HIP_TRY(hipStreamSynchronize(st)); memset(s->h_ctrl, 0, sizeof(Ctrl)); s->h_ctrl->status = 1; }
@@ -1333,15 +1375,33 @@ extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *r
     int chunk = s->last_iter > 0 ? std::min(s->last_iter + 1, 16) : s->chunk;
     while (!finished) {
         const int n = persist ? 0 : std::min(chunk, o->maxIter - h);
+#ifdef TQ_HOSTPROF
+        auto hp1 = HP_NOW();
+#endif
         if (persist) { int rcx = launch_persist(s, O, launches, first_launch ? 1 : 0); if (rcx != TQGPU_OK) return rcx; first_launch = false; }
+#ifdef TQ_HOSTPROF
+        auto hp2 = HP_NOW();
+#endif
         for (int i = 0; i < n; i++) {
             if (fast) { int rcx = launch_fast_iteration(s, O, h + i, launches); if (rcx != TQGPU_OK) return rcx; }
             else launch_generic_iteration(s, O, h + i, launches);
             if (o->profile && ev_idx + 1 < (int)s->iter_ev.size()) HIP_TRY(hipEventRecord(s->iter_ev[++ev_idx], st));
         }
-        int rc = read_ctrl(s);
+        int rc;
+        if (persist) {
+            /* the launch normally ends the solve: close the timing here, fetch the log behind it, and take the verdict from the result block */
+            HIP_TRY(hipEventRecord(ev1, st));
+            HIP_TRY(hipMemcpyAsync(s->h_ls_log, D.ls_log, sizeof(int) * (size_t)std::min(s->ls_log_cap, std::max(o->maxIter, 1)), hipMemcpyDeviceToHost, st));
+            rc = wait_result_block(s);
+        } else rc = read_ctrl(s);
         if (rc != TQGPU_OK) return rc;
+#ifdef TQ_HOSTPROF
+        { auto hp3 = HP_NOW(); hp_acc[0] += HP_US(hp0, hp1); hp_acc[1] += HP_US(hp1, hp2); hp_acc[2] += HP_US(hp2, hp3); hp_n++;
+          if (hp_n % 200 == 0) { fprintf(stderr, "[hostprof] pre %.2f us, launch %.2f us, readback+sync %.2f us (avg of %ld)\n", hp_acc[0] / hp_n, hp_acc[1] / hp_n, hp_acc[2] / hp_n, hp_n); } }
+#endif
+        tail_done = persist;
         while (!s->h_ctrl->done && s->h_ctrl->ls_pending) {
+            tail_done = false;
             /* the line search of iteration `iter` wants more trials (rare): a batch of them */
             const int it = s->h_ctrl->iter, t0 = s->h_ctrl->ls_iter;
             for (int t = t0; t < t0 + 8 && t <= O.lsMaxIter; t++) { int rcx = launch_trial(s, O, fast, it, t, launches); if (rcx != TQGPU_OK) return rcx; }
@@ -1357,14 +1417,20 @@ extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *r
         }
     }
     const int host_iter = ev_idx;
-    HIP_TRY(hipEventRecord(s->ev1, st));
-    HIP_TRY(hipMemcpyAsync(s->h_ls_log, D.ls_log, sizeof(int) * (size_t)std::min(s->ls_log_cap, std::max(o->maxIter, 1)), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    float ms = 0.f;
+    if (!tail_done) {
+        HIP_TRY(hipEventRecord(ev1, st));
+        HIP_TRY(hipMemcpyAsync(s->h_ls_log, D.ls_log, sizeof(int) * (size_t)std::min(s->ls_log_cap, std::max(o->maxIter, 1)), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+    } else {
+        /* single persistent launch: the kernel's own clock, launch start to verdict (the event pair of this
+         * solve can be read later through tqgpu_get_device_times, which synchronises) */
+        ms = 1e-5f * (float)(s->h_res->t_end - s->h_res->t_start);
+    }
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return fail(TQGPU_ENODEVICE, std::string("kernel launch failed: ") + hipGetErrorString(le));
 
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
     if (o->profile) {
         for (int i = 0; i < host_iter && i + 1 < (int)s->iter_ev.size() && i < (int)s->iter_times.size(); i++) {
             float t = 0.f;
@@ -1592,11 +1658,26 @@ extern "C" int tqgpu_get_solution(tqgpu_solver *s, double *x, double *u, double 
 extern "C" int tqgpu_get_iteration_log(const tqgpu_solver *s, int *ls_iters, double *iter_times, int cap) {
     if (!s) return fail(TQGPU_EINVAL, "null solver");
     const int n = std::min(std::min(cap, s->last_iter), s->ls_log_cap);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);       /* the log copy of the last solve may still be in flight */
     for (int i = 0; i < n; i++) {
         if (ls_iters) ls_iters[i] = s->h_ls_log[i];
         if (iter_times) iter_times[i] = i < (int)s->iter_times.size() ? s->iter_times[i] : NAN;
     }
     return TQGPU_OK;
+}
+
+/* Device times (HIP events on the solver's stream, first to last enqueued operation of a solve) of the
+ * last `n` solves, oldest first; synchronises the stream.  Returns the number written. */
+extern "C" int tqgpu_get_device_times(tqgpu_solver *s, double *out, int n) {
+    if (!s || !out || n < 0) return -1;
+    if (hipSetDevice(s->device) != hipSuccess || hipStreamSynchronize(s->stream) != hipSuccess) return -1;
+    const long have = std::min<long>(std::min<long>(n, s->solve_no), EV_RING);
+    for (long i = 0; i < have; i++) {
+        const int ring = (int)((s->solve_no - have + i) % EV_RING);
+        float ms = 0.f;
+        out[i] = hipEventElapsedTime(&ms, s->ring_ev0[ring], s->ring_ev1[ring]) == hipSuccess ? 1e-3 * ms : NAN;
+    }
+    return (int)have;
 }
 
 /* Algorithmic bytes / flops of one Newton iteration (every input read once, every output written

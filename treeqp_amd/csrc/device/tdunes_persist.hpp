@@ -51,12 +51,21 @@ typedef unsigned long long u64;
 
 /* what only the start and the end of a launch touch; lives in device memory so that the kernel
  * holds ONE pointer during the loop (scalar register pressure) */
+/* result block in pinned host memory: the top workgroup writes it the moment the launch is decided, the
+ * host polls `seq` -- it does not wait for the other workgroups to leave nor for a stream synchronisation */
+struct HostRes {
+    Ctrl c;
+    unsigned long long t_start, t_end;      /* 100 MHz wall clock of the top workgroup: launch start, verdict */
+    unsigned seq;                           /* == PSync.seq of the launch when the block is complete */
+};
+
 struct PDump {
     double *x, *u, *xUnc, *uUnc, *qmod, *rmod, *QinvCal, *RinvCal, *lam0, *lam1, *dlam;
     const double *lam_init;
     unsigned long long *stamps;
     int *ls_log;
     int ls_log_cap;
+    HostRes *hres;
 };
 
 /* what the loop touches in global memory besides the hand-over buffers */
@@ -543,6 +552,7 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(PConst C, Opts O, PGeom G
     const int nbt = U::first(th);                                      /* my blocks */
     const int nown = nbt + (is_bottom ? U::width(th) : 0);             /* nodes I own */
     const int root_blk = U::first(l0) + s;                             /* subtree root block (= node) */
+    const unsigned long long t_start = wall_clock64();
     int cur = 0;
     unsigned nd = 0u;          /* stage sweeps (= {fval, dot} reductions) of this launch so far */
     bool have_dl = false;      /* a forward sweep of this launch has filled the step of my blocks */
@@ -680,7 +690,15 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(PConst C, Opts O, PGeom G
                     const int ii = U::first(l0 + t) + s * nb + wave, loc = U::first(t) + wave;
                     const bool is_root = is_top && t == 0;
                     bool ok = true;
+#ifdef TQ_FINE_STAMPS
+                    const bool fs = is_top && t == 1 && wave == 0 && O.stamps == (int)e;
+                    long long fc[6] = {0, 0, 0, 0, 0, 0};
+                    if (fs) fc[0] = clock64();
+#endif
                     p_load_rows<NX, NU, MD>(L, loc, lane, is_root, Tc);
+#ifdef TQ_FINE_STAMPS
+                    if (fs) { lds_fence(); fc[1] = clock64(); }
+#endif
                     if (t < th - 1) sub_children<NX, NU, MD>((lds_cptr)(L.sch + (U::first(t + 1) + MD * wave) * U::SCH), lane, Tc);
                     else if (!is_bottom) {
                         ok = p_sub_children_tagged<NX, NU, MD>(Sy, Sy.sch + (size_t)U::kid0(ii) * U::SCH * 2, tag_e, lane, Tc);
@@ -688,11 +706,26 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(PConst C, Opts O, PGeom G
                         if (!ok && lane == 0) *L.abort = 1;
                     }
                     double myinv = 0.0;
+#ifdef TQ_FINE_STAMPS
+                    if (fs) { lds_fence(); fc[2] = clock64(); }
+#endif
                     factor_rows<NX, NU, MD>(c, O, lane, Tc, myinv);
+#ifdef TQ_FINE_STAMPS
+                    if (fs) fc[3] = clock64();
+#endif
                     if (!is_root) {
                         p_store_factor<NX, NU, MD>(L, loc, lane, Tc, myinv);
+#ifdef TQ_FINE_STAMPS
+                        if (fs) { lds_fence(); fc[4] = clock64(); }
+#endif
                         if (t == 0) { if (ok) p_schur<NX, NU, MD, true>(L, loc, lane, L.sch, Sy.sch + (size_t)ii * U::SCH * 2, tag_e); }
                         else p_schur<NX, NU, MD, false>(L, loc, lane, L.sch + loc * U::SCH, nullptr, 0u);
+#ifdef TQ_FINE_STAMPS
+                        if (fs) {
+                            lds_fence(); fc[5] = clock64();
+                            if (lane == 0) { unsigned long long *st = C.dump->stamps; for (int i = 0; i < 6; i++) { st[(7 * 32 + i) * 2] = (unsigned long long)fc[i]; st[(7 * 32 + i) * 2 + 1] = 1ull; } }
+                        }
+#endif
                     } else {
                         /* root: keep L and 1/diag, then dlam_0 = L^-T (L^-1 res) */
                         if (lane <= D) {
@@ -762,6 +795,16 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(PConst C, Opts O, PGeom G
     __syncthreads();
     {
         const PDump *dp = C.dump;
+        if (is_top && threadIdx.x == 0) {
+            /* the verdict goes straight to the host (system-scope stores to pinned memory, then the sequence word) */
+            HostRes *hr = dp->hres;
+            const unsigned long long *src = reinterpret_cast<const unsigned long long *>(c);
+            unsigned long long *dst = reinterpret_cast<unsigned long long *>(&hr->c);
+            for (int i = 0; i < (int)(sizeof(Ctrl) / 8); i++) __hip_atomic_store(dst + i, src[i], RLX, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&hr->t_start, t_start, RLX, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&hr->t_end, (unsigned long long)wall_clock64(), RLX, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&hr->seq, Sy.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         if (nd > 0u) {
             for (int i = threadIdx.x; i < nown * 16; i += FW * WAVE) {
                 const int q = i >> 4, t = i & 15;
