@@ -92,7 +92,7 @@ int tqgpu_dims(const tqgpu_solver *s, int *sum_nx, int *sum_nu, int *sum_lam, in
 
 /* per-iteration line-search counts and event times (seconds) of the last solve; arrays of
  * length >= iter; times are NaN unless opts.profile != 0 */
-int tqgpu_get_iteration_log(const tqgpu_solver *s, int *ls_iters, double *iter_times, int cap);
+int tqgpu_get_iteration_log(tqgpu_solver *s, int *ls_iters, double *iter_times, int cap);
 
 /* roofline support: algorithmic bytes and flops of ONE Newton iteration with n_ls line-search
  * trials (closed form of SURVEY.md §8(d) generalised to per-node dimensions) */

@@ -1391,7 +1391,6 @@ extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *r
         if (persist) {
             /* the launch normally ends the solve: close the timing here, fetch the log behind it, and take the verdict from the result block */
             HIP_TRY(hipEventRecord(ev1, st));
-            HIP_TRY(hipMemcpyAsync(s->h_ls_log, D.ls_log, sizeof(int) * (size_t)std::min(s->ls_log_cap, std::max(o->maxIter, 1)), hipMemcpyDeviceToHost, st));
             rc = wait_result_block(s);
         } else rc = read_ctrl(s);
         if (rc != TQGPU_OK) return rc;
@@ -1420,7 +1419,6 @@ extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *r
     float ms = 0.f;
     if (!tail_done) {
         HIP_TRY(hipEventRecord(ev1, st));
-        HIP_TRY(hipMemcpyAsync(s->h_ls_log, D.ls_log, sizeof(int) * (size_t)std::min(s->ls_log_cap, std::max(o->maxIter, 1)), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
     } else {
@@ -1655,10 +1653,15 @@ extern "C" int tqgpu_get_solution(tqgpu_solver *s, double *x, double *u, double 
     return TQGPU_OK;
 }
 
-extern "C" int tqgpu_get_iteration_log(const tqgpu_solver *s, int *ls_iters, double *iter_times, int cap) {
+extern "C" int tqgpu_get_iteration_log(tqgpu_solver *s, int *ls_iters, double *iter_times, int cap) {
     if (!s) return fail(TQGPU_EINVAL, "null solver");
     const int n = std::min(std::min(cap, s->last_iter), s->ls_log_cap);
-    if (s->stream) (void)hipStreamSynchronize(s->stream);       /* the log copy of the last solve may still be in flight */
+    if (n > 0 && ls_iters) {
+        /* fetched on request (stream-ordered behind the solve), not on every solve */
+        HIP_TRY(hipSetDevice(s->device));
+        HIP_TRY(hipMemcpyAsync(s->h_ls_log, s->D.ls_log, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+    }
     for (int i = 0; i < n; i++) {
         if (ls_iters) ls_iters[i] = s->h_ls_log[i];
         if (iter_times) iter_times[i] = i < (int)s->iter_times.size() ? s->iter_times[i] : NAN;
