@@ -1,0 +1,92 @@
+// Microbenchmark: the backward level step of the persistent kernel (one 4-wave workgroup, LDS resident),
+// with parts switched off by a mask to attribute the cycles.  Numerics are irrelevant here.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I treeqp_amd/csrc/device -o level_bench tools/microbench/level_bench.hip
+#include "../../treeqp_amd/csrc/device/tdunes_device.hip"
+
+namespace {
+// MASK bits: 1 load_rows, 2 sub_children, 4 factor, 8 store_factor, 16 schur, 32 barrier
+template <int MASK>
+__global__ void __launch_bounds__(FW * WAVE) level_bench(Ctrl *c, Opts O, long long *cycles, int reps, double *sink) {
+    constexpr int NX = 8, NU = 3, MD = 2;
+    using U = Uni<NX, NU, MD>;
+    constexpr int D = U::D;
+    extern __shared__ __attribute__((aligned(16))) double lds_all[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    PLds<NX, NU, MD> L(lds_all, wave);
+    for (int i = threadIdx.x; i < PLds<NX, NU, MD>::DOUBLES; i += FW * WAVE) lds_all[i] = 0.01 * ((i * 7) % 13);
+    __syncthreads();
+    for (int b = 0; b < U::NBT; b++)
+        if (threadIdx.x < D) L.W[b * D * D + threadIdx.x * D + threadIdx.x] = 50.0;
+    __syncthreads();
+    const int th = 3;
+    double Tc[D];
+#pragma unroll
+    for (int j = 0; j < D; j++) Tc[j] = (lane == j) ? 40.0 : 0.01 * j;
+    long long t0 = clock64();
+    for (int r = 0; r < reps; r++) {
+        for (int t = th - 1; t >= 0; t--) {
+            const int nb = U::width(t);
+            if (wave < nb) {
+                const int loc = U::first(t) + wave;
+                if (MASK & 1) p_load_rows<NX, NU, MD>(L, loc, lane, false, Tc);
+                if ((MASK & 2) && t < th - 1) sub_children<NX, NU, MD>((lds_cptr)(L.sch + (U::first(t + 1) + MD * wave) * U::SCH), lane, Tc);
+                if (MASK & 4) p_factor_rows<NX, NU, MD>(c, O, lane, Tc);
+                if (MASK & 64) { double pm = p_potrf_rows<D>(Tc, lane); if (pm == 1.2345) sink[1] = pm; }
+                if (MASK & 128) {      /* bare left-looking factorisation, nothing stored */
+#pragma unroll
+                    for (int j = 0; j < D; j++) {
+                        double s = Tc[j];
+#pragma unroll
+                        for (int k = 0; k < j; k++) s = fma(-Tc[k], rdlane(Tc[k], j), s);
+                        const double pj = rdlane(s, j);
+                        Tc[j] = s * pivot_rsqrt3(pj);
+                    }
+                }
+                if (MASK & 8) p_store_factor<NX, NU, MD>(L, loc, lane, Tc);
+                if (MASK & 16) p_schur<NX, NU, MD, false>(L, loc, lane, L.sch + loc * U::SCH, nullptr, 0u);
+            }
+            if (MASK & 32) lds_barrier();
+        }
+        if (!(MASK & 1)) {
+#pragma unroll
+            for (int j = 0; j < D; j++) Tc[j] = (lane == j) ? 40.0 + Tc[j] * 1e-300 : 0.01 * j;
+        }
+    }
+    long long t1 = clock64();
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < D; j++) acc += Tc[j];
+    if (threadIdx.x == 0) cycles[0] = (t1 - t0) / (reps * th);
+    if (acc == 1.2345) sink[0] = acc;
+}
+}  // namespace
+
+template <int MASK>
+static void run(const char *name, Ctrl *c, Opts O, long long *dc, double *sink) {
+    const size_t lds = PLds<8, 3, 2>::DOUBLES * sizeof(double);
+    for (int it = 0; it < 2; it++) { hipLaunchKernelGGL(level_bench<MASK>, dim3(1), dim3(FW * WAVE), lds, 0, c, O, dc, 300, sink); (void)hipDeviceSynchronize(); }
+    long long h = 0;
+    (void)hipMemcpy(&h, dc, 8, hipMemcpyDeviceToHost);
+    printf("%-44s %6lld cycles per level\n", name, h);
+}
+
+int main() {
+    Ctrl *c; long long *dc; double *sink;
+    (void)hipMalloc(&c, sizeof(Ctrl)); (void)hipMemset(c, 0, sizeof(Ctrl)); (void)hipMalloc(&dc, 64); (void)hipMalloc(&sink, 64);
+    Opts O; memset(&O, 0, sizeof(O));
+    O.regType = 2; O.regTol = 1e-6; O.regValue = 1e-6; O.termCondition = 2;
+    run<63>("all (load, sub, factor, store, schur, barrier)", c, O, dc, sink);
+    run<63 - 32>("no barrier", c, O, dc, sink);
+    run<63 - 16>("no schur", c, O, dc, sink);
+    run<63 - 8>("no store_factor", c, O, dc, sink);
+    run<63 - 2>("no sub_children", c, O, dc, sink);
+    run<63 - 1>("no load_rows", c, O, dc, sink);
+    run<4 + 32>("factor + barrier only", c, O, dc, sink);
+    run<4>("factor only", c, O, dc, sink);
+    run<1 + 2 + 8 + 16 + 32>("everything but factor", c, O, dc, sink);
+    run<64>("p_potrf_rows only", c, O, dc, sink);
+    run<128>("bare potrf (no inv store, no pmin)", c, O, dc, sink);
+    run<63 - 4 + 64>("all with p_potrf_rows instead of factor_rows", c, O, dc, sink);
+    run<63 - 4 + 128>("all with bare potrf", c, O, dc, sink);
+    return 0;
+}

@@ -136,6 +136,72 @@ __device__ __forceinline__ void potrf_v8(double (&T)[D], int lane) {
     }
 }
 
+// third-order one-step reciprocal square root (4 dependent ops after v_rsq)
+__device__ __forceinline__ double pivot_rsqrt3(double p) {
+    const double y0 = __builtin_amdgcn_rsq(p);
+    const double e = fma(-(p * y0), y0, 1.0);
+    const double h = fma(0.375, e, 0.5);
+    const double y = fma(y0 * e, h, y0);
+    return p > 0.0 ? y : 0.0;
+}
+// reciprocal: v_rcp_f64 + one Newton step
+__device__ __forceinline__ double pivot_rcp1(double p) {
+    const double y0 = __builtin_amdgcn_rcp(p);
+    const double e = fma(-p, y0, 1.0);
+    const double y = fma(y0, e, y0);
+    return p > 0.0 ? y : 0.0;
+}
+// V9: V4 with the one-step rsqrt
+__device__ __forceinline__ void potrf_v9(double (&T)[D], int lane) {
+#pragma unroll
+    for (int j = 0; j < D; j++) {
+        double s = T[j];
+#pragma unroll
+        for (int k = 0; k < j; k++) s = fma(-T[k], rdlane(T[k], j), s);
+        const double pj = rdlane(s, j);
+        const double finv = pivot_rsqrt3(pj);
+        T[j] = s * finv;
+    }
+}
+// V10: right-looking (V1) with the one-step rsqrt
+__device__ __forceinline__ void potrf_v10(double (&T)[D], int lane) {
+#pragma unroll
+    for (int j = 0; j < D; j++) {
+        const double pj = rdlane(T[j], j);
+        const double finv = pivot_rsqrt3(pj);
+        T[j] *= finv;
+#pragma unroll
+        for (int c = j + 1; c < D; c++) { const double lc = rdlane(T[j], c); T[c] = fma(-T[j], lc, T[c]); }
+    }
+}
+// V11: right-looking, unscaled columns (LDL'-style recurrence): only a reciprocal (rcp + 1 Newton) sits on the
+// pivot-to-pivot chain, the rsqrt scaling of the columns happens off the critical path
+__device__ __forceinline__ void potrf_v11(double (&T)[D], int lane) {
+    double finv[D];
+#pragma unroll
+    for (int j = 0; j < D; j++) {
+        const double pj = rdlane(T[j], j);
+        const double dinv = pivot_rcp1(pj);
+#pragma unroll
+        for (int c = j + 1; c < D; c++) { const double lc = rdlane(T[j], c) * dinv; T[c] = fma(-T[j], lc, T[c]); }
+        finv[j] = pivot_rsqrt3(pj);
+    }
+#pragma unroll
+    for (int j = 0; j < D; j++) T[j] *= finv[j];
+}
+// V12: as V11 but the scaling of column j is issued right after its trailing updates (no finv array)
+__device__ __forceinline__ void potrf_v12(double (&T)[D], int lane) {
+#pragma unroll
+    for (int j = 0; j < D; j++) {
+        const double pj = rdlane(T[j], j);
+        const double dinv = pivot_rcp1(pj);
+        const double tj = T[j];
+#pragma unroll
+        for (int c = j + 1; c < D; c++) { const double lc = rdlane(tj, c) * dinv; T[c] = fma(-tj, lc, T[c]); }
+        T[j] = tj * pivot_rsqrt3(pj);
+    }
+}
+
 // V5: right-looking with ds_bpermute broadcast (__shfl)
 __device__ __forceinline__ void potrf_v5(double (&T)[D], int lane) {
 #pragma unroll
@@ -168,6 +234,10 @@ __global__ void bench(const double *in, double *out, long long *cycles, int reps
         if (V == 6) potrf_v6(T, lane);
         if (V == 7) potrf_v7(T, lane);
         if (V == 8) potrf_v8(T, lane);
+        if (V == 9) potrf_v9(T, lane);
+        if (V == 10) potrf_v10(T, lane);
+        if (V == 11) potrf_v11(T, lane);
+        if (V == 12) potrf_v12(T, lane);
 #pragma unroll
         for (int j = 0; j < D; j++) acc += T[j];
     }
@@ -222,7 +292,7 @@ int main() {
     hipMemcpy(din, h.data(), sizeof(double) * R * D, hipMemcpyHostToDevice);
     long long c[8];
     std::vector<double> ref(64 * D), got(64 * D);
-    for (int v = 1; v <= 8; v++) {
+    for (int v = 1; v <= 12; v++) {
         for (int it = 0; it < 2; it++) {
             switch (v) {
                 case 1: hipLaunchKernelGGL(bench<1>, dim3(1), dim3(64), 0, 0, din, dout, dc, 200); break;
@@ -233,6 +303,10 @@ int main() {
                 case 6: hipLaunchKernelGGL(bench<6>, dim3(1), dim3(64), 0, 0, din, dout, dc, 200); break;
                 case 7: hipLaunchKernelGGL(bench<7>, dim3(1), dim3(64), 0, 0, din, dout, dc, 200); break;
                 case 8: hipLaunchKernelGGL(bench<8>, dim3(1), dim3(64), 0, 0, din, dout, dc, 200); break;
+                case 9: hipLaunchKernelGGL(bench<9>, dim3(1), dim3(64), 0, 0, din, dout, dc, 200); break;
+                case 10: hipLaunchKernelGGL(bench<10>, dim3(1), dim3(64), 0, 0, din, dout, dc, 200); break;
+                case 11: hipLaunchKernelGGL(bench<11>, dim3(1), dim3(64), 0, 0, din, dout, dc, 200); break;
+                case 12: hipLaunchKernelGGL(bench<12>, dim3(1), dim3(64), 0, 0, din, dout, dc, 200); break;
             }
             hipDeviceSynchronize();
         }

@@ -228,6 +228,88 @@ __device__ __forceinline__ double p_gh_compute(PLds<NX, NU, MD> &L, int loc, int
     return (termCondition == 2) ? wmax(e) : wsum(e);
 }
 
+/* 1/sqrt(p) for p > 0, 0 otherwise: v_rsq_f64 (relative error ~ 2^-26) and ONE third-order correction
+ * y0 (1 + e/2 + 3 e^2/8), e = 1 - p y0^2 -- four dependent operations instead of the six of two Newton
+ * steps, remaining error ~ e^3 (far below one ulp) */
+__device__ __forceinline__ double pivot_rsqrt3(double p) {
+    const double y0 = __builtin_amdgcn_rsq(p);
+    const double e = fma(-(p * y0), y0, 1.0);
+    const double h = fma(0.375, e, 0.5);
+    const double y = fma(y0 * e, h, y0);
+    return p > 0.0 ? y : 0.0;
+}
+
+/* T[j][lane j] = K[j][lane j] + a for every j, other lanes T[j] = K[j] -- without lane masks (the masks of
+ * all D lanes would sit in scalar registers for the whole sweep): v_writelane with an immediate lane */
+template <int J, int D>
+struct ShiftDiag {
+    static __device__ __forceinline__ void run(double (&T)[D], const double (&K)[D], double a) {
+        const double sj = rdlane(K[J], J) + a;
+        const int slo = __builtin_amdgcn_readfirstlane(__double2loint(sj)), shi = __builtin_amdgcn_readfirstlane(__double2hiint(sj));
+        int lo = __double2loint(K[J]), hi = __double2hiint(K[J]);
+        /* s_nop: the scalar operands come from VALU instructions the assembler cannot see through */
+        asm volatile("s_nop 4\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4" : "+v"(lo), "+v"(hi) : "s"(slo), "s"(shi), "n"(J));
+        T[J] = __hiloint2double(hi, lo);
+        ShiftDiag<J + 1, D>::run(T, K, a);
+    }
+};
+template <int D>
+struct ShiftDiag<D, D> { static __device__ __forceinline__ void run(double (&)[D], const double (&)[D], double) {} };
+
+/* in-register tall Cholesky as potrf_rows (left-looking, row broadcasts by readlane) and nothing else in
+ * the loop: no per-lane select or store of the reciprocal pivots (the substitutions recompute 1/diag from
+ * the stored factor; an exec-masked LDS store per column cost ~70 cycles each in tools/microbench/level_bench);
+ * returns the smallest pivot (on-the-fly regularisation trigger) */
+template <int D>
+__device__ __forceinline__ double p_potrf_rows(double (&T)[D], int lane) {
+    double pmin = __builtin_inf();
+#pragma unroll
+    for (int j = 0; j < D; j++) {
+        double s = T[j];
+#pragma unroll
+        for (int k = 0; k < j; k++) s = fma(-T[k], rdlane(T[k], j), s);
+        const double pj = rdlane(s, j);
+        pmin = fmin(pmin, pj);
+        T[j] = s * pivot_rsqrt3(pj);
+    }
+    return pmin;
+}
+
+/* 1/d for a diagonal entry of the factor (0 for the zero column of a non-positive pivot, as the
+ * reciprocal pivot of the factorisation): v_rcp_f64 + two Newton steps */
+__device__ __forceinline__ double diag_inv(double d) {
+    double y = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-d, y, 1.0);
+    y = fma(y, e, y);
+    return d > 0.0 ? y : 0.0;
+}
+
+/* dual_Newton_common.c:36-78 around p_potrf_rows: ALWAYS shifts the diagonal first, ON_THE_FLY
+ * refactorises the shifted block when a diagonal entry of the factor came out <= regTol */
+template <int NX, int NU, int MD>
+__device__ __forceinline__ void p_factor_rows(Ctrl *ctrl, const Opts &O, int lane, double (&T)[Uni<NX, NU, MD>::D]) {
+    constexpr int D = Uni<NX, NU, MD>::D;
+    double K[D];
+    if (O.regType != 0) {
+#pragma unroll
+        for (int j = 0; j < D; j++) K[j] = T[j];
+        if (O.regType == 1) {
+            ShiftDiag<0, D>::run(T, K, O.regValue);                                /* ddiare (ALWAYS) */
+#pragma unroll
+            for (int j = 0; j < D; j++) K[j] = T[j];
+        }
+    }
+    for (int pass = 0; pass < 2; pass++) {
+        const double pmin = p_potrf_rows<D>(T, lane);
+        const bool small = pmin <= O.regTol * O.regTol;                             /* sqrt(pivot) <= regTol, incl. non-positive pivots */
+        if (O.regType != 2 || !small || pass == 1) break;
+        ShiftDiag<0, D>::run(T, K, O.regValue);                                    /* rare: shift and refactorise */
+        if (lane == 0) atomicAdd(&ctrl->n_reg, 1);
+    }
+}
+
 template <int NX, int NU, int MD>
 __device__ __forceinline__ void p_load_rows(PLds<NX, NU, MD> &L, int loc, int lane, bool is_root, double (&T)[Uni<NX, NU, MD>::D]) {
     using U = Uni<NX, NU, MD>;
@@ -242,9 +324,9 @@ __device__ __forceinline__ void p_load_rows(PLds<NX, NU, MD> &L, int loc, int la
 }
 
 /* factor data of block `loc` back into LDS with ONE store per column (per-lane base + stride):
- * L over W (lanes < D), y (lane D), CholUt over Ut (lanes D+1 .. R-1), plus 1/diag */
+ * L over W (lanes < D), y (lane D), CholUt over Ut (lanes D+1 .. R-1); 1/diag was stored by the factorisation */
 template <int NX, int NU, int MD>
-__device__ __forceinline__ void p_store_factor(PLds<NX, NU, MD> &L, int loc, int lane, const double (&T)[Uni<NX, NU, MD>::D], double myinv) {
+__device__ __forceinline__ void p_store_factor(PLds<NX, NU, MD> &L, int loc, int lane, const double (&T)[Uni<NX, NU, MD>::D]) {
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D, R = U::R;
     lds_ptr dst; int stride;
@@ -255,7 +337,6 @@ __device__ __forceinline__ void p_store_factor(PLds<NX, NU, MD> &L, int loc, int
 #pragma unroll
         for (int j = 0; j < D; j++) dst[j * stride] = T[j];
     }
-    if (lane < D) L.inv[loc * D + lane] = myinv;
 }
 
 /* Schur record [S | v] = CUt * [CUt' | y] (one f64 MFMA tile, K = D) straight from the CholUt / y just
@@ -326,7 +407,7 @@ __device__ __forceinline__ double p_forward(const PSync &Sy, PLds<NX, NU, MD> &L
 #pragma unroll
     for (int r = 0; r < NX; r++) acc = fma(Cc[r], dv[r], acc);
     double s = fma(-1.0, acc, L.y[loc * D + li]);
-    const double inv = L.inv[loc * D + li];
+    const double inv = diag_inv(Lc[li]);
     double Lcol[D];
 #pragma unroll
     for (int k = 0; k < D; k++) Lcol[k] = Lc[k];
@@ -690,42 +771,18 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(PConst C, Opts O, PGeom G
                     const int ii = U::first(l0 + t) + s * nb + wave, loc = U::first(t) + wave;
                     const bool is_root = is_top && t == 0;
                     bool ok = true;
-#ifdef TQ_FINE_STAMPS
-                    const bool fs = is_top && t == 1 && wave == 0 && O.stamps == (int)e;
-                    long long fc[6] = {0, 0, 0, 0, 0, 0};
-                    if (fs) fc[0] = clock64();
-#endif
                     p_load_rows<NX, NU, MD>(L, loc, lane, is_root, Tc);
-#ifdef TQ_FINE_STAMPS
-                    if (fs) { lds_fence(); fc[1] = clock64(); }
-#endif
                     if (t < th - 1) sub_children<NX, NU, MD>((lds_cptr)(L.sch + (U::first(t + 1) + MD * wave) * U::SCH), lane, Tc);
                     else if (!is_bottom) {
                         ok = p_sub_children_tagged<NX, NU, MD>(Sy, Sy.sch + (size_t)U::kid0(ii) * U::SCH * 2, tag_e, lane, Tc);
                         ok = __all(ok);
                         if (!ok && lane == 0) *L.abort = 1;
                     }
-                    double myinv = 0.0;
-#ifdef TQ_FINE_STAMPS
-                    if (fs) { lds_fence(); fc[2] = clock64(); }
-#endif
-                    factor_rows<NX, NU, MD>(c, O, lane, Tc, myinv);
-#ifdef TQ_FINE_STAMPS
-                    if (fs) fc[3] = clock64();
-#endif
+                    p_factor_rows<NX, NU, MD>(c, O, lane, Tc);
                     if (!is_root) {
-                        p_store_factor<NX, NU, MD>(L, loc, lane, Tc, myinv);
-#ifdef TQ_FINE_STAMPS
-                        if (fs) { lds_fence(); fc[4] = clock64(); }
-#endif
+                        p_store_factor<NX, NU, MD>(L, loc, lane, Tc);
                         if (t == 0) { if (ok) p_schur<NX, NU, MD, true>(L, loc, lane, L.sch, Sy.sch + (size_t)ii * U::SCH * 2, tag_e); }
                         else p_schur<NX, NU, MD, false>(L, loc, lane, L.sch + loc * U::SCH, nullptr, 0u);
-#ifdef TQ_FINE_STAMPS
-                        if (fs) {
-                            lds_fence(); fc[5] = clock64();
-                            if (lane == 0) { unsigned long long *st = C.dump->stamps; for (int i = 0; i < 6; i++) { st[(7 * 32 + i) * 2] = (unsigned long long)fc[i]; st[(7 * 32 + i) * 2 + 1] = 1ull; } }
-                        }
-#endif
                     } else {
                         /* root: keep L and 1/diag, then dlam_0 = L^-T (L^-1 res) */
                         if (lane <= D) {
@@ -734,6 +791,7 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(PConst C, Opts O, PGeom G
                         }
                         lds_fence();
                         const int lc = lane < D ? lane : 0;
+                        const double myinv = diag_inv(L.wave[lc * U::LDW + lc]);
                         double sv = L.wave[D * U::LDW + lc], Lcol[D];
 #pragma unroll
                         for (int k = 0; k < D; k++) Lcol[k] = L.wave[k * U::LDW + lc];
