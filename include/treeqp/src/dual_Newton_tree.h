@@ -66,6 +66,7 @@ typedef struct treeqp_tdunes_workspace_ {
     int stage_doubles;
     int lsTotal;                    /* total line-search trials of the last solve */
     int maxIterAtCreate;
+    int denseStageSolver;           /* 1: every node uses the dense unconstrained stage solver (TREEQP_QPOASES_SOLVER selector) */
 } treeqp_tdunes_workspace;
 
 int treeqp_tdunes_opts_calculate_size(int Nn);

@@ -74,6 +74,12 @@ void tqgpu_destroy(tqgpu_solver *s);
 
 int tqgpu_set_dynamics(tqgpu_solver *s, const double *A, const double *B, const double *b);
 int tqgpu_set_objective_diag(tqgpu_solver *s, const double *Qd, const double *Rd, const double *q, const double *r);
+/* Dense objective + dense UNCONSTRAINED stage solver: replaces the reference's qpOASES stage backend
+ * (dual_Newton_tree_qpoases.c:153-217 init/solve, :401-476 elimination matrices) for nodes without
+ * bounds: z_k = H_k^-1 h_k, P_k = H_k^-1 with H_k = [Q S'; S R].  Flat layout as
+ * tree_qp_in_set_ltv_objective_colmajor (tree_qp_common.c:2010-2050): per node Q (nx x nx), R (nu x nu),
+ * S (nu x nx) column major, then q, r.  Bounds are ignored while it is selected. */
+int tqgpu_set_objective_dense(tqgpu_solver *s, const double *Q, const double *R, const double *S, const double *q, const double *r);
 int tqgpu_set_bounds(tqgpu_solver *s, const double *xmin, const double *xmax, const double *umin, const double *umax);
 int tqgpu_set_lambda(tqgpu_solver *s, const double *lambda);   /* NULL = zeros */
 

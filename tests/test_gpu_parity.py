@@ -241,6 +241,20 @@ def test_dropin_thesis_driver(gpu, tmp_path):
     assert "Solver status: 0" in out.stdout and "Number of iterations: 3" in out.stdout
 
 
+@pytest.mark.parametrize("i", range(6))
+def test_dropin_random_qp_driver_goldens(gpu, tmp_path, i):
+    """examples/random_qp.c, unchanged, -DDATA=<i>: the reference's own unit test with golden vectors
+    (dense Q, S != 0, unconstrained, TREEQP_QPOASES_SOLVER selector).  Its asserts (:249-254): KKT < 1e-12,
+    |x - xopt|, |u - uopt| < 1e-12, at most one iteration, status 0 -- they abort the process when violated."""
+    out, _ = _run_dropin(f"random_qp_data0{i}", tmp_path)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "SOLVER:\ttdunes" in out.stdout
+    its = [l for l in out.stdout.splitlines() if l.startswith("ITERS:")][0]
+    assert int(its.split()[-1]) in (0, 1)
+    err = [l for l in out.stdout.splitlines() if l.startswith("ERROR:")][0]
+    assert float(err.split()[-1]) < 1e-12
+
+
 # --- fused uniform-tree path (tdunes_fast.hpp) ---------------------------------------------------
 
 FUSED_CASES = [
@@ -375,3 +389,26 @@ def test_shard_init_rejects_bad_configs(gpu):
     with pytest.raises(RuntimeError, match="too small"):
         g.shard_init(0, 64)
     g.close()
+
+
+# ---- dense unconstrained stage solver on the device: the reference's own golden vectors ----------------
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", range(6))
+def test_random_qp_goldens_dense_on_device(gpu, orc, i):
+    """examples/random_qp.c + random_qp_utils/data0<i>: dense Q, S != 0, unconstrained, per-node dimensions.
+    Same bar as the reference's own asserts (random_qp.c:249-254): |x - xopt|, |u - uopt| < 1e-12, KKT < 1e-12,
+    at most one Newton iteration; options of random_qp.c:131-133."""
+    f = P.random_qp_fixture(i)
+    g = gpu.TqGpu(f["nk"], f["nx"], f["nu"]).upload_dense(f)
+    assert g.path == 0                                                          # per-node dense blocks: generic kernels
+    r = g.solve(maxIter=10, stationarityTolerance=1e-10, regType=0)
+    sol = g.solution()
+    g.close()
+    assert r["status"] == 0 and r["iter"] in (0, 1)
+    assert np.max(np.abs(sol["x"] - f["xopt"])) < 1e-12
+    assert np.max(np.abs(sol["u"] - f["uopt"])) < 1e-12
+    assert orc.max_kkt(f, sol, dense=True) < 1e-12
+    ref = orc.solve_dense(f, orc.default_opts(maxIter=10, stationarityTolerance=1e-10, regType=0))
+    assert r["iter"] == ref["iter"]
+    assert np.max(np.abs(sol["lam"] - ref["lam"])) < 1e-11

@@ -99,6 +99,9 @@ REF_EXAMPLES = {
     # output name -> (source relative to the reference root, extra defines)
     "spring_mass_tdunes": ("examples/spring_mass_dual_newton_tree.c", ["-DNREP=20", "-DPRINT_LEVEL=1", "-DPROFILE=0"]),
     "thesis_example": ("examples/thesis_example.c", ["-DNREP=1", "-DPRINT_LEVEL=1", "-DPROFILE=0"]),
+    # the reference's unit test with golden vectors (cmake: test_random_qp_DATA<i>): dense Q, S != 0, unconstrained;
+    # its own asserts compare with xopt / uopt of random_qp_utils/data0<i>.c to 1e-12
+    **{f"random_qp_data0{i}": ("examples/random_qp.c", [f"-DDATA={i}", "-DPRINT_LEVEL=0", "-DPROFILE=0"]) for i in range(6)},
 }
 
 

@@ -90,7 +90,7 @@ class TdunesWork(C.Structure):
                 ("npar", c_int_p), ("idxpos", c_int_p), ("sx", C.POINTER(Dvec)), ("su", C.POINTER(Dvec)),
                 ("slambda", C.POINTER(Dvec)), ("sDeltalambda", C.POINTER(Dvec)), ("timings", Profiling),
                 ("device", C.c_void_p), ("stage", c_dbl_p), ("stage_doubles", C.c_int), ("lsTotal", C.c_int),
-                ("maxIterAtCreate", C.c_int)]
+                ("maxIterAtCreate", C.c_int), ("denseStageSolver", C.c_int)]
 
 
 class GpuOpts(C.Structure):
@@ -461,6 +461,19 @@ class TqGpu:
         self._chk(L.tqgpu_set_dynamics(self.h, _dp(keep["A"]), _dp(keep["B"]), _dp(keep["b"])))
         self._chk(L.tqgpu_set_objective_diag(self.h, _dp(keep["Qd"]), _dp(keep["Rd"]), _dp(keep["q"]), _dp(keep["r"])))
         self._chk(L.tqgpu_set_bounds(self.h, _dp(keep["xmin"]), _dp(keep["xmax"]), _dp(keep["umin"]), _dp(keep["umax"])))
+        self.set_lambda(lambda0)
+        return self
+
+    def upload_dense(self, p, lambda0=None):
+        """Dense objective (Q, R, S per node, column major) + the dense unconstrained stage solver."""
+        g = (lambda k: getattr(p, k)) if not isinstance(p, dict) else (lambda k: p[k])
+        L = lib()
+        keep = {k: _f64(g(k)) for k in ("A", "B", "b", "Q", "R", "S", "q", "r")}
+        assert len(keep["A"]) == self.sum_A and len(keep["B"]) == self.sum_B and len(keep["b"]) == self.sum_lam
+        assert len(keep["Q"]) == int((self.nx.astype(np.int64) ** 2).sum()) and len(keep["R"]) == int((self.nu.astype(np.int64) ** 2).sum())
+        assert len(keep["S"]) == int((self.nx.astype(np.int64) * self.nu).sum())
+        self._chk(L.tqgpu_set_dynamics(self.h, _dp(keep["A"]), _dp(keep["B"]), _dp(keep["b"])))
+        self._chk(L.tqgpu_set_objective_dense(self.h, _dp(keep["Q"]), _dp(keep["R"]), _dp(keep["S"]), _dp(keep["q"]), _dp(keep["r"])))
         self.set_lambda(lambda0)
         return self
 

@@ -93,6 +93,12 @@ struct Data {            /* device pointers, passed by value */
     Ctrl *ctrl;
     int *ls_log;
     int ls_log_cap;
+    /* dense unconstrained stage solver (generic path only; dual_Newton_tree_qpoases.c restricted to no bounds):
+     * per node the stage Hessian H = [Q S'; S R] ((nx+nu)^2, column major) and its inverse P = H^-1 */
+    int dense;
+    const double *Hd;
+    double *Pd;
+    const int *poff;          /* [Nn+1] offsets of the (nx+nu)^2 blocks */
 };
 
 struct Opts {
@@ -125,6 +131,52 @@ __global__ void k_init(int n_x, int n_u, Data D) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_x) D.Qinv[i] = 1.0 / D.Qd[i];
     if (i < n_u) D.Rinv[i] = 1.0 / D.Rd[i];
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* k_dense_init: one wave per node: P = H^-1 through the Cholesky factor of H (stage_qp_qpoases */
+/* restricted to unconstrained nodes, dual_Newton_tree_qpoases.c:153-217: the stage solution is */
+/* z = H^-1 h and the elimination matrix is P = H^-1).  H in LDS, column by column; then lane j  */
+/* solves L L' p_j = e_j.                                                                       */
+/* ------------------------------------------------------------------------------------------ */
+__global__ void __launch_bounds__(WAVE) k_dense_init(Tree T, Data D) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int k = blockIdx.x, lane = threadIdx.x;
+    const int nz = T.nx[k] + T.nu[k];
+    if (nz == 0) return;
+    const double *H = D.Hd + D.poff[k];
+    double *P = D.Pd + D.poff[k];
+    double *Lm = lds;                      /* nz x nz, ld = nz */
+    double *dinv = lds + (size_t)nz * nz;  /* nz */
+    for (int e = lane; e < nz * nz; e += WAVE) Lm[e] = H[e];
+    __syncthreads();
+    for (int j = 0; j < nz; j++) {
+        for (int i = j + lane; i < nz; i += WAVE) {
+            double sacc = Lm[i + (size_t)j * nz];
+            for (int c = 0; c < j; c++) sacc = fma(-Lm[i + (size_t)c * nz], Lm[j + (size_t)c * nz], sacc);
+            Lm[i + (size_t)j * nz] = sacc;
+        }
+        __syncthreads();
+        const double cjj = Lm[j + (size_t)j * nz];
+        const double finv = cjj > 0.0 ? 1.0 / sqrt(cjj) : 0.0;
+        for (int i = j + lane; i < nz; i += WAVE) Lm[i + (size_t)j * nz] *= finv;
+        if (lane == 0) dinv[j] = finv;
+        __syncthreads();
+    }
+    /* column j of P: forward then backward substitution on e_j (solution kept in global memory) */
+    for (int j = lane; j < nz; j += WAVE) {
+        double *pj = P + (size_t)j * nz;
+        for (int i = 0; i < nz; i++) {
+            double v = (i == j) ? 1.0 : 0.0;
+            for (int c = 0; c < i; c++) v = fma(-Lm[i + (size_t)c * nz], pj[c], v);
+            pj[i] = v * dinv[i];
+        }
+        for (int i = nz - 1; i >= 0; i--) {
+            double v = pj[i];
+            for (int c = i + 1; c < nz; c++) v = fma(-Lm[c + (size_t)i * nz], pj[c], v);
+            pj[i] = v * dinv[i];
+        }
+    }
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -162,6 +214,48 @@ __global__ void __launch_bounds__(WAVE) k_stage(Tree T, Data D, int mode, int h,
         lown[t] = v;
     }
     __syncthreads();
+
+    if (D.dense) {
+        /* dense unconstrained stage QP: z = P hmod; dual term -1/2 z'Hz + hmod'z - cmod */
+        const int nz = nxk + nuk;
+        double *hm = lds + d + nxk, *zz = hm + nz;
+        for (int t = lane; t < nz; t += WAVE) {
+            const bool isx = t < nxk;
+            const int j = isx ? t : t - nxk;
+            double v = isx ? fma(-1.0, D.q[xo + j], lown[j]) : -1.0 * D.r[uo + j];
+            int rowoff = 0;
+            for (int cc = 0; cc < nkid; cc++) {
+                const int kid = T.kid0[k] + cc, nxc = T.nx[kid];
+                const double *col = isx ? D.A + T.aoff[kid] + (size_t)j * nxc : D.B + T.boff[kid] + (size_t)j * nxc;
+                double acc = 0.0;
+                for (int i = 0; i < nxc; i++) acc = fma(col[i], lk[rowoff + i], acc);
+                v = fma(-1.0, acc, v);
+                rowoff += nxc;
+            }
+            hm[t] = v;
+            if (isx) D.qmod[xo + j] = v; else D.rmod[uo + j] = v;
+        }
+        __syncthreads();
+        const double *P = D.Pd + D.poff[k], *H = D.Hd + D.poff[k];
+        for (int t = lane; t < nz; t += WAVE) {
+            double acc = 0.0;
+            for (int j = 0; j < nz; j++) acc = fma(P[t + (size_t)j * nz], hm[j], acc);
+            zz[t] = acc;
+            if (t < nxk) { D.x[xo + t] = acc; D.xUnc[xo + t] = acc; } else { D.u[uo + t - nxk] = acc; D.uUnc[uo + t - nxk] = acc; }
+        }
+        __syncthreads();
+        double p_quad = 0.0, p_lin = 0.0, p_cd = 0.0;
+        for (int t = lane; t < nz; t += WAVE) {
+            double acc = 0.0;
+            for (int j = 0; j < nz; j++) acc = fma(H[t + (size_t)j * nz], zz[j], acc);
+            p_quad = fma(zz[t], acc, p_quad);
+            p_lin = fma(hm[t], zz[t], p_lin);
+        }
+        for (int t = lane; t < d; t += WAVE) p_cd = fma(D.b[ko + t], lk[t], p_cd);
+        p_quad = wave_sum(p_quad); p_lin = wave_sum(p_lin); p_cd = wave_sum(p_cd);
+        if (lane == 0) D.fval[k] = -0.5 * p_quad - p_cd + p_lin;
+        return;
+    }
 
     double p_qx = 0.0, p_hx = 0.0, p_ru = 0.0, p_hu = 0.0;   /* partial dots for the dual term */
     for (int t = lane; t < nxk + nuk; t += WAVE) {
@@ -299,13 +393,23 @@ __global__ void __launch_bounds__(WAVE) k_hess(Tree T, Data D, int h) {
         for (int e = lane; e < nxc * nz; e += WAVE) {
             const int i = e % nxc, col = e / nxc;
             const double a = col < nxp ? A[i + (size_t)col * nxc] : B[i + (size_t)(col - nxp) * nxc];
-            const double pc = col < nxp ? Qc[col] : Rc[col - nxp];
             Cs[rowoff + i + (size_t)col * d] = a;
-            CP[rowoff + i + (size_t)col * d] = a * pc;
+            if (!D.dense) { const double pc = col < nxp ? Qc[col] : Rc[col - nxp]; CP[rowoff + i + (size_t)col * d] = a * pc; }
         }
         rowoff += nxc;
     }
     __syncthreads();
+    if (D.dense) {
+        /* CP = C P_p with the dense elimination matrix of the parent (build_M of the qpOASES stage solver) */
+        const double *P = D.Pd + D.poff[p];
+        for (int e = lane; e < d * nz; e += WAVE) {
+            const int i = e % d, col = e / d;
+            double acc = 0.0;
+            for (int cidx = 0; cidx < nz; cidx++) acc = fma(Cs[i + (size_t)cidx * d], P[cidx + (size_t)col * nz], acc);
+            CP[i + (size_t)col * d] = acc;
+        }
+        __syncthreads();
+    }
     double *W = D.W + T.woff[p];
     for (int e = lane; e < d * d; e += WAVE) {
         const int i = e % d, j = e / d;
@@ -314,7 +418,16 @@ __global__ void __launch_bounds__(WAVE) k_hess(Tree T, Data D, int h) {
         for (int cidx = 0; cidx < nxp; cidx++) acc = fma(Cs[i + (size_t)cidx * d], CP[j + (size_t)cidx * d], acc);
         for (int cidx = nxp; cidx < nz; cidx++) acc2 = fma(Cs[i + (size_t)cidx * d], CP[j + (size_t)cidx * d], acc2);
         double w = acc + acc2;
-        if (i == j) w += D.QinvCal[ko + i];
+        if (!D.dense) { if (i == j) w += D.QinvCal[ko + i]; }
+        else {
+            /* add_EPmE: the state block of the child's own elimination matrix on the diagonal block */
+            int ro = 0;
+            for (int cc = 0; cc < T.nk[p]; cc++) {
+                const int kid = k0 + cc, nxc = T.nx[kid];
+                if (i >= ro && i < ro + nxc && j >= ro && j < ro + nxc) { const int nzk = nxc + T.nu[kid]; w += D.Pd[D.poff[kid] + (i - ro) + (size_t)(j - ro) * nzk]; }
+                ro += nxc;
+            }
+        }
         W[i + (size_t)j * d] = w;
     }
     if (p > 0) {
@@ -600,8 +713,8 @@ __global__ void __launch_bounds__(WAVE) k_ls_decide_parts(Data D, Opts O, const 
 /* export_mu (clipping.c:386-399): mu = Q .* (xUnc - x) */
 __global__ void k_export_mu(int n_x, int n_u, Data D, double *mu_x, double *mu_u) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_x) mu_x[i] = D.Qd[i] * fma(-1.0, D.x[i], D.xUnc[i]);
-    if (i < n_u) mu_u[i] = D.Rd[i] * fma(-1.0, D.u[i], D.uUnc[i]);
+    if (i < n_x) mu_x[i] = D.dense ? 0.0 : D.Qd[i] * fma(-1.0, D.x[i], D.xUnc[i]);      /* dense stage solver: unconstrained */
+    if (i < n_u) mu_u[i] = D.dense ? 0.0 : D.Rd[i] * fma(-1.0, D.u[i], D.uUnc[i]);
 }
 
 }  // namespace
@@ -615,7 +728,11 @@ struct tqgpu_solver {
     int Nn = 0, Np = 0, Nh = 0;
     std::vector<int> nk, nx, nu, dad, stage, kid0, xoff, uoff, aoff, boff, pos, bdim, woff, utoff, lvl_first;
     int sum_nx = 0, sum_nu = 0, sum_lam = 0, sum_A = 0, sum_B = 0, sum_W = 0, sum_Ut = 0, nx0 = 0;
-    size_t lds_stage = 0, lds_hess = 0, lds_factor = 0, lds_forward = 0;
+    size_t lds_stage = 0, lds_hess = 0, lds_factor = 0, lds_forward = 0, lds_dense = 0;
+    bool dense = false, need_dense_init = false;   /* dense unconstrained stage solver selected (generic path only) */
+    double *d_Hd = nullptr;      /* writable alias of Data.Hd */
+    std::vector<int> poff;
+    int use_fast_orig = 1;
     void *slab = nullptr;
     size_t slab_bytes = 0;
     Tree T{};
@@ -624,6 +741,7 @@ struct tqgpu_solver {
     double *d_lam_init = nullptr;   /* starting point of every solve (tqgpu_set_lambda) */
     unsigned launch_no = 0;         /* persistent launches so far (16 bits, never 0): tags of the hand-over words */
     void *pconst_slab = nullptr;    /* packed constants of the persistent path + its PDump */
+    int *wg_map = nullptr;          /* blockIdx.x -> workgroup id (XCD-aware placement) */
     double *pab = nullptr, *pcst = nullptr;
     bool need_pack = true;          /* QP data changed since the constants were packed */
     /* writable aliases of the const inputs */
@@ -737,7 +855,8 @@ int build_tables(tqgpu_solver *s) {
     s->lds_stage = s->lds_hess = s->lds_factor = s->lds_forward = 0;
     for (int k = 0; k < Nn; k++) {
         const size_t d = s->bdim[k], nz = s->nx[k] + s->nu[k];
-        s->lds_stage = std::max(s->lds_stage, (d + s->nx[k] + 2) * sizeof(double));
+        s->lds_stage = std::max(s->lds_stage, (d + s->nx[k] + 2 * (s->nx[k] + s->nu[k]) + 2) * sizeof(double));
+        s->lds_dense = std::max(s->lds_dense, ((size_t)(s->nx[k] + s->nu[k]) * (s->nx[k] + s->nu[k] + 1) + 2) * sizeof(double));
         if (k < s->Np) {
             s->lds_hess = std::max(s->lds_hess, (2 * d * nz + 2) * sizeof(double));
             const size_t R = d + 1 + (k > 0 ? s->nx[k] : 0), ld = R | 1;
@@ -1029,6 +1148,32 @@ int setup_persist(tqgpu_solver *s, int device) {
     s->psync.halt = reinterpret_cast<unsigned *>(s->psync.errs + n_errs);
     s->psync.timeout = s->psync.halt + 32;
     s->psync.seq = 0;
+    /* XCD-aware placement: the hardware deals workgroups round-robin over the 8 XCDs (workgroup b -> XCD b % 8)
+     * and every XCD has its own L2.  A tier subtree talks to its parent and its children only, so whole
+     * families go to one XCD: each subtree of the lowest tier with at most 8 subtrees picks an XCD, everything
+     * below follows its ancestor there; the tiers above (one workgroup each, typically) take what is left. */
+    {
+        const int NXCD = 8, Gn = G.G;
+        int anchor = s->n_tiers - 1;
+        for (int i = 0; i < s->n_tiers; i++) if (G.grid[i] <= NXCD) { anchor = i; break; }
+        std::vector<std::vector<int>> want(NXCD);
+        std::vector<int> rest;
+        for (int i = 0; i < s->n_tiers; i++)
+            for (int q = 0; q < G.grid[i]; q++) {
+                const int id = G.wg0[i] + q;
+                if (i <= anchor) want[(int)((long long)q * G.grid[anchor] / G.grid[i]) % NXCD].push_back(id);   /* subtree q of tier i sits under subtree q*grid[anchor]/grid[i] */
+                else rest.push_back(id);
+            }
+        std::vector<int> map((size_t)Gn, -1);
+        std::vector<size_t> next(NXCD, 0);
+        for (int b = 0; b < Gn; b++) { auto &w = want[b % NXCD]; if (next[b % NXCD] < w.size()) map[b] = w[next[b % NXCD]++]; }
+        for (int x = 0; x < NXCD; x++) for (size_t k = next[x]; k < want[x].size(); k++) rest.push_back(want[x][k]);
+        size_t r = 0;
+        for (int b = 0; b < Gn; b++) if (map[b] < 0) map[b] = rest[r++];
+        HIP_TRY(hipMalloc(&s->wg_map, sizeof(int) * (size_t)Gn));
+        HIP_TRY(hipMemcpy(s->wg_map, map.data(), sizeof(int) * (size_t)Gn, hipMemcpyHostToDevice));
+        G.wg_of_block = s->wg_map;
+    }
     /* packed constants + the start/end view of the mirror */
     const int nz = nx0 + s->nu[0];
     const size_t n_ab = (size_t)(s->Nn - 1) * nx0 * nz, n_cst = (size_t)s->Nn * 16 * 5;
@@ -1136,6 +1281,9 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
     const size_t o_sbuf = cv.take((s->fast >= 0 ? (size_t)Nn * (maxnx * maxnx + maxnx) : 1) * Dbl), o_ybuf = cv.take((SX + 1) * Dbl);
     const size_t o_mux = cv.take(SX * Dbl), o_muu = cv.take(SU * Dbl);
     const size_t o_lami = cv.take(SX * Dbl);
+    s->poff.assign(Nn + 1, 0);
+    for (int k = 0; k < Nn; k++) s->poff[k + 1] = s->poff[k] + (s->nx[k] + s->nu[k]) * (s->nx[k] + s->nu[k]);
+    const size_t o_poff = cv.take((Nn + 1) * I), o_Hd = cv.take((size_t)std::max(s->poff[Nn], 1) * Dbl), o_Pd = cv.take((size_t)std::max(s->poff[Nn], 1) * Dbl);
     const size_t o_ctrl = cv.take(sizeof(Ctrl));
     const size_t o_stamps = cv.take(8 * 32 * 2 * sizeof(unsigned long long));
     s->ls_log_cap = 4096;
@@ -1159,6 +1307,7 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
     UP(o_dad, s->dad); UP(o_nk, s->nk); UP(o_kid0, s->kid0); UP(o_nx, s->nx); UP(o_nu, s->nu);
     UP(o_xoff, s->xoff); UP(o_uoff, s->uoff); UP(o_aoff, s->aoff); UP(o_boff, s->boff);
     UP(o_pos, s->pos); UP(o_bdim, s->bdim); UP(o_woff, s->woff); UP(o_utoff, s->utoff);
+    UP(o_poff, s->poff);
 #undef UP
     Tree &T = s->T;
     T.Nn = Nn; T.Np = s->Np; T.Nh = s->Nh; T.nx0 = s->nx0;
@@ -1182,6 +1331,8 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
     D.Sbuf = at<double>(base, o_sbuf); D.ybuf = at<double>(base, o_ybuf);
     D.stamps = at<unsigned long long>(base, o_stamps);
     D.ctrl = at<Ctrl>(base, o_ctrl); D.ls_log = at<int>(base, o_log); D.ls_log_cap = s->ls_log_cap;
+    D.dense = 0; s->d_Hd = at<double>(base, o_Hd); D.Hd = s->d_Hd; D.Pd = at<double>(base, o_Pd); D.poff = at<int>(base, o_poff);
+    s->use_fast_orig = s->use_fast;
     s->d_mu_x = at<double>(base, o_mux); s->d_mu_u = at<double>(base, o_muu);
     s->d_lam_init = at<double>(base, o_lami);
 
@@ -1210,6 +1361,7 @@ extern "C" void tqgpu_destroy(tqgpu_solver *s) {
     if (s->shard_slab) (void)hipFree(s->shard_slab);
     if (s->sync_slab) (void)hipFree(s->sync_slab);
     if (s->pconst_slab) (void)hipFree(s->pconst_slab);
+    if (s->wg_map) (void)hipFree(s->wg_map);
     if (s->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(s->comm);
     if (s->slab) (void)hipFree(s->slab);
     delete s;
@@ -1259,6 +1411,39 @@ extern "C" int tqgpu_set_objective_diag(tqgpu_solver *s, const double *Qd, const
     HIP_TRY(hipStreamSynchronize(s->stream));
     s->need_init = true;
     s->need_pack = true;
+    if (s->dense) { s->dense = false; s->D.dense = 0; s->use_fast = s->use_fast_orig; }
+    return TQGPU_OK;
+}
+
+/* Dense objective for the dense UNCONSTRAINED stage solver (the reference's qpOASES stage backend restricted
+ * to nodes without bounds, dual_Newton_tree_qpoases.c:153-217,401-476).  Flat layout of
+ * tree_qp_in_set_ltv_objective_colmajor (tree_qp_common.c): per node Q (nx x nx), R (nu x nu), S (nu x nx),
+ * all column major, then q, r.  Selects the generic device path; tqgpu_set_objective_diag selects clipping again. */
+extern "C" int tqgpu_set_objective_dense(tqgpu_solver *s, const double *Q, const double *R, const double *S, const double *q, const double *r) {
+    if (!s || !Q || !q) return fail(TQGPU_EINVAL, "tqgpu_set_objective_dense: bad arguments");
+    if (s->nranks > 1) return fail(TQGPU_EINVAL, "the dense stage solver is not available in sharded mode");
+    HIP_TRY(hipSetDevice(s->device));
+    std::vector<double> H((size_t)std::max(s->poff[s->Nn], 1), 0.0);
+    size_t oq = 0, orr = 0, os = 0;
+    for (int k = 0; k < s->Nn; k++) {
+        const int nx = s->nx[k], nu = s->nu[k], nz = nx + nu;
+        double *Hk = H.data() + s->poff[k];
+        for (int j = 0; j < nx; j++) for (int i = 0; i < nx; i++) Hk[i + (size_t)j * nz] = Q[oq + i + (size_t)j * nx];
+        for (int j = 0; j < nu; j++) for (int i = 0; i < nu; i++) Hk[nx + i + (size_t)(nx + j) * nz] = R ? R[orr + i + (size_t)j * nu] : 0.0;
+        for (int j = 0; j < nx; j++) for (int i = 0; i < nu; i++) {          /* S is nu x nx */
+            const double v = S ? S[os + i + (size_t)j * nu] : 0.0;
+            Hk[nx + i + (size_t)j * nz] = v;
+            Hk[j + (size_t)(nx + i) * nz] = v;
+        }
+        oq += (size_t)nx * nx; orr += (size_t)nu * nu; os += (size_t)nu * nx;
+    }
+    H2D(s->d_Hd, H.data(), s->poff[s->Nn]);
+    H2D(s->q, q, s->sum_nx); H2D(s->r, r, s->sum_nu);
+    HIP_TRY(hipMemsetAsync(s->Qd, 0, sizeof(double) * (size_t)std::max(s->sum_nx, 1), s->stream));
+    HIP_TRY(hipMemsetAsync(s->Rd, 0, sizeof(double) * (size_t)std::max(s->sum_nu, 1), s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    s->dense = true; s->need_dense_init = true; s->D.dense = 1;
+    s->use_fast = 0;                                       /* per-node dense blocks: generic kernels */
     return TQGPU_OK;
 }
 
@@ -1351,9 +1536,13 @@ extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *r
     s->solve_no++;
     HIP_TRY(hipEventRecord(ev0, st));
     if (!persist) HIP_TRY(hipMemsetAsync(D.ctrl, 0, sizeof(Ctrl), st));     /* persistent path: zeroed with its inter-workgroup words */
-    if (s->need_init) {
+    if (s->need_init && !s->dense) {
         hipLaunchKernelGGL(k_init, dim3((nxu + 255) / 256), dim3(256), 0, st, s->sum_nx, s->sum_nu, D); launches++;
         s->need_init = false;
+    }
+    if (s->dense && s->need_dense_init) {
+        hipLaunchKernelGGL(k_dense_init, dim3(T.Nn), dim3(WAVE), s->lds_dense, st, T, D); launches++;
+        s->need_dense_init = false;
     }
     if (!persist) {
         /* the current buffer is lam0 at the start of every solve */

@@ -100,13 +100,18 @@ __device__ __forceinline__ double ld_tag(const u64 *p, unsigned tag, bool &ok) {
     ok = ok && (unsigned)(a >> 32) == tag && (unsigned)(b >> 32) == tag;
     return __hiloint2double((int)(unsigned)b, (int)(unsigned)a);
 }
-/* between two polls: false when the launch is over (halt / timeout) and the poller must give up */
-__device__ __forceinline__ bool spin_on(const PSync &Sy, u64 t0) {
-    if (__hip_atomic_load(Sy.halt, RLX, AGENT) == Sy.seq || __hip_atomic_load(Sy.timeout, RLX, AGENT)) return false;
-    if (wall_clock64() - t0 > 50000000ull) { __hip_atomic_store(Sy.timeout, 1u, RLX, AGENT); return false; }   /* 0.5 s at 100 MHz */
-    __builtin_amdgcn_s_sleep(1);
-    return true;
-}
+/* Poll loops read the payload AND the two "launch is over" words in the same round trip (the loads are
+ * independent, so they are in flight together); a poll iteration is then one memory latency long and needs
+ * no sleep.  `over` = halt word == launch number or timeout word set; false = give up. */
+struct PollGuard {
+    unsigned h, tmo;
+    __device__ __forceinline__ void load(const PSync &Sy) { h = __hip_atomic_load(Sy.halt, RLX, AGENT); tmo = __hip_atomic_load(Sy.timeout, RLX, AGENT); }
+    __device__ __forceinline__ bool go_on(const PSync &Sy, u64 t0) const {
+        if (h == Sy.seq || tmo) return false;
+        if (wall_clock64() - t0 > 50000000ull) { __hip_atomic_store(Sy.timeout, 1u, RLX, AGENT); return false; }   /* 0.5 s at 100 MHz */
+        return true;
+    }
+};
 
 template <int NX, int NU, int MD>
 struct PLds {
@@ -180,9 +185,11 @@ __device__ __forceinline__ void p_gh_load(const PConst &C, const PSync &Sy, cons
         const u64 t0 = wall_clock64();
         bool ok;
         for (;;) {
+            PollGuard pg;
             ok = true;
             xv = ld_tag(src, tag, ok); qv = ld_tag(src + 2 * NX, tag, ok);
-            if (ok || !spin_on(Sy, t0)) break;
+            pg.load(Sy);
+            if (ok || !pg.go_on(Sy, t0)) break;
         }
         if (!ok) *L.abort = 1;
     } else if (foreign) { const PDump *dp = C.dump; xv = dp->x[bo + rowc]; qv = dp->QinvCal[bo + rowc]; }   /* relaunch: staged by earlier kernels */
@@ -388,10 +395,12 @@ __device__ __forceinline__ double p_forward(const PSync &Sy, PLds<NX, NU, MD> &L
         const u64 *src = Sy.dlt + (size_t)NX * ii * 2;
         const u64 t0 = wall_clock64();
         for (;;) {
+            PollGuard pg;
             ok = true;
 #pragma unroll
             for (int r = 0; r < NX; r++) dv[r] = ld_tag(src + 2 * r, tag, ok);
-            if (ok || !spin_on(Sy, t0)) break;
+            pg.load(Sy);
+            if (ok || !pg.go_on(Sy, t0)) break;
         }
         ok = __all(ok);
         if (!ok) *L.abort = 1;                            /* the launch is over: nothing below may leave the workgroup */
@@ -517,6 +526,8 @@ struct PGeom {
     int n_tiers;
     int l0[8], l1[8], grid[8], wg0[8];      /* per tier: block levels [l0,l1), subtrees, first workgroup id */
     int G;
+    const int *wg_of_block;                 /* blockIdx.x -> workgroup id: families of tier subtrees share an XCD (hardware
+                                               places workgroup b on XCD b % 8), so most hand-overs stay inside one L2 */
 };
 
 /* diagnostic stamps of the persistent kernel: first workgroup of every tier, thread 0, iteration O.stamps of the launch */
@@ -542,6 +553,7 @@ __device__ __forceinline__ bool p_sub_children_tagged(const PSync &Sy, const u64
     const u64 t0 = wall_clock64();
     bool ok;
     for (;;) {
+        PollGuard pg;
         ok = true;
 #pragma unroll
         for (int c = 0; c < MD; c++) {
@@ -549,8 +561,9 @@ __device__ __forceinline__ bool p_sub_children_tagged(const PSync &Sy, const u64
 #pragma unroll
             for (int j = 0; j < NX; j++) v[c][j] = ld_tag(src + (size_t)j * stride * 2, tag, ok);
         }
+        pg.load(Sy);
         ok = ok || !need;
-        if (ok || !spin_on(Sy, t0)) break;
+        if (ok || !pg.go_on(Sy, t0)) break;
     }
 #pragma unroll
     for (int c = 0; c < MD; c++) {
@@ -597,10 +610,12 @@ __device__ __forceinline__ bool p_gather3(const PSync &Sy, PLds<NX, NU, MD> &L, 
             double f = 0.0, d = 0.0, er;
             bool ok;
             for (;;) {
+                PollGuard pg;
                 ok = true;
                 if (want_parts) { f = ld_tag(pp, tag_p, ok); d = ld_tag(pp + 2, tag_p, ok); }
                 er = ld_tag(pe, tag_e, ok);
-                if (ok || !spin_on(Sy, t0)) break;
+                pg.load(Sy);
+                if (ok || !pg.go_on(Sy, t0)) break;
             }
             if (!ok) *L.abort = 1;
             L.sch[3 * w] = f; L.sch[3 * w + 1] = d; L.sch[3 * w + 2] = er;
@@ -623,7 +638,7 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(PConst C, Opts O, PGeom G
     Ctrl *c = C.ctrl;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     PLds<NX, NU, MD> L(lds_all, wave);
-    const int wg = blockIdx.x;
+    const int wg = Gm.wg_of_block[blockIdx.x];
     /* my tier / subtree */
     int tier = 0;
     for (int i = 0; i < Gm.n_tiers; i++) if (wg >= Gm.wg0[i]) tier = i;

@@ -110,6 +110,8 @@ static int staging_doubles(const tree_qp_in *qp_in)
     size_t d = 0;
     for (int k = 0; k < Nn; k++) {
         d += 4 * (size_t)qp_in->nx[k] + 4 * (size_t)qp_in->nu[k];
+        /* dense stage solver: Q, R, S flattened */
+        d += (size_t)(qp_in->nx[k] + qp_in->nu[k]) * (qp_in->nx[k] + qp_in->nu[k]);
         if (k > 0) {
             const int p = qp_in->tree[k].dad;
             d += (size_t)qp_in->nx[k] * (qp_in->nx[p] + qp_in->nu[p] + 1);
@@ -151,6 +153,19 @@ static void require_clipping_applicable(const tree_qp_in *qp_in, int k)
         fatal("Specified stage QP solver (clipping) not applicable.", NULL);
 }
 
+/* The dense stage solver of this build covers unconstrained nodes only (bounds at +-inf as written by
+ * tree_qp_in_set_inf_bounds, no general constraints); constrained dense stage QPs need an active-set QP
+ * solver (qpOASES in the reference), which is out of scope. */
+static int is_inf_bound(double lo, double hi) { return lo <= -1e12 && hi >= 1e12; }
+static void require_dense_unconstrained(const tree_qp_in *qp_in, int k)
+{
+    int ok = qp_in->nc[k] == 0;
+    for (int j = 0; ok && j < qp_in->nx[k]; j++) ok = is_inf_bound(BLASFEO_DVECEL(&qp_in->xmin[k], j), BLASFEO_DVECEL(&qp_in->xmax[k], j));
+    for (int j = 0; ok && j < qp_in->nu[k]; j++) ok = is_inf_bound(BLASFEO_DVECEL(&qp_in->umin[k], j), BLASFEO_DVECEL(&qp_in->umax[k], j));
+    if (!ok)
+        fatal("TREEQP_QPOASES_SOLVER is available for unconstrained nodes only in the MI355X build (dense stage solver; qpOASES itself is out of scope).", NULL);
+}
+
 void treeqp_tdunes_create(const tree_qp_in *qp_in, const treeqp_tdunes_opts_t *opts,
     treeqp_tdunes_workspace *work, void *ptr)
 {
@@ -165,13 +180,20 @@ void treeqp_tdunes_create(const tree_qp_in *qp_in, const treeqp_tdunes_opts_t *o
     work->Np = Np;
     work->maxIterAtCreate = opts->maxIter;
 
+    /* Stage solvers (dual_Newton_tree.c:1399-1425 dispatches per node): clipping, or -- under the reference's
+     * TREEQP_QPOASES_SOLVER selector -- the dense stage solver for UNCONSTRAINED nodes (the part of that backend
+     * that needs no active-set QP solver: z = H^-1 h, P = H^-1).  One kind for the whole tree. */
+    int n_dense = 0;
     for (int k = 0; k < Nn; k++) {
         /* the solver (like the reference, dual_Newton_tree.c:675,1377) needs parents == nodes 0..Np-1 */
         if ((tree[k].nkids > 0) != (k < Np)) fatal("tdunes needs all leaves at the same depth.", NULL);
-        if (opts->qp_solver[k] != TREEQP_CLIPPING_SOLVER)
-            fatal("Only TREEQP_CLIPPING_SOLVER stage QPs are available in the MI355X build (qpOASES backend is out of scope).", NULL);
-        require_clipping_applicable(qp_in, k);
+        if (opts->qp_solver[k] == TREEQP_CLIPPING_SOLVER) require_clipping_applicable(qp_in, k);
+        else if (opts->qp_solver[k] == TREEQP_QPOASES_SOLVER) { require_dense_unconstrained(qp_in, k); n_dense++; }
+        else fatal("Unknown stage QP solver.", NULL);
     }
+    if (n_dense != 0 && n_dense != Nn)
+        fatal("Mixing stage QP solvers across nodes is not available in the MI355X build.", NULL);
+    work->denseStageSolver = n_dense == Nn;
 
     /* integer tables: dual_Newton_tree.c:166-194 */
     work->npar = (int *)c_ptr; c_ptr += (size_t)(Nh + 1) * sizeof(int);
@@ -344,8 +366,18 @@ return_t treeqp_tdunes_solve(const tree_qp_in *qp_in, tree_qp_out *qp_out,
     assert(stage <= work->stage + work->stage_doubles);
 
     DEV_CALL(tqgpu_set_dynamics(work->device, A, B, b));
-    DEV_CALL(tqgpu_set_objective_diag(work->device, Qd, Rd, q, r));
-    DEV_CALL(tqgpu_set_bounds(work->device, xmin, xmax, umin, umax));
+    if (work->denseStageSolver) {
+        /* flat Q, R, S in the order of tree_qp_in_set_ltv_objective_colmajor; bounds are re-checked, not uploaded */
+        double *Qf = stage; for (int k = 0; k < Nn; k++) for (int j = 0; j < qp_in->nx[k]; j++) for (int i = 0; i < qp_in->nx[k]; i++) *stage++ = BLASFEO_DMATEL(&qp_in->Q[k], i, j);
+        double *Rf = stage; for (int k = 0; k < Nn; k++) for (int j = 0; j < qp_in->nu[k]; j++) for (int i = 0; i < qp_in->nu[k]; i++) *stage++ = BLASFEO_DMATEL(&qp_in->R[k], i, j);
+        double *Sf = stage; for (int k = 0; k < Nn; k++) for (int j = 0; j < qp_in->nx[k]; j++) for (int i = 0; i < qp_in->nu[k]; i++) *stage++ = BLASFEO_DMATEL(&qp_in->S[k], i, j);
+        assert(stage <= work->stage + work->stage_doubles);
+        for (int k = 0; k < Nn; k++) require_dense_unconstrained(qp_in, k);
+        DEV_CALL(tqgpu_set_objective_dense(work->device, Qf, Rf, Sf, q, r));
+    } else {
+        DEV_CALL(tqgpu_set_objective_diag(work->device, Qd, Rd, q, r));
+        DEV_CALL(tqgpu_set_bounds(work->device, xmin, xmax, umin, umax));
+    }
     /* warm start from whatever slambda holds (set_dual_initialization or the previous solve) */
     DEV_CALL(tqgpu_set_lambda(work->device, flat_of_vecs(work->slambda, Np, &stage)));
 
