@@ -43,3 +43,36 @@ def assert_solution_close(got: dict, ref: dict, tol=1e-10, keys=("x", "u", "lam"
     for k in keys:
         e = rel_err(got[k], ref[k])
         assert e <= tol, f"{k}: relative error {e:.3e} > {tol:.1e}"
+
+
+def flat_to_json(flat: dict, options: dict | None = None) -> dict:
+    """Flat ("ltv" order) clipping QP -> the qp_in.json wire format of the reference's JSON front end
+    (examples/solve_qp_json.cpp): nodes {Q,R,S,q,r,lx,lu,ux,uu}, edges {from,to,A,B,b}, matrices as arrays of rows."""
+    nk, nx, nu = [np.asarray(flat[k], dtype=int) for k in ("nk", "nx", "nu")]
+    Nn = len(nk)
+    dad = np.full(Nn, -1)
+    c = 1
+    for k in range(Nn):
+        for _ in range(nk[k]):
+            dad[c] = k
+            c += 1
+    xo, uo = np.concatenate([[0], np.cumsum(nx)]), np.concatenate([[0], np.cumsum(nu)])
+    rows = lambda v, m, n: np.asarray(v, dtype=float).reshape((m, n), order="F").tolist()
+    nodes, edges = [], []
+    for k in range(Nn):
+        sx, su = slice(xo[k], xo[k + 1]), slice(uo[k], uo[k + 1])
+        nodes.append(dict(Q=np.diag(flat["Qd"][sx]).tolist(), R=np.diag(flat["Rd"][su]).tolist(),
+                          S=np.zeros((nu[k], nx[k])).tolist(), q=list(map(float, flat["q"][sx])), r=list(map(float, flat["r"][su])),
+                          lx=list(map(float, flat["xmin"][sx])), ux=list(map(float, flat["xmax"][sx])),
+                          lu=list(map(float, flat["umin"][su])), uu=list(map(float, flat["umax"][su]))))
+    ao = bo = lo = 0
+    for k in range(1, Nn):
+        p = dad[k]
+        na, nb = nx[k] * nx[p], nx[k] * nu[p]
+        edges.append({"from": int(p), "to": int(k), "A": rows(flat["A"][ao:ao + na], nx[k], nx[p]),
+                      "B": rows(flat["B"][bo:bo + nb], nx[k], nu[p]), "b": list(map(float, flat["b"][lo:lo + nx[k]]))})
+        ao += na; bo += nb; lo += nx[k]
+    out = dict(nodes=nodes, edges=edges)
+    if options is not None:
+        out["options"] = options
+    return out

@@ -126,3 +126,36 @@ def test_eliminate_x0_and_update(capi, orc):
     assert sol["status"] == 0
     qp.set_solution(sol)
     assert qp.max_kkt_res() < 1e-10
+
+
+# ---- JSON front end (treeqp_solve_json): parsing needs no device --------------------------------
+
+def _json_tool():
+    from pathlib import Path
+    exe = Path(__file__).resolve().parent.parent / "treeqp_amd" / "lib" / "treeqp_solve_json"
+    if not exe.exists():
+        pytest.skip("treeqp_solve_json was not built")
+    return exe
+
+
+@pytest.mark.parametrize("i", range(6))
+def test_json_front_end_reads_reference_fixture_dims(i):
+    """examples/random_qp_utils/data0<i>.json: dimensions and tree shape as the Python loader sees them."""
+    import json, subprocess
+    from pathlib import Path
+    from treeqp_amd import problems as P
+    f = P.random_qp_fixture(i)
+    path = Path(__file__).resolve().parent / "golden" / f"random_qp_data0{i}.json"
+    out = subprocess.run([str(_json_tool()), "--dims", str(path)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    d = json.loads(out.stdout)
+    assert d["Nn"] == len(f["nk"]) and d["nx"] == list(map(int, f["nx"])) and d["nu"] == list(map(int, f["nu"]))
+    assert d["nk"] == list(map(int, f["nk"])) and d["has_options"] is False
+
+
+def test_json_front_end_rejects_malformed_input(tmp_path):
+    import subprocess
+    bad = tmp_path / "bad.json"
+    bad.write_text('{"nodes": [{"q": [1, 2], "r": []}], "edges": [')
+    out = subprocess.run([str(_json_tool()), "--dims", str(bad)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 2 and "solve_qp_json" in out.stderr

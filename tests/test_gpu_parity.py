@@ -5,6 +5,7 @@ front end (treeqp_tdunes_*) or the thin device ABI (tqgpu_*).  Tolerance: 1e-10 
 x, u, lambda, mu (north_star: "within 1e-10 relative on KKT residuals"), identical Newton
 iteration counts; integer tables are bit-exact.
 """
+import json
 import os
 import shutil
 import subprocess
@@ -412,3 +413,50 @@ def test_random_qp_goldens_dense_on_device(gpu, orc, i):
     ref = orc.solve_dense(f, orc.default_opts(maxIter=10, stationarityTolerance=1e-10, regType=0))
     assert r["iter"] == ref["iter"]
     assert np.max(np.abs(sol["lam"] - ref["lam"])) < 1e-11
+
+
+# ---- JSON front end: qp_in.json [init.json] -> qp_out.json -------------------------------
+
+def _run_json_tool(args, tmp_path):
+    exe = ROOT / "treeqp_amd" / "lib" / "treeqp_solve_json"
+    assert exe.exists(), "treeqp_solve_json was not built"
+    out = subprocess.run([str(exe), *map(str, args)], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    return json.loads(out.stdout)
+
+
+@pytest.mark.parametrize("i", range(6))
+def test_json_front_end_replays_reference_fixtures(gpu, tmp_path, i):
+    """The reference's unit-test fixtures straight from their JSON files (dense, unconstrained): x, u = goldens to 1e-12."""
+    f = P.random_qp_fixture(i)
+    d = _run_json_tool([ROOT / "tests" / "golden" / f"random_qp_data0{i}.json"], tmp_path)
+    x = np.concatenate([np.atleast_1d(np.asarray(n["x"], dtype=float)) for n in d["solution"]["nodes"]])
+    u = np.concatenate([np.atleast_1d(np.asarray(n["u"], dtype=float)) for n in d["solution"]["nodes"]])
+    assert d["info"]["solver"] == "tdunes" and d["info"]["status"] == 0 and d["info"]["num_iter"] in (0, 1)
+    assert np.max(np.abs(x - f["xopt"])) < 1e-12 and np.max(np.abs(u - f["uopt"])) < 1e-12
+    assert d["info"]["kkt_tol"] < 1e-12
+    assert len(d["init"]["lam0_tree"]) == int(np.sum(f["nx"][1:]))
+
+
+def test_json_front_end_clipping_with_init_file(gpu, orc, tmp_path):
+    """Clipping stage solver through the wire format: bounds, options, x0 + lam0_tree from the init file, x0 eliminated."""
+    from helpers import flat_to_json
+    p = P.spring_mass(md=2, Nr=2, Nh=4)
+    flat = oracle_flat_from_lti(orc, p)                                         # x0 pinned by equal bounds on node 0
+    rng = np.random.Generator(np.random.PCG64(5))
+    lam0 = 0.1 * rng.standard_normal(len(p.lambda0))
+    opts = dict(solver="tdunes", maxit=50, stationarityTolerance=1e-9, lineSearchMaxIter=40, lineSearchBeta=0.7, lineSearchGamma=0.1,
+                checkLastActiveSet=1, clipping=True, regType="TREEQP_ALWAYS_LEVENBERG_MARQUARDT", regTol=1e-6, regValue=1e-8)
+    (tmp_path / "qp_in.json").write_text(json.dumps(flat_to_json(flat, opts)))
+    x0 = flat["xmin"][: flat["nx"][0]]
+    (tmp_path / "init.json").write_text(json.dumps(dict(x0=list(map(float, x0)), lam0_tree=list(map(float, lam0)))))
+    d = _run_json_tool([tmp_path / "qp_in.json", tmp_path / "init.json"], tmp_path)
+    ref = orc.solve(flat, orc.default_opts(maxIter=50, stationarityTolerance=1e-9, lineSearchMaxIter=40, lineSearchBeta=0.7,
+                                           lineSearchGamma=0.1, regType=1, regTol=1e-6, regValue=1e-8), lam0)
+    x = np.concatenate([np.atleast_1d(np.asarray(n["x"], dtype=float)) for n in d["solution"]["nodes"]])
+    u = np.concatenate([np.atleast_1d(np.asarray(n["u"], dtype=float)) for n in d["solution"]["nodes"]])
+    lam = np.concatenate([np.atleast_1d(np.asarray(e["lam"], dtype=float)) for e in d["solution"]["edges"]])
+    assert d["info"]["status"] == ref["status"] == 0 and d["info"]["num_iter"] == ref["iter"]
+    assert np.max(np.abs(x - ref["x"])) < 1e-9 and np.max(np.abs(u - ref["u"])) < 1e-9 and np.max(np.abs(lam - ref["lam"])) < 1e-8
+    assert np.allclose(d["init"]["lam0_tree"], lam, rtol=0, atol=0)              # tdunes_update_multipliers: the next warm start
+    assert d["info"]["kkt_tol"] < 1e-8

@@ -76,6 +76,12 @@ def build_product(force: bool = False) -> Path:
     lib = product_library()
     if force or _newer(lib, objs):
         _run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", *objs, "-o", lib, "-lm"])
+    # the JSON front end (qp_in.json -> qp_out.json), a small C program on top of the library
+    tool_src = CSRC / "host" / "solve_qp_json.c"
+    tool = LIBDIR / "treeqp_solve_json"
+    if force or _newer(tool, [tool_src, lib] + headers):
+        _run(["gcc", "-O2", "-std=gnu99", "-Wall", f"-I{INCLUDE}", tool_src, "-o", tool,
+              f"-L{LIBDIR}", "-ltreeqp_amd", "-Wl,-rpath,$ORIGIN", "-lm"])
     return lib
 
 

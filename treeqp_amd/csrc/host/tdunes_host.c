@@ -307,22 +307,29 @@ static const double *flat_of_vecs(const struct blasfeo_dvec *v, int n, double **
     *stage += total;
     return out;
 }
-/* writable variant for outputs: returns the region start if contiguous, else NULL */
-static double *flat_out(struct blasfeo_dvec *v, int n)
+/* writable variant for outputs: returns the region start if the views the solver writes (dims[i] > 0
+ * entries each; dims == NULL: the views' own sizes) are contiguous and exactly that long, else NULL.
+ * The solver's dimensions rule: after tree_qp_in_eliminate_x0 the caller's qp_out may still carry an
+ * x[0] of the original size (solve_qp_json.cpp never shrinks it), which then is simply not written,
+ * as in the reference's per-node blasfeo_dveccp (dual_Newton_tree.c:1235-1247). */
+static double *flat_out(struct blasfeo_dvec *v, int n, const int *dims)
 {
     double *first = NULL, *expect = NULL;
     for (int i = 0; i < n; i++) {
-        if (v[i].m == 0 || !v[i].pa) continue;
+        const int m = dims ? dims[i] : v[i].m;
+        if (m == 0 || !v[i].pa) continue;
+        if (v[i].m != m) return NULL;
         if (!first) first = v[i].pa; else if (v[i].pa != expect) return NULL;
-        expect = v[i].pa + v[i].m;
+        expect = v[i].pa + m;
     }
     return first;
 }
-static void scatter(const double *flat, struct blasfeo_dvec *v, int n)
+static void scatter(const double *flat, struct blasfeo_dvec *v, int n, const int *dims)
 {
     for (int i = 0; i < n; i++) {
-        if (v[i].m == 0 || !v[i].pa) continue;
-        memcpy(v[i].pa, flat, (size_t)v[i].m * sizeof(double)); flat += v[i].m;
+        const int m = dims ? dims[i] : v[i].m;
+        if (m == 0 || !v[i].pa) continue;
+        memcpy(v[i].pa, flat, (size_t)m * sizeof(double)); flat += m;
     }
 }
 
@@ -411,20 +418,20 @@ return_t treeqp_tdunes_solve(const tree_qp_in *qp_in, tree_qp_out *qp_out,
 
     /* --- export (:1235-1247) */
     treeqp_tic(&interface_tmr);
-    double *ox = flat_out(qp_out->x, Nn), *ou = flat_out(qp_out->u, Nn), *ol = flat_out(qp_out->lam, Nn - 1);
-    double *omx = flat_out(qp_out->mu_x, Nn), *omu = flat_out(qp_out->mu_u, Nn);
-    double *wx = flat_out(work->sx, Nn), *wl = flat_out(work->slambda, Np), *wd = flat_out(work->sDeltalambda, Np);
+    double *ox = flat_out(qp_out->x, Nn, qp_in->nx), *ou = flat_out(qp_out->u, Nn, qp_in->nu), *ol = flat_out(qp_out->lam, Nn - 1, NULL);
+    double *omx = flat_out(qp_out->mu_x, Nn, qp_in->nx), *omu = flat_out(qp_out->mu_u, Nn, qp_in->nu);
+    double *wx = flat_out(work->sx, Nn, NULL), *wl = flat_out(work->slambda, Np, NULL), *wd = flat_out(work->sDeltalambda, Np, NULL);
     int sum_nx = 0, sum_nu = 0, sum_lam = 0;
     tqgpu_dims(work->device, &sum_nx, &sum_nu, &sum_lam, NULL, NULL);
     /* download once into the workspace mirrors (always contiguous), then fan out */
-    double *wu = flat_out(work->su, Nn);
+    double *wu = flat_out(work->su, Nn, NULL);
     double *tmp_mx = work->stage, *tmp_mu = work->stage + sum_nx;
     DEV_CALL(tqgpu_get_solution(work->device, wx, wu, wl, omx ? omx : tmp_mx, omu ? omu : tmp_mu, wd));
-    if (ox) { if (sum_nx) memcpy(ox, wx, sizeof(double) * (size_t)sum_nx); } else scatter(wx, qp_out->x, Nn);
-    if (ou) { if (sum_nu) memcpy(ou, wu, sizeof(double) * (size_t)sum_nu); } else scatter(wu, qp_out->u, Nn);
-    if (ol) { if (sum_lam) memcpy(ol, wl, sizeof(double) * (size_t)sum_lam); } else scatter(wl, qp_out->lam, Nn - 1);
-    if (!omx) scatter(tmp_mx, qp_out->mu_x, Nn);
-    if (!omu) scatter(tmp_mu, qp_out->mu_u, Nn);
+    if (ox) { if (sum_nx) memcpy(ox, wx, sizeof(double) * (size_t)sum_nx); } else scatter(wx, qp_out->x, Nn, qp_in->nx);
+    if (ou) { if (sum_nu) memcpy(ou, wu, sizeof(double) * (size_t)sum_nu); } else scatter(wu, qp_out->u, Nn, qp_in->nu);
+    if (ol) { if (sum_lam) memcpy(ol, wl, sizeof(double) * (size_t)sum_lam); } else scatter(wl, qp_out->lam, Nn - 1, NULL);
+    if (!omx) scatter(tmp_mx, qp_out->mu_x, Nn, qp_in->nx);
+    if (!omu) scatter(tmp_mu, qp_out->mu_u, Nn, qp_in->nu);
 
     qp_out->info.iter = res.iter;
     qp_out->info.solver_time = solver_time;
