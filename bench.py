@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", choices=["batch", "shard"], default="batch", help="N > 1: independent trees (weak) or one sharded tree (strong)")
+    ap.add_argument("--trees", type=int, default=1, help="independent trees per GPU solved by one batched call per step (throughput mode; default 1 = the latency metric)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -106,7 +107,19 @@ def main():
     qp = capi.TreeQp(nx, nu, nk).fill_lti(p)
     flat = qp.flat()
     g = capi.TqGpu(nk, nx, nu, device=local_rank if world > 1 else -1).upload(flat, p.lambda0)
+    extra = [capi.TqGpu(nk, nx, nu, device=local_rank if world > 1 else -1).upload(flat, p.lambda0) for _ in range(max(0, args.trees - 1))]
+    mirrors = [g] + extra
     shard = world > 1 and args.mode == "shard"
+    if shard and extra:
+        raise SystemExit("--trees > 1 is a batch-mode option")
+
+    def solve_step():
+        """One step: every tree of this rank once; returns (iterations, line-search trials, launches, last result)."""
+        if not extra:
+            r = g.solve()
+            return r["iter"], r["ls_total"], r["n_launches"], r
+        rs = capi.solve_batch(mirrors)
+        return sum(r["iter"] for r in rs), sum(r["ls_total"] for r in rs), sum(r["n_launches"] for r in rs), rs[0]
     if shard:
         import torch
         idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
@@ -123,7 +136,7 @@ def main():
 
     r = None
     for _ in range(args.warmup):
-        r = g.solve()
+        r = solve_step()[3]
     barrier()
     t0 = time.perf_counter()
     dev_time = 0.0
@@ -132,10 +145,10 @@ def main():
     launches = 0
     pending = 0
     for _ in range(args.steps):
-        r = g.solve()               # returns when the verdict (status, iteration count) is on the host
-        iters += r["iter"]
-        ls += r["ls_total"]
-        launches += r["n_launches"]
+        it_, ls_, la_, r = solve_step()   # returns when the verdict (status, iteration count) of every tree is on the host
+        iters += it_
+        ls += ls_
+        launches += la_
         pending += 1
         if pending == 256:          # HIP-event times of the solves, fetched in batches (each fetch synchronises the stream)
             dev_time += float(g.device_times(pending).sum())
@@ -164,12 +177,12 @@ def main():
         import ctypes as C
         qp.set_solution(sol)
         kkt = qp.max_kkt_res()
-        it_per_solve = iters / args.steps
+        it_per_solve = iters / args.steps / len(mirrors)
         ls_per_iter = ls / max(iters, 1)
         bytes_it, flops_it = g.iteration_cost(max(1, round(ls_per_iter)))
         # dominant kernel: one f_persist launch = one solve (persistent path); algorithmic bytes per launch =
         # closed-form bytes per Newton iteration x the iterations of the launch, over the launch's duration
-        achieved = bytes_it * iters / dev_time / 1e9
+        achieved = bytes_it * (iters / len(mirrors)) / dev_time / 1e9          # one tree's launches (mirror 0)
         traffic = None
         tf = ROOT / "profiles" / f"traffic_{args.workload}.json"
         if tf.exists() and g.path == 2:
@@ -190,7 +203,7 @@ def main():
             "config": {"workload": f"{args.workload}: {desc}", "nodes": int(p.Nn), "newton_iter_per_solve": it_per_solve,
                        "ls_trials_per_iter": ls_per_iter, "ms_per_newton_iter": 1e3 * tmax / max(iters, 1),
                        "device_ms_per_newton_iter": 1e3 * dev_time / max(iters, 1),
-                       "kernel_launches_per_solve": launches / args.steps, "max_kkt_residual": kkt,
+                       "kernel_launches_per_solve": launches / args.steps / len(mirrors), "max_kkt_residual": kkt, "trees_per_gpu": len(mirrors),
                        "parallelism": ("one tree sharded by subtrees, 2 RCCL all-gathers per Newton iteration" if shard else
                                        "1 tree per GPU (independent scenario trees), no collective") if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -205,7 +218,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(p, flat)
         print(json.dumps(out), flush=True)
-    g.close()
+    for m in mirrors:
+        m.close()
     if dist is not None:
         dist.destroy_process_group()
 

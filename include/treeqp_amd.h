@@ -117,6 +117,11 @@ int tqgpu_shard_gather_solution(tqgpu_solver *s);
 /* test / diagnostic: n virtual ranks of one tree in one process on one device, lock-step */
 int tqgpu_solve_virtual_ranks(tqgpu_solver **ranks, int n, const tqgpu_opts *opts, tqgpu_result *res);
 
+/* Batched multi-tree solve: n independent mirrors with the same options (examples/fault_tolerance.c:486-530
+ * holds one tree_qp_in / workspace pair per configuration and solves them one after the other).  Mirrors whose
+ * solve is a single persistent launch run concurrently, as many as fit on the device at once. */
+int tqgpu_solve_batch(tqgpu_solver **solvers, int n, const tqgpu_opts *opts, tqgpu_result *results);
+
 /* Device times [s] of the last n solves (oldest first), measured with HIP events on the solver's
  * stream around everything a solve enqueues; synchronises the stream; returns the number written
  * (at most 512 solves back) or -1.  tqgpu_result.device_time of a single-launch (persistent) solve is

@@ -460,3 +460,28 @@ def test_json_front_end_clipping_with_init_file(gpu, orc, tmp_path):
     assert np.max(np.abs(x - ref["x"])) < 1e-9 and np.max(np.abs(u - ref["u"])) < 1e-9 and np.max(np.abs(lam - ref["lam"])) < 1e-8
     assert np.allclose(d["init"]["lam0_tree"], lam, rtol=0, atol=0)              # tdunes_update_multipliers: the next warm start
     assert d["info"]["kkt_tol"] < 1e-8
+
+
+# ---- batched multi-tree solve ----------------------------------------------------------
+
+def test_batched_multi_tree_solve_matches_single_solves(gpu, orc):
+    """Independent trees (different bounds, sizes, paths) in one batch call == each solved on its own."""
+    cases = [P.linear_chain(2, 6, 6), P.linear_chain(2, 6, 6, ubound=0.2), P.linear_chain(2, 7, 7, ubound=0.3),
+             P.spring_mass(), P.linear_chain(2, 5, 5, nm=3), P.linear_chain(2, 6, 6, ubound=0.05)]
+    flats = [oracle_flat_from_lti(orc, p) for p in cases]
+    singles = []
+    for p, f in zip(cases, flats):
+        g = gpu.TqGpu(f["nk"], f["nx"], f["nu"]).upload(f, p.lambda0)
+        singles.append((g.solve(), g.solution()))
+        g.close()
+    mirrors = [gpu.TqGpu(f["nk"], f["nx"], f["nu"]).upload(f, p.lambda0) for p, f in zip(cases, flats)]
+    assert sorted(m.path for m in mirrors) == [0, 2, 2, 2, 2, 2]                # the spring-mass example tree is irregular
+    for _ in range(2):                                                          # twice: hand-over tags must not collide across launches
+        res = gpu.solve_batch(mirrors)
+    for m, r, (r1, s1), f in zip(mirrors, res, singles, flats):
+        sol = m.solution()
+        assert r["status"] == r1["status"] == 0 and r["iter"] == r1["iter"] and r["ls_total"] == r1["ls_total"]
+        for k in ("x", "u", "lam"):
+            assert np.array_equal(sol[k], s1[k])                                # same kernels, same data: bit-identical
+        assert orc.max_kkt(f, sol) < 1e-8
+        m.close()

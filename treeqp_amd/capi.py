@@ -419,6 +419,23 @@ def solve_virtual_ranks(mirrors, **kw) -> dict:
     return {f: getattr(r, f) for f, _ in GpuResult._fields_}
 
 
+def solve_batch(mirrors, profile=0, **kw) -> list:
+    """Batched multi-tree solve: independent mirrors, same options; persistent launches run concurrently."""
+    o = GpuOpts(maxIter=100, termCondition=2, stationarityTolerance=1e-8, regType=2, regTol=1e-6, regValue=1e-6,
+                lineSearchMaxIter=50, lineSearchGamma=0.1, lineSearchBeta=0.6, lineSearchRestartTrigger=-1, profile=profile)
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise KeyError(k)
+        setattr(o, k, v)
+    n = len(mirrors)
+    arr = (C.c_void_p * n)(*[m.h for m in mirrors])
+    res = (GpuResult * n)()
+    rc = lib().tqgpu_solve_batch(arr, n, C.byref(o), res)
+    if rc != 0:
+        raise RuntimeError(f"tqgpu_solve_batch failed ({rc}): {lib().tqgpu_last_error().decode()}")
+    return [{f: getattr(res[i], f) for f, _ in GpuResult._fields_} for i in range(n)]
+
+
 class TqGpu:
     def __init__(self, nk, nx, nu, device: int = -1):
         L = lib()

@@ -742,6 +742,7 @@ struct tqgpu_solver {
     unsigned launch_no = 0;         /* persistent launches so far (16 bits, never 0): tags of the hand-over words */
     void *pconst_slab = nullptr;    /* packed constants of the persistent path + its PDump */
     int *wg_map = nullptr;          /* blockIdx.x -> workgroup id (XCD-aware placement) */
+    int co_capacity = 1;            /* workgroups of persistent launches that can be resident on the device together */
     double *pab = nullptr, *pcst = nullptr;
     bool need_pack = true;          /* QP data changed since the constants were packed */
     /* writable aliases of the const inputs */
@@ -1134,6 +1135,7 @@ int setup_persist(tqgpu_solver *s, int device) {
     /* every workgroup must be resident at once (they wait for each other); keep one block per CU of
      * margin against the occupancy query over-reporting (MI355X guide, "Residency and cooperative launch") */
     const int capacity = prop.multiProcessorCount * std::max(1, per_cu - 1);
+    s->co_capacity = std::max(1, capacity);
     if (per_cu < 1 || G.G > capacity) return TQGPU_OK;
     /* hand-over buffers (tagged 64-bit words, see tdunes_persist.hpp); zeroed once, never reset */
     const int nx0 = s->nx[0];
@@ -1501,13 +1503,28 @@ static double hp_acc[4] = {0, 0, 0, 0}; static long hp_n = 0;
 #define HP_US(a, b) std::chrono::duration<double, std::micro>((b) - (a)).count()
 #endif
 
-extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *res) {
-    if (!s || !o || !res) return fail(TQGPU_EINVAL, "tqgpu_solve: bad arguments");
+namespace {
+
+/* A solve in two halves, so that several mirrors can have their (single) persistent launch in flight at the
+ * same time (tqgpu_solve_batch): solve_begin enqueues everything up to and including the first launch,
+ * solve_end waits for the verdict, runs whatever is left (extra line-search trials, relaunches, the whole
+ * Newton loop on the non-persistent paths) and fills the result. */
+struct SolveCtx {
+    Opts O;
+    int launches = 0, ring = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool fast = false, persist = false, first_launch = true, prelaunched = false;
 #ifdef TQ_HOSTPROF
-    auto hp0 = HP_NOW();
+    std::chrono::steady_clock::time_point hp0, hp1, hp2;
+#endif
+};
+
+int solve_begin(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx) {
+#ifdef TQ_HOSTPROF
+    cx.hp0 = HP_NOW();
 #endif
     HIP_TRY(hipSetDevice(s->device));
-    Opts O;
+    Opts &O = cx.O;
     O.maxIter = o->maxIter; O.termCondition = o->termCondition; O.regType = o->regType;
     O.lsMaxIter = o->lineSearchMaxIter; O.lsRestartTrigger = o->lineSearchRestartTrigger;
     O.tol = o->stationarityTolerance; O.regTol = o->regTol; O.regValue = o->regValue;
@@ -1519,7 +1536,6 @@ extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *r
     if (s->nranks > 1 && !s->comm) return fail(TQGPU_ECOMM, "sharded mirror without a communicator: use tqgpu_solve_virtual_ranks");
     const Tree &T = s->T; const Data &D = s->D;
     hipStream_t st = s->stream;
-    int launches = 0;
     const int nxu = std::max(s->sum_nx, s->sum_nu);
 
     /* ls_log needs no reset: entry i is written by iteration i */
@@ -1529,34 +1545,54 @@ extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *r
     }
     s->iter_times.assign((size_t)std::max(o->maxIter, 1), NAN);
 
-    const bool fast = s->fast >= 0 && s->use_fast;
-    const bool persist = fast && s->persist_ok && s->use_persist && s->nranks == 1 && !o->profile && o->maxIter > 0;
-    const int ring = (int)(s->solve_no % EV_RING);
-    hipEvent_t ev0 = s->ring_ev0[ring], ev1 = s->ring_ev1[ring];
+    cx.fast = s->fast >= 0 && s->use_fast;
+    cx.persist = cx.fast && s->persist_ok && s->use_persist && s->nranks == 1 && !o->profile && o->maxIter > 0;
+    cx.ring = (int)(s->solve_no % EV_RING);
+    cx.ev0 = s->ring_ev0[cx.ring]; cx.ev1 = s->ring_ev1[cx.ring];
     s->solve_no++;
-    HIP_TRY(hipEventRecord(ev0, st));
-    if (!persist) HIP_TRY(hipMemsetAsync(D.ctrl, 0, sizeof(Ctrl), st));     /* persistent path: zeroed with its inter-workgroup words */
+    HIP_TRY(hipEventRecord(cx.ev0, st));
+    if (!cx.persist) HIP_TRY(hipMemsetAsync(D.ctrl, 0, sizeof(Ctrl), st));     /* persistent path: reset by the launch's prologue */
     if (s->need_init && !s->dense) {
-        hipLaunchKernelGGL(k_init, dim3((nxu + 255) / 256), dim3(256), 0, st, s->sum_nx, s->sum_nu, D); launches++;
+        hipLaunchKernelGGL(k_init, dim3((nxu + 255) / 256), dim3(256), 0, st, s->sum_nx, s->sum_nu, D); cx.launches++;
         s->need_init = false;
     }
     if (s->dense && s->need_dense_init) {
-        hipLaunchKernelGGL(k_dense_init, dim3(T.Nn), dim3(WAVE), s->lds_dense, st, T, D); launches++;
+        hipLaunchKernelGGL(k_dense_init, dim3(T.Nn), dim3(WAVE), s->lds_dense, st, T, D); cx.launches++;
         s->need_dense_init = false;
     }
-    if (!persist) {
+    if (!cx.persist) {
         /* the current buffer is lam0 at the start of every solve */
         HIP_TRY(hipMemcpyAsync(D.lam0, s->d_lam_init, sizeof(double) * (size_t)s->sum_nx, hipMemcpyDeviceToDevice, st));
         /* first sweep at lambda0 (phase S of iteration 0 + fval0); the persistent launch does it as its prologue */
-        hipLaunchKernelGGL(k_stage, dim3(T.Nn), dim3(WAVE), s->lds_stage, st, T, D, 0, 0, 0); launches++;
-        hipLaunchKernelGGL(k_fval_init, dim3(1), dim3(256), 0, st, T, D); launches++;
+        hipLaunchKernelGGL(k_stage, dim3(T.Nn), dim3(WAVE), s->lds_stage, st, T, D, 0, 0, 0); cx.launches++;
+        hipLaunchKernelGGL(k_fval_init, dim3(1), dim3(256), 0, st, T, D); cx.launches++;
+    } else {
+#ifdef TQ_HOSTPROF
+        cx.hp1 = HP_NOW();
+#endif
+        int rcx = launch_persist(s, O, cx.launches, 1);
+        if (rcx != TQGPU_OK) return rcx;
+        cx.first_launch = false; cx.prelaunched = true;
+        /* the launch normally ends the solve: close the timing here */
+        HIP_TRY(hipEventRecord(cx.ev1, st));
+#ifdef TQ_HOSTPROF
+        cx.hp2 = HP_NOW();
+#endif
     }
+    return TQGPU_OK;
+}
 
+int solve_end(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, tqgpu_result *res) {
+    HIP_TRY(hipSetDevice(s->device));
+    const Opts &O = cx.O;
+    hipStream_t st = s->stream;
+    const bool fast = cx.fast, persist = cx.persist;
+    int &launches = cx.launches;
     /* Newton loop (dual_Newton_tree.c:1166-1228).  The device decides (termination, Armijo);
      * the host enqueues `chunk` tagged iterations ahead and reads the control block once per chunk.
      * Iterations enqueued beyond convergence, or while a line search still needs trials, are
      * no-ops by their phase guards. */
-    bool first_launch = true, tail_done = false;
+    bool tail_done = false;
     int h = 0, ev_idx = 0;
     bool finished = o->maxIter <= 0;       /* nothing to iterate: reported as "maximum iterations" */
     if (finished) { HIP_TRY(hipStreamSynchronize(st)); memset(s->h_ctrl, 0, sizeof(Ctrl)); s->h_ctrl->status = 1; }
@@ -1564,27 +1600,25 @@ extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *r
     int chunk = s->last_iter > 0 ? std::min(s->last_iter + 1, 16) : s->chunk;
     while (!finished) {
         const int n = persist ? 0 : std::min(chunk, o->maxIter - h);
-#ifdef TQ_HOSTPROF
-        auto hp1 = HP_NOW();
-#endif
-        if (persist) { int rcx = launch_persist(s, O, launches, first_launch ? 1 : 0); if (rcx != TQGPU_OK) return rcx; first_launch = false; }
-#ifdef TQ_HOSTPROF
-        auto hp2 = HP_NOW();
-#endif
+        if (persist) {
+            if (!cx.prelaunched) {
+                int rcx = launch_persist(s, O, launches, cx.first_launch ? 1 : 0);
+                if (rcx != TQGPU_OK) return rcx;
+                cx.first_launch = false;
+                HIP_TRY(hipEventRecord(cx.ev1, st));
+            }
+            cx.prelaunched = false;
+        }
         for (int i = 0; i < n; i++) {
             if (fast) { int rcx = launch_fast_iteration(s, O, h + i, launches); if (rcx != TQGPU_OK) return rcx; }
             else launch_generic_iteration(s, O, h + i, launches);
             if (o->profile && ev_idx + 1 < (int)s->iter_ev.size()) HIP_TRY(hipEventRecord(s->iter_ev[++ev_idx], st));
         }
-        int rc;
-        if (persist) {
-            /* the launch normally ends the solve: close the timing here, fetch the log behind it, and take the verdict from the result block */
-            HIP_TRY(hipEventRecord(ev1, st));
-            rc = wait_result_block(s);
-        } else rc = read_ctrl(s);
+        /* persistent path: the verdict comes through the result block in pinned host memory */
+        int rc = persist ? wait_result_block(s) : read_ctrl(s);
         if (rc != TQGPU_OK) return rc;
 #ifdef TQ_HOSTPROF
-        { auto hp3 = HP_NOW(); hp_acc[0] += HP_US(hp0, hp1); hp_acc[1] += HP_US(hp1, hp2); hp_acc[2] += HP_US(hp2, hp3); hp_n++;
+        if (persist) { auto hp3 = HP_NOW(); hp_acc[0] += HP_US(cx.hp0, cx.hp1); hp_acc[1] += HP_US(cx.hp1, cx.hp2); hp_acc[2] += HP_US(cx.hp2, hp3); hp_n++;
           if (hp_n % 200 == 0) { fprintf(stderr, "[hostprof] pre %.2f us, launch %.2f us, readback+sync %.2f us (avg of %ld)\n", hp_acc[0] / hp_n, hp_acc[1] / hp_n, hp_acc[2] / hp_n, hp_n); } }
 #endif
         tail_done = persist;
@@ -1599,6 +1633,7 @@ extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *r
         finished = s->h_ctrl->done != 0;
         chunk = s->chunk;
         if (persist && !finished) {
+            tail_done = false;
             unsigned tmo = 0;
             HIP_TRY(hipMemcpy(&tmo, s->psync.timeout, sizeof(unsigned), hipMemcpyDeviceToHost));
             if (tmo) return fail(TQGPU_ENODEVICE, "persistent solve kernel: a bounded inter-workgroup wait timed out");
@@ -1607,9 +1642,9 @@ extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *r
     const int host_iter = ev_idx;
     float ms = 0.f;
     if (!tail_done) {
-        HIP_TRY(hipEventRecord(ev1, st));
+        HIP_TRY(hipEventRecord(cx.ev1, st));
         HIP_TRY(hipStreamSynchronize(st));
-        HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+        HIP_TRY(hipEventElapsedTime(&ms, cx.ev0, cx.ev1));
     } else {
         /* single persistent launch: the kernel's own clock, launch start to verdict (the event pair of this
          * solve can be read later through tqgpu_get_device_times, which synchronises) */
@@ -1628,6 +1663,57 @@ extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *r
     res->status = c.status; res->iter = c.iter; res->ls_total = c.ls_total; res->ls_last = c.ls_last;
     res->n_launches = launches; res->device_time = 1e-3 * ms; res->last_error_norm = c.err; res->last_fval = c.fval;
     s->last_iter = c.iter;
+    return TQGPU_OK;
+}
+
+}  // namespace
+
+extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *res) {
+    if (!s || !o || !res) return fail(TQGPU_EINVAL, "tqgpu_solve: bad arguments");
+    SolveCtx cx;
+    int rc = solve_begin(s, o, cx);
+    if (rc != TQGPU_OK) return rc;
+    return solve_end(s, o, cx, res);
+}
+
+/* Batched multi-tree solve (the usage pattern of examples/fault_tolerance.c:486-530, one QP per
+ * configuration): n independent mirrors, same options.  Mirrors on the persistent path have their launches in
+ * flight together, as many at a time as fit on the device at once (every workgroup of a persistent launch must
+ * be resident); the others are solved one after the other.  results[i] belongs to solvers[i]; the first error
+ * is returned after every started solve has been waited for. */
+extern "C" int tqgpu_solve_batch(tqgpu_solver **solvers, int n, const tqgpu_opts *o, tqgpu_result *results) {
+    if (!solvers || n < 1 || !o || !results) return fail(TQGPU_EINVAL, "tqgpu_solve_batch: bad arguments");
+    for (int i = 0; i < n; i++) if (!solvers[i]) return fail(TQGPU_EINVAL, "tqgpu_solve_batch: null mirror");
+    std::vector<SolveCtx> cx((size_t)n);
+    int first_err = TQGPU_OK;
+    std::string first_msg;
+    int i = 0;
+    while (i < n) {
+        /* a wave of mirrors on one device whose persistent launches fit together */
+        const int dev = solvers[i]->device;
+        int used = 0, j = i;
+        for (; j < n; j++) {
+            tqgpu_solver *s = solvers[j];
+            const bool persist_like = s->fast >= 0 && s->use_fast && s->persist_ok && s->use_persist && s->nranks == 1 && !o->profile && o->maxIter > 0;
+            const int need = persist_like ? s->geom.G : s->co_capacity + 1;       /* non-persistent mirrors go alone */
+            if (j > i && (s->device != dev || used + need > s->co_capacity)) break;
+            used += need;
+        }
+        const int begun_from = i, begun_to = j;
+        int ok_to = begun_from;
+        for (int k = begun_from; k < begun_to; k++) {
+            int rc = solve_begin(solvers[k], o, cx[(size_t)k]);
+            if (rc != TQGPU_OK) { if (first_err == TQGPU_OK) { first_err = rc; first_msg = g_err; } break; }
+            ok_to = k + 1;
+        }
+        for (int k = begun_from; k < ok_to; k++) {
+            int rc = solve_end(solvers[k], o, cx[(size_t)k], &results[k]);
+            if (rc != TQGPU_OK && first_err == TQGPU_OK) { first_err = rc; first_msg = g_err; }
+        }
+        if (first_err != TQGPU_OK) break;
+        i = j;
+    }
+    if (first_err != TQGPU_OK) return fail(first_err, first_msg);
     return TQGPU_OK;
 }
 
