@@ -1134,7 +1134,10 @@ int setup_persist(tqgpu_solver *s, int device) {
     }
     /* every workgroup must be resident at once (they wait for each other); keep one block per CU of
      * margin against the occupancy query over-reporting (MI355X guide, "Residency and cooperative launch") */
-    const int capacity = prop.multiProcessorCount * std::max(1, per_cu - 1);
+    /* one workgroup per CU needs no margin (the figure is exact when registers allow a single 4-wave workgroup);
+     * with more per CU keep half a CU-load of workgroups in hand */
+    const int capacity = per_cu <= 1 ? prop.multiProcessorCount * per_cu : prop.multiProcessorCount * per_cu - prop.multiProcessorCount / 2;
+    if (getenv("TREEQP_AMD_VERBOSE")) fprintf(stderr, "[treeqp_amd] persistent path: %d workgroups, %d per CU possible, capacity %d\n", G.G, per_cu, capacity);
     s->co_capacity = std::max(1, capacity);
     if (per_cu < 1 || G.G > capacity) return TQGPU_OK;
     /* hand-over buffers (tagged 64-bit words, see tdunes_persist.hpp); zeroed once, never reset */
