@@ -124,6 +124,13 @@ __device__ __forceinline__ double wave_max(double v) {
     return v;
 }
 
+/* The generic kernels work one wavefront per node / block on a private LDS window.  Their bodies are
+ * device functions so that the same code runs (a) as one launch per phase and tree level, one wave per
+ * workgroup, and (b) inside the single-workgroup persistent kernel g_persist, many waves side by side.
+ * Inside a body the only synchronisation needed is among the lanes of ONE wave (they run in lockstep;
+ * LDS operations of a wave complete in order), i.e. a compiler-level fence. */
+#define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
 /* ------------------------------------------------------------------------------------------ */
 /* k_init: Qinv = 1/Qd, Rinv = 1/Rd  (stage_qp_clipping_init, clipping.c:163-170)             */
 /* ------------------------------------------------------------------------------------------ */
@@ -184,12 +191,8 @@ __global__ void __launch_bounds__(WAVE) k_dense_init(Tree T, Data D) {
 /* mode 1: line-search trial, lam_next = lam_cur + (tau - tauPrev) * dlam, evaluate there.     */
 /* Produces qmod,rmod,x,u,xUnc,uUnc,QinvCal,RinvCal and the node's dual-function term.         */
 /* ------------------------------------------------------------------------------------------ */
-__global__ void __launch_bounds__(WAVE) k_stage(Tree T, Data D, int mode, int h, int t) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+__device__ void stage_body(const Tree &T, const Data &D, int mode, int k, int lane, double *lds) {
     const Ctrl *c = D.ctrl;
-    if (mode == 1 && !phase_trial(c, h, t)) return;
-
-    const int k = blockIdx.x, lane = threadIdx.x;
     const int nxk = T.nx[k], nuk = T.nu[k], xo = T.xoff[k], uo = T.uoff[k];
     const int nkid = T.nk[k], d = T.bdim[k];
     const double *lamc = c->cur ? D.lam1 : D.lam0;
@@ -213,7 +216,7 @@ __global__ void __launch_bounds__(WAVE) k_stage(Tree T, Data D, int mode, int h,
         }
         lown[t] = v;
     }
-    __syncthreads();
+    WSYNC();
 
     if (D.dense) {
         /* dense unconstrained stage QP: z = P hmod; dual term -1/2 z'Hz + hmod'z - cmod */
@@ -235,7 +238,7 @@ __global__ void __launch_bounds__(WAVE) k_stage(Tree T, Data D, int mode, int h,
             hm[t] = v;
             if (isx) D.qmod[xo + j] = v; else D.rmod[uo + j] = v;
         }
-        __syncthreads();
+        WSYNC();
         const double *P = D.Pd + D.poff[k], *H = D.Hd + D.poff[k];
         for (int t = lane; t < nz; t += WAVE) {
             double acc = 0.0;
@@ -243,7 +246,7 @@ __global__ void __launch_bounds__(WAVE) k_stage(Tree T, Data D, int mode, int h,
             zz[t] = acc;
             if (t < nxk) { D.x[xo + t] = acc; D.xUnc[xo + t] = acc; } else { D.u[uo + t - nxk] = acc; D.uUnc[uo + t - nxk] = acc; }
         }
-        __syncthreads();
+        WSYNC();
         double p_quad = 0.0, p_lin = 0.0, p_cd = 0.0;
         for (int t = lane; t < nz; t += WAVE) {
             double acc = 0.0;
@@ -304,6 +307,12 @@ __global__ void __launch_bounds__(WAVE) k_stage(Tree T, Data D, int mode, int h,
     }
 }
 
+__global__ void __launch_bounds__(WAVE) k_stage(Tree T, Data D, int mode, int h, int t) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    if (mode == 1 && !phase_trial(D.ctrl, h, t)) return;
+    stage_body(T, D, mode, blockIdx.x, threadIdx.x, lds);
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* block reductions (one workgroup of 256 threads, fixed pairwise order => deterministic)      */
 /* ------------------------------------------------------------------------------------------ */
@@ -332,10 +341,7 @@ __global__ void __launch_bounds__(256) k_fval_init(Tree T, Data D) {
 /* ------------------------------------------------------------------------------------------ */
 /* k_grad: one wave per node k >= 1:  res_k = b_k - x_k + A_k x_dad + B_k u_dad                */
 /* ------------------------------------------------------------------------------------------ */
-__global__ void __launch_bounds__(WAVE) k_grad(Tree T, Data D, int termCondition, int h) {
-    const Ctrl *c = D.ctrl;
-    if (!phase_main(c, h)) return;
-    const int k = blockIdx.x + 1, lane = threadIdx.x;
+__device__ void grad_body(const Tree &T, const Data &D, int termCondition, int k, int lane) {
     const int p = T.dad[k], nxk = T.nx[k], nxp = T.nx[p], nup = T.nu[p];
     const int xo = T.xoff[k], xp = T.xoff[p], up = T.uoff[p];
     const double *A = D.A + T.aoff[k], *B = D.B + T.boff[k];
@@ -354,6 +360,11 @@ __global__ void __launch_bounds__(WAVE) k_grad(Tree T, Data D, int termCondition
     }
     part = (termCondition == 2) ? wave_max(part) : wave_sum(part);
     if (lane == 0) D.part_err[k] = part;
+}
+
+__global__ void __launch_bounds__(WAVE) k_grad(Tree T, Data D, int termCondition, int h) {
+    if (!phase_main(D.ctrl, h)) return;
+    grad_body(T, D, termCondition, blockIdx.x + 1, threadIdx.x);
 }
 
 /* termination test; also the top-of-loop bookkeeping of the Newton iteration */
@@ -375,11 +386,7 @@ __global__ void __launch_bounds__(256) k_check(Tree T, Data D, Opts O, int h) {
 /*   W_p = C P C' + blockdiag(QinvCal_kids),  C = [A_c B_c] stacked over the children,         */
 /*   P = diag(QinvCal_p, RinvCal_p);   Ut_p = -(C[:, :nx_p] P)'                                */
 /* ------------------------------------------------------------------------------------------ */
-__global__ void __launch_bounds__(WAVE) k_hess(Tree T, Data D, int h) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const Ctrl *c = D.ctrl;
-    if (!phase_main(c, h)) return;
-    const int p = blockIdx.x, lane = threadIdx.x;
+__device__ void hess_body(const Tree &T, const Data &D, int p, int lane, double *lds) {
     const int d = T.bdim[p], nxp = T.nx[p], nup = T.nu[p], nz = nxp + nup;
     double *Cs = lds;                 /* d x nz, column major, ld = d */
     double *CP = lds + (size_t)d * nz;
@@ -398,7 +405,7 @@ __global__ void __launch_bounds__(WAVE) k_hess(Tree T, Data D, int h) {
         }
         rowoff += nxc;
     }
-    __syncthreads();
+    WSYNC();
     if (D.dense) {
         /* CP = C P_p with the dense elimination matrix of the parent (build_M of the qpOASES stage solver) */
         const double *P = D.Pd + D.poff[p];
@@ -408,7 +415,7 @@ __global__ void __launch_bounds__(WAVE) k_hess(Tree T, Data D, int h) {
             for (int cidx = 0; cidx < nz; cidx++) acc = fma(Cs[i + (size_t)cidx * d], P[cidx + (size_t)col * nz], acc);
             CP[i + (size_t)col * d] = acc;
         }
-        __syncthreads();
+        WSYNC();
     }
     double *W = D.W + T.woff[p];
     for (int e = lane; e < d * d; e += WAVE) {
@@ -439,6 +446,12 @@ __global__ void __launch_bounds__(WAVE) k_hess(Tree T, Data D, int h) {
     }
 }
 
+__global__ void __launch_bounds__(WAVE) k_hess(Tree T, Data D, int h) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    if (!phase_main(D.ctrl, h)) return;
+    hess_body(T, D, blockIdx.x, threadIdx.x, lds);
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* k_factor: one wave per block of one tree level (blocks first .. first+count-1).             */
 /* Tall Cholesky of T = [W ; resMod' ; Ut] (R = d + 1 + nx_ii rows, d columns), left-looking,   */
@@ -453,20 +466,17 @@ __device__ __forceinline__ void tall_potrf(double *Tm, double *invd, int R, int 
             for (int k = 0; k < j; k++) s = fma(-Tm[i + (size_t)k * ld], Tm[j + (size_t)k * ld], s);
             Tm[i + (size_t)j * ld] = s;
         }
-        __syncthreads();
+        WSYNC();
         const double cjj = Tm[j + (size_t)j * ld];
         const double finv = cjj > 0.0 ? 1.0 / sqrt(cjj) : 0.0;      /* pivot <= 0 -> zero column */
         for (int i = j + lane; i < R; i += WAVE) Tm[i + (size_t)j * ld] *= finv;
         if (lane == 0) invd[j] = finv;
-        __syncthreads();
+        WSYNC();
     }
 }
 
-__global__ void __launch_bounds__(WAVE) k_factor(Tree T, Data D, Opts O, int first, int h) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+__device__ void factor_body(const Tree &T, const Data &D, const Opts &O, int ii, int lane, double *lds) {
     Ctrl *c = D.ctrl;
-    if (!phase_main(c, h)) return;
-    const int ii = first + blockIdx.x, lane = threadIdx.x;
     const int d = T.bdim[ii], nxi = ii > 0 ? T.nx[ii] : 0;
     const int R = d + 1 + nxi, ld = R | 1;
     double *Tm = lds;                         /* ld x d */
@@ -487,7 +497,7 @@ __global__ void __launch_bounds__(WAVE) k_factor(Tree T, Data D, Opts O, int fir
             const int i = e % nxi, j = e / nxi;
             Tm[d + 1 + i + (size_t)j * ld] = Ut[i + (size_t)j * nxi];
         }
-        __syncthreads();
+        WSYNC();
         tall_potrf(Tm, invd, R, d, ld, lane);
         if (O.regType != 2 || pass == 1) break;
         /* on-the-fly Levenberg-Marquardt: any diagonal entry <= regTol -> shift and refactorize */
@@ -495,7 +505,7 @@ __global__ void __launch_bounds__(WAVE) k_factor(Tree T, Data D, Opts O, int fir
         for (int j = lane; j < d; j += WAVE) small |= (Tm[j + (size_t)j * ld] <= O.regTol);
         if (!__any(small)) break;
         if (lane == 0) atomicAdd(&c->n_reg, 1);
-        __syncthreads();
+        WSYNC();
     }
 
     /* outputs: factor, reciprocal diagonal */
@@ -534,13 +544,13 @@ __global__ void __launch_bounds__(WAVE) k_factor(Tree T, Data D, Opts O, int fir
         double *z = Tm + d;                 /* row d, stride ld */
         double pd = 0.0;
         for (int k = d - 1; k >= 0; k--) {
-            __syncthreads();
+            WSYNC();
             const double zk = z[(size_t)k * ld] * invd[k];
             for (int i = lane; i < k; i += WAVE) z[(size_t)i * ld] = fma(-Tm[k + (size_t)i * ld], zk, z[(size_t)i * ld]);
-            __syncthreads();
+            WSYNC();
             if (lane == 0) z[(size_t)k * ld] = zk;
         }
-        __syncthreads();
+        WSYNC();
         for (int j = lane; j < d; j += WAVE) {
             const double v = z[(size_t)j * ld];
             D.dlam[bo + j] = v;
@@ -551,15 +561,17 @@ __global__ void __launch_bounds__(WAVE) k_factor(Tree T, Data D, Opts O, int fir
     }
 }
 
+__global__ void __launch_bounds__(WAVE) k_factor(Tree T, Data D, Opts O, int first, int h) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    if (!phase_main(D.ctrl, h)) return;
+    factor_body(T, D, O, first + blockIdx.x, threadIdx.x, lds);
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* k_forward: one wave per block of one level:                                                 */
 /*   dlam_ii = L^-T ( y_ii - CholUt_ii' * dlam_dad[pos..] )                                    */
 /* ------------------------------------------------------------------------------------------ */
-__global__ void __launch_bounds__(WAVE) k_forward(Tree T, Data D, int first, int h) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const Ctrl *c = D.ctrl;
-    if (!phase_main(c, h)) return;
-    const int ii = first + blockIdx.x, lane = threadIdx.x;
+__device__ void forward_body(const Tree &T, const Data &D, int ii, int lane, double *lds) {
     const int d = T.bdim[ii], nxi = T.nx[ii], ld = d | 1;
     double *L = lds;                      /* ld x d */
     double *z = lds + (size_t)ld * d;     /* d */
@@ -571,7 +583,7 @@ __global__ void __launch_bounds__(WAVE) k_forward(Tree T, Data D, int first, int
         if (i >= j) L[i + (size_t)j * ld] = Lg[i + (size_t)j * d];
     }
     for (int i = lane; i < nxi; i += WAVE) dl[i] = D.dlam[xo + i];
-    __syncthreads();
+    WSYNC();
     const double *CUt = D.CholUt + T.utoff[ii];
     for (int j = lane; j < d; j += WAVE) {
         double acc = 0.0;
@@ -580,13 +592,13 @@ __global__ void __launch_bounds__(WAVE) k_forward(Tree T, Data D, int first, int
     }
     const double *invd = D.invd + bo;
     for (int k = d - 1; k >= 0; k--) {
-        __syncthreads();
+        WSYNC();
         const double zk = z[k] * invd[k];
         for (int i = lane; i < k; i += WAVE) z[i] = fma(-L[k + (size_t)i * ld], zk, z[i]);
-        __syncthreads();
+        WSYNC();
         if (lane == 0) z[k] = zk;
     }
-    __syncthreads();
+    WSYNC();
     double pd = 0.0;
     for (int j = lane; j < d; j += WAVE) {
         D.dlam[bo + j] = z[j];
@@ -594,6 +606,12 @@ __global__ void __launch_bounds__(WAVE) k_forward(Tree T, Data D, int first, int
     }
     pd = wave_sum(pd);
     if (lane == 0) D.part_dot[ii] = pd;
+}
+
+__global__ void __launch_bounds__(WAVE) k_forward(Tree T, Data D, int first, int h) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    if (!phase_main(D.ctrl, h)) return;
+    forward_body(T, D, first + blockIdx.x, threadIdx.x, lds);
 }
 
 /* ------------------------------------------------------------------------------------------ */
