@@ -727,6 +727,7 @@ __global__ void __launch_bounds__(WAVE) k_ls_decide_parts(Data D, Opts O, const 
 
 #include "tdunes_fast.hpp"
 #include "tdunes_persist.hpp"
+#include "tdunes_gpersist.hpp"
 
 /* export_mu (clipping.c:386-399): mu = Q .* (xUnc - x) */
 __global__ void k_export_mu(int n_x, int n_u, Data D, double *mu_x, double *mu_u) {
@@ -761,6 +762,10 @@ struct tqgpu_solver {
     void *pconst_slab = nullptr;    /* packed constants of the persistent path + its PDump */
     int *wg_map = nullptr;          /* blockIdx.x -> workgroup id (XCD-aware placement) */
     int co_capacity = 1;            /* workgroups of persistent launches that can be resident on the device together */
+    bool gpersist_ok = false;       /* small tree of any shape: whole solve in one launch of one workgroup (tdunes_gpersist.hpp) */
+    int use_gpersist = 1;
+    int *d_lvl_first = nullptr;
+    size_t lds_gp_wave = 0;         /* doubles of LDS per wave of g_persist */
     double *pab = nullptr, *pcst = nullptr;
     bool need_pack = true;          /* QP data changed since the constants were packed */
     /* writable aliases of the const inputs */
@@ -1277,7 +1282,7 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
     detect_fast(s);
     {
         const char *env = getenv("TREEQP_AMD_PATH");
-        if (env && strcmp(env, "generic") == 0) s->use_fast = 0;
+        if (env && strcmp(env, "generic") == 0) { s->use_fast = 0; s->use_gpersist = 0; }
         if (env && strcmp(env, "tiered") == 0) s->use_persist = 0;
         const char *ch = getenv("TREEQP_AMD_CHUNK");
         if (ch && atoi(ch) > 0) s->chunk = atoi(ch);
@@ -1367,6 +1372,20 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
         if (hipGetDeviceProperties(&prop, device) != hipSuccess || prop.maxThreadsPerBlock < FW * WAVE) s->fast = -1;
     }
     if ((rc = setup_persist(s, device))) return cleanup_fail(rc);
+    {
+        /* single-workgroup persistent kernel for small trees of any shape: every level must be a few rounds
+         * of GP_WAVES blocks at most, and the per-wave LDS windows must fit the default 64 KB */
+        int widest = 0;
+        for (int l = 0; l <= s->Nh; l++) widest = std::max(widest, s->lvl_first[l + 1] - s->lvl_first[l]);
+        const size_t per_wave = (std::max(std::max(s->lds_stage, s->lds_hess), std::max(s->lds_factor, s->lds_forward)) + 7) / 8 + 2;
+        s->lds_gp_wave = per_wave;
+        s->gpersist_ok = widest <= 6 * GP_WAVES && per_wave * 8 * GP_WAVES <= 64 * 1024;
+        if (s->gpersist_ok) {
+            if (hipMalloc(&s->d_lvl_first, sizeof(int) * s->lvl_first.size()) != hipSuccess ||
+                hipMemcpy(s->d_lvl_first, s->lvl_first.data(), sizeof(int) * s->lvl_first.size(), hipMemcpyHostToDevice) != hipSuccess)
+                return cleanup_fail(fail(TQGPU_ENOMEM, "hipMalloc failed"));
+        }
+    }
     *out = s;
     return TQGPU_OK;
 }
@@ -1385,12 +1404,20 @@ extern "C" void tqgpu_destroy(tqgpu_solver *s) {
     if (s->sync_slab) (void)hipFree(s->sync_slab);
     if (s->pconst_slab) (void)hipFree(s->pconst_slab);
     if (s->wg_map) (void)hipFree(s->wg_map);
+    if (s->d_lvl_first) (void)hipFree(s->d_lvl_first);
     if (s->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(s->comm);
     if (s->slab) (void)hipFree(s->slab);
     delete s;
 }
 
-extern "C" int tqgpu_uses_fused_path(const tqgpu_solver *s) { return s && s->fast >= 0 && s->use_fast ? (s->persist_ok && s->use_persist && s->nranks == 1 ? 2 : 1) : 0; }
+static bool uses_gpersist(const tqgpu_solver *s) {
+    return s->gpersist_ok && s->use_gpersist && !s->dense && s->nranks == 1 && !(s->fast >= 0 && s->use_fast);
+}
+extern "C" int tqgpu_uses_fused_path(const tqgpu_solver *s) {
+    if (!s) return 0;
+    if (s->fast >= 0 && s->use_fast) return s->persist_ok && s->use_persist && s->nranks == 1 ? 2 : 1;
+    return uses_gpersist(s) ? 3 : 0;
+}
 
 /* diagnostic: copy the in-kernel time stamps of the last fused iteration (8 kernels x 32 slots x
  * {shader clock, 100 MHz wall clock}); only filled when TREEQP_AMD_STAMPS is set */
@@ -1534,7 +1561,7 @@ struct SolveCtx {
     Opts O;
     int launches = 0, ring = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool fast = false, persist = false, first_launch = true, prelaunched = false;
+    bool fast = false, persist = false, first_launch = true, prelaunched = false, gpersist = false;
 #ifdef TQ_HOSTPROF
     std::chrono::steady_clock::time_point hp0, hp1, hp2;
 #endif
@@ -1568,12 +1595,14 @@ int solve_begin(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx) {
 
     cx.fast = s->fast >= 0 && s->use_fast;
     cx.persist = cx.fast && s->persist_ok && s->use_persist && s->nranks == 1 && !o->profile && o->maxIter > 0;
+    cx.gpersist = !cx.persist && uses_gpersist(s) && !o->profile && o->maxIter > 0;
+    if (cx.gpersist) cx.persist = true;                  /* same host flow: one launch, verdict through the result block */
     cx.ring = (int)(s->solve_no % EV_RING);
     cx.ev0 = s->ring_ev0[cx.ring]; cx.ev1 = s->ring_ev1[cx.ring];
     s->solve_no++;
     HIP_TRY(hipEventRecord(cx.ev0, st));
     if (!cx.persist) HIP_TRY(hipMemsetAsync(D.ctrl, 0, sizeof(Ctrl), st));     /* persistent path: reset by the launch's prologue */
-    if (s->need_init && !s->dense) {
+    if (s->need_init && !s->dense && !cx.gpersist) {     /* g_persist recomputes the reciprocal weights itself */
         hipLaunchKernelGGL(k_init, dim3((nxu + 255) / 256), dim3(256), 0, st, s->sum_nx, s->sum_nu, D); cx.launches++;
         s->need_init = false;
     }
@@ -1591,7 +1620,15 @@ int solve_begin(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx) {
 #ifdef TQ_HOSTPROF
         cx.hp1 = HP_NOW();
 #endif
-        int rcx = launch_persist(s, O, cx.launches, 1);
+        int rcx = TQGPU_OK;
+        if (cx.gpersist) {
+            s->launch_no = (s->launch_no + 1) & 0xFFFFu;
+            if (s->launch_no == 0) s->launch_no = 1;
+            s->psync.seq = s->launch_no << 16;
+            GParams gp;
+            gp.lvl_first = s->d_lvl_first; gp.lam_init = s->d_lam_init; gp.hres = s->h_res; gp.seq = s->psync.seq; gp.lds_wave = (int)s->lds_gp_wave;
+            hipLaunchKernelGGL(g_persist, dim3(1), dim3(GP_WAVES * WAVE), s->lds_gp_wave * 8 * GP_WAVES, st, T, D, O, gp); cx.launches++;
+        } else rcx = launch_persist(s, O, cx.launches, 1);
         if (rcx != TQGPU_OK) return rcx;
         cx.first_launch = false; cx.prelaunched = true;
         /* the launch normally ends the solve: close the timing here */
@@ -1623,6 +1660,7 @@ int solve_end(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, tqgpu_result *
         const int n = persist ? 0 : std::min(chunk, o->maxIter - h);
         if (persist) {
             if (!cx.prelaunched) {
+                if (cx.gpersist) return fail(TQGPU_ENODEVICE, "single-workgroup persistent kernel ended without a verdict");
                 int rcx = launch_persist(s, O, launches, cx.first_launch ? 1 : 0);
                 if (rcx != TQGPU_OK) return rcx;
                 cx.first_launch = false;
@@ -1653,7 +1691,7 @@ int solve_end(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, tqgpu_result *
         h = s->h_ctrl->iter;
         finished = s->h_ctrl->done != 0;
         chunk = s->chunk;
-        if (persist && !finished) {
+        if (persist && !finished && !cx.gpersist) {
             tail_done = false;
             unsigned tmo = 0;
             HIP_TRY(hipMemcpy(&tmo, s->psync.timeout, sizeof(unsigned), hipMemcpyDeviceToHost));
@@ -1716,7 +1754,8 @@ extern "C" int tqgpu_solve_batch(tqgpu_solver **solvers, int n, const tqgpu_opts
         for (; j < n; j++) {
             tqgpu_solver *s = solvers[j];
             const bool persist_like = s->fast >= 0 && s->use_fast && s->persist_ok && s->use_persist && s->nranks == 1 && !o->profile && o->maxIter > 0;
-            const int need = persist_like ? s->geom.G : s->co_capacity + 1;       /* non-persistent mirrors go alone */
+            const bool gp_like = !persist_like && uses_gpersist(s) && !o->profile && o->maxIter > 0;
+            const int need = persist_like ? s->geom.G : (gp_like ? 1 : s->co_capacity + 1);   /* launch-per-level mirrors go alone */
             if (j > i && (s->device != dev || used + need > s->co_capacity)) break;
             used += need;
         }
