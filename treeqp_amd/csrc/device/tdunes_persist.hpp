@@ -593,21 +593,22 @@ __device__ __forceinline__ double p_stage_owned(const PConst &C, const PSync &Sy
     return rows_fold<false>(fsum);       /* every lane of a 16-lane group holds its group's sum */
 }
 
-/* top workgroup: ordered sums (workgroup order) of the per-workgroup {fval, dot} partials (tag tag_p;
- * skipped when want_parts is false) and of the termination partials (tag tag_e; sum or maximum), polled
- * in parallel through the Schur record scratch in chunks; results valid in thread 0.  Returns false in
+/* top workgroup: sums of the per-workgroup {fval, dot} partials (tag tag_p; skipped when want_parts is
+ * false) and of the termination partials (tag tag_e; sum or maximum).  Every thread polls one entry per
+ * round; the sums are taken in a FIXED order (cross-lane tree inside a wave, waves in order, rounds in
+ * order), so the result does not depend on arrival times.  Results valid in thread 0.  Returns false in
  * every thread when a poll gave up. */
 template <int NX, int NU, int MD>
 __device__ __forceinline__ bool p_gather3(const PSync &Sy, PLds<NX, NU, MD> &L, int count, bool want_parts, unsigned tag_p, unsigned tag_e, bool err_max,
                                           double &fa, double &da, double &ea) {
-    constexpr int CAP = PLds<NX, NU, MD>::RED_CAP * 2 / 3;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     fa = 0.0; da = 0.0; ea = 0.0;
-    for (int c0 = 0; c0 < count; c0 += CAP) {
-        const int n = min(CAP, count - c0);
-        for (int w = threadIdx.x; w < n; w += FW * WAVE) {
-            const u64 *pp = Sy.parts + (size_t)(c0 + w) * 4, *pe = Sy.errs + (size_t)(c0 + w) * 2;
+    for (int c0 = 0; c0 < count; c0 += FW * WAVE) {
+        const int w = c0 + (int)threadIdx.x;
+        double f = 0.0, d = 0.0, er = 0.0;
+        if (w < count) {
+            const u64 *pp = Sy.parts + (size_t)w * 4, *pe = Sy.errs + (size_t)w * 2;
             const u64 t0 = wall_clock64();
-            double f = 0.0, d = 0.0, er;
             bool ok;
             for (;;) {
                 PollGuard pg;
@@ -617,13 +618,14 @@ __device__ __forceinline__ bool p_gather3(const PSync &Sy, PLds<NX, NU, MD> &L, 
                 pg.load(Sy);
                 if (ok || !pg.go_on(Sy, t0)) break;
             }
-            if (!ok) *L.abort = 1;
-            L.sch[3 * w] = f; L.sch[3 * w + 1] = d; L.sch[3 * w + 2] = er;
+            if (!ok) { *L.abort = 1; f = 0.0; d = 0.0; er = 0.0; }
         }
+        f = wsum(f); d = wsum(d); er = err_max ? wmax(er) : wsum(er);
+        if (lane == 0) { L.sch[3 * wave] = f; L.sch[3 * wave + 1] = d; L.sch[3 * wave + 2] = er; }
         __syncthreads();
         if (*L.abort) return false;
         if (threadIdx.x == 0) {
-            for (int w = 0; w < n; w++) { fa += L.sch[3 * w]; da += L.sch[3 * w + 1]; ea = err_max ? fmax(ea, L.sch[3 * w + 2]) : ea + L.sch[3 * w + 2]; }
+            for (int v = 0; v < FW; v++) { fa += L.sch[3 * v]; da += L.sch[3 * v + 1]; ea = err_max ? fmax(ea, L.sch[3 * v + 2]) : ea + L.sch[3 * v + 2]; }
         }
         __syncthreads();
     }
