@@ -59,6 +59,34 @@ __global__ void __launch_bounds__(FW * WAVE) level_bench(Ctrl *c, Opts O, long l
     if (threadIdx.x == 0) cycles[0] = (t1 - t0) / (reps * th);
     if (acc == 1.2345) sink[0] = acc;
 }
+// forward sweep of one tier (levels 1..2 from LDS data, level 0 with a fixed delta): cycles per level
+template <int VARIANT>
+__global__ void __launch_bounds__(FW * WAVE) fwd_bench(long long *cycles, int reps, double *sink, PSync Sy) {
+    constexpr int NX = 8, NU = 3, MD = 2;
+    using U = Uni<NX, NU, MD>;
+    constexpr int D = U::D;
+    extern __shared__ __attribute__((aligned(16))) double lds_all[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    PLds<NX, NU, MD> L(lds_all, wave);
+    for (int i = threadIdx.x; i < PLds<NX, NU, MD>::DOUBLES; i += FW * WAVE) lds_all[i] = 0.01 * ((i * 7) % 13) + 0.5;
+    __syncthreads();
+    const int th = 3;
+    double dotp = 0.0;
+    long long t0 = clock64();
+    for (int r = 0; r < reps; r++) {
+        for (int t = 0; t < th; t++) {
+            const int nb = U::width(t);
+            if (wave < nb) {
+                const int loc = U::first(t) + wave;
+                dotp += p_forward<NX, NU, MD>(Sy, L, loc, loc, lane, (lds_cptr)(L.dl + (t ? (U::first(t - 1) + wave / MD) * D + (wave % MD) * NX : 0)), false, false, 0u);
+            }
+            lds_barrier();
+        }
+    }
+    long long t1 = clock64();
+    if (threadIdx.x == 0) cycles[0] = (t1 - t0) / (reps * th);
+    if (dotp == 1.2345) sink[0] = dotp;
+}
 }  // namespace
 
 template <int MASK>
@@ -88,5 +116,13 @@ int main() {
     run<128>("bare potrf (no inv store, no pmin)", c, O, dc, sink);
     run<63 - 4 + 64>("all with p_potrf_rows instead of factor_rows", c, O, dc, sink);
     run<63 - 4 + 128>("all with bare potrf", c, O, dc, sink);
+    {
+        PSync Sy; memset(&Sy, 0, sizeof(Sy));
+        const size_t lds = PLds<8, 3, 2>::DOUBLES * sizeof(double);
+        for (int it = 0; it < 2; it++) { hipLaunchKernelGGL(fwd_bench<0>, dim3(1), dim3(FW * WAVE), lds, 0, dc, 300, sink, Sy); (void)hipDeviceSynchronize(); }
+        long long h = 0;
+        (void)hipMemcpy(&h, dc, 8, hipMemcpyDeviceToHost);
+        printf("%-44s %6lld cycles per level\n", "forward level (p_forward + barrier)", h);
+    }
     return 0;
 }

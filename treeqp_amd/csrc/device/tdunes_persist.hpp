@@ -412,21 +412,22 @@ __device__ __forceinline__ double p_forward(const PSync &Sy, PLds<NX, NU, MD> &L
 #pragma unroll
         for (int r = 0; r < NX; r++) dv[r] = delta_lds[r];
     }
-    double acc = 0.0;
+    double acc0 = 0.0, acc1 = 0.0;                       /* two chains: half the dependent latency */
 #pragma unroll
-    for (int r = 0; r < NX; r++) acc = fma(Cc[r], dv[r], acc);
-    double s = fma(-1.0, acc, L.y[loc * D + li]);
+    for (int r = 0; r < NX; r += 2) { acc0 = fma(Cc[r], dv[r], acc0); if (r + 1 < NX) acc1 = fma(Cc[r + 1], dv[r + 1], acc1); }
+    double s = fma(-1.0, acc0 + acc1, L.y[loc * D + li]);
     const double inv = diag_inv(Lc[li]);
+    /* column li of L below the diagonal, zero on and above it: the substitution loop then needs no lane
+     * masks at all -- a lane whose entry is zero simply keeps its value, and lane k's value is final after step k */
     double Lcol[D];
 #pragma unroll
-    for (int k = 0; k < D; k++) Lcol[k] = Lc[k];
-    double mine = 0.0;
+    for (int k = 0; k < D; k++) { const double v = Lc[k]; Lcol[k] = (k > li) ? v : 0.0; }
 #pragma unroll
-    for (int k = D - 1; k >= 0; k--) {
+    for (int k = D - 1; k >= 1; k--) {
         const double zk = rdlane(s * inv, k);
-        if (lane == k) mine = zk;
-        if (lane < k) s = fma(-Lcol[k], zk, s);
+        s = fma(-Lcol[k], zk, s);
     }
+    const double mine = s * inv;
     double pd = 0.0;
     if (lane < D) {
         if (to_children && ok) st_tag(Sy.dlt + (size_t)(U::bo(ii) + lane) * 2, mine, tag);
@@ -812,13 +813,14 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(PConst C, Opts O, PGeom G
                         double sv = L.wave[D * U::LDW + lc], Lcol[D];
 #pragma unroll
                         for (int k = 0; k < D; k++) Lcol[k] = L.wave[k * U::LDW + lc];
-                        double mine = 0.0;
 #pragma unroll
-                        for (int k = D - 1; k >= 0; k--) {
+                        for (int k = 0; k < D; k++) Lcol[k] = (k > lc) ? Lcol[k] : 0.0;      /* strictly below the diagonal: no lane masks in the loop */
+#pragma unroll
+                        for (int k = D - 1; k >= 1; k--) {
                             const double zk = rdlane(sv * myinv, k);
-                            if (lane == k) mine = zk;
-                            if (lane < k) sv = fma(-Lcol[k], zk, sv);
+                            sv = fma(-Lcol[k], zk, sv);
                         }
+                        const double mine = sv * myinv;
                         if (lane < D) {
                             if (th == 1 && !is_bottom && ok) st_tag(Sy.dlt + (size_t)(U::bo(0) + lane) * 2, mine, tag_e);
                             L.dl[lane] = mine; dotp = L.res[lane] * mine;
