@@ -232,11 +232,12 @@ __device__ __forceinline__ void sub_children(P sch, int lane, double (&T)[Uni<NX
             else v[c][j] = src[j * stride];
         }
     }
+    /* a 0/1 factor instead of a select: one fma per entry (the records hold finite numbers) */
 #pragma unroll
     for (int c = 0; c < MD; c++) {
-        const bool act = vrow || (lane < D && lc == c);
+        const double m = (vrow || (lane < D && lc == c)) ? 1.0 : 0.0;
 #pragma unroll
-        for (int j = 0; j < NX; j++) T[c * NX + j] -= act ? v[c][j] : 0.0;
+        for (int j = 0; j < NX; j++) T[c * NX + j] = fma(-m, v[c][j], T[c * NX + j]);
     }
 }
 

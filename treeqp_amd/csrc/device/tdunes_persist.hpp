@@ -568,7 +568,7 @@ __device__ __forceinline__ bool p_sub_children_tagged(const PSync &Sy, const u64
     }
 #pragma unroll
     for (int c = 0; c < MD; c++) {
-        const bool act = vrow || (lane < D && lc == c);
+        const bool act = (vrow || (lane < D && lc == c)) && ok;       /* words of a failed poll may hold anything */
 #pragma unroll
         for (int j = 0; j < NX; j++) T[c * NX + j] -= act ? v[c][j] : 0.0;
     }
