@@ -202,6 +202,36 @@ __device__ __forceinline__ void potrf_v12(double (&T)[D], int lane) {
     }
 }
 
+// V13: left-looking; row j of the factor comes from LDS for the columns finished at least two steps ago
+// (each finished column is stored once, row-major with stride 18, and read back as a broadcast, two
+// entries per ds_read_b128), the newest column by readlane.  Reads for step j are issued during step j-1.
+typedef __attribute__((address_space(3))) double lds_f64;
+__device__ __forceinline__ void potrf_v13(double (&T)[D], int lane, double *lds_generic) {
+    lds_f64 *lds = (lds_f64 *)lds_generic;
+    constexpr int LS = 18;
+    double row[D], rown[D];
+#pragma unroll
+    for (int k = 0; k < D; k++) { row[k] = 0.0; rown[k] = 0.0; }
+#pragma unroll
+    for (int j = 0; j < D; j++) {
+        /* prefetch row j+1 (columns 0 .. j-1 are in LDS; column j is not finished yet) */
+        if (j + 1 < D) {
+#pragma unroll
+            for (int k = 0; k < j; k++) rown[k] = lds[(j + 1) * LS + k];
+        }
+        double s = T[j];
+#pragma unroll
+        for (int k = 0; k < j - 1; k++) s = fma(-T[k], row[k], s);
+        if (j >= 1) s = fma(-T[j - 1], rdlane(T[j - 1], j), s);
+        const double pj = rdlane(s, j);
+        const double finv = pivot_rsqrt3(pj);
+        T[j] = s * finv;
+        lds[lane * LS + j] = T[j];
+#pragma unroll
+        for (int k = 0; k < D; k++) row[k] = rown[k];
+    }
+}
+
 // V5: right-looking with ds_bpermute broadcast (__shfl)
 __device__ __forceinline__ void potrf_v5(double (&T)[D], int lane) {
 #pragma unroll
@@ -216,7 +246,7 @@ __device__ __forceinline__ void potrf_v5(double (&T)[D], int lane) {
 
 template <int V>
 __global__ void bench(const double *in, double *out, long long *cycles, int reps) {
-    __shared__ double lds[17 * 17 + 8];
+    __shared__ double lds[64 * 18 + 8];
     const int lane = threadIdx.x;
     double T0[D], T[D];
 #pragma unroll
@@ -238,6 +268,7 @@ __global__ void bench(const double *in, double *out, long long *cycles, int reps
         if (V == 10) potrf_v10(T, lane);
         if (V == 11) potrf_v11(T, lane);
         if (V == 12) potrf_v12(T, lane);
+        if (V == 13) potrf_v13(T, lane, lds);
 #pragma unroll
         for (int j = 0; j < D; j++) acc += T[j];
     }
@@ -292,7 +323,7 @@ int main() {
     hipMemcpy(din, h.data(), sizeof(double) * R * D, hipMemcpyHostToDevice);
     long long c[8];
     std::vector<double> ref(64 * D), got(64 * D);
-    for (int v = 1; v <= 12; v++) {
+    for (int v = 1; v <= 13; v++) {
         for (int it = 0; it < 2; it++) {
             switch (v) {
                 case 1: hipLaunchKernelGGL(bench<1>, dim3(1), dim3(64), 0, 0, din, dout, dc, 200); break;
@@ -307,6 +338,7 @@ int main() {
                 case 10: hipLaunchKernelGGL(bench<10>, dim3(1), dim3(64), 0, 0, din, dout, dc, 200); break;
                 case 11: hipLaunchKernelGGL(bench<11>, dim3(1), dim3(64), 0, 0, din, dout, dc, 200); break;
                 case 12: hipLaunchKernelGGL(bench<12>, dim3(1), dim3(64), 0, 0, din, dout, dc, 200); break;
+                case 13: hipLaunchKernelGGL(bench<13>, dim3(1), dim3(64), 0, 0, din, dout, dc, 200); break;
             }
             hipDeviceSynchronize();
         }
