@@ -87,6 +87,40 @@ __global__ void __launch_bounds__(FW * WAVE) fwd_bench(long long *cycles, int re
     if (threadIdx.x == 0) cycles[0] = (t1 - t0) / (reps * th);
     if (dotp == 1.2345) sink[0] = dotp;
 }
+// stage sweep (15 owned nodes of a bottom-tier workgroup) and G + H (7 blocks) from LDS state + global constants
+template <int WHAT>
+__global__ void __launch_bounds__(FW * WAVE) sg_bench(PConst C, Opts O, PSync Sy, long long *cycles, int reps, double *sink) {
+    constexpr int NX = 8, NU = 3, MD = 2;
+    using U = Uni<NX, NU, MD>;
+    extern __shared__ __attribute__((aligned(16))) double lds_all[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    PLds<NX, NU, MD> L(lds_all, wave);
+    for (int i = threadIdx.x; i < PLds<NX, NU, MD>::DOUBLES; i += FW * WAVE) lds_all[i] = 0.01 * ((i * 7) % 13) + 0.5;
+    __syncthreads();
+    const int l0 = 6, s = 0, th = 3, nbt = 7, nown = 15;
+    double acc = 0.0;
+    long long t0 = clock64();
+    for (int r = 0; r < reps; r++) {
+        if (WHAT == 0) {
+            acc += p_stage_owned<NX, NU, MD>(C, Sy, L, l0, nown, s, wave, lane, 1.0, r & 1, false, false, 0u);
+            __syncthreads();
+        } else {
+            for (int loc0 = wave; loc0 < nbt; loc0 += 2 * FW) {
+                const int loc1 = loc0 + FW;
+                GhRegs<NX, NU, MD> g0, g1;
+                p_gh_load<NX, NU, MD>(C, Sy, L, p_slot_node<NX, NU, MD>(loc0, l0, s), loc0, false, 1u, lane, g0);
+                if (loc1 < nbt) p_gh_load<NX, NU, MD>(C, Sy, L, p_slot_node<NX, NU, MD>(loc1, l0, s), loc1, false, 1u, lane, g1);
+                acc += p_gh_compute<NX, NU, MD>(L, loc0, lane, g0, O.termCondition);
+                if (loc1 < nbt) acc += p_gh_compute<NX, NU, MD>(L, loc1, lane, g1, O.termCondition);
+            }
+            __syncthreads();
+        }
+        (void)th;
+    }
+    long long t1 = clock64();
+    if (threadIdx.x == 0) cycles[0] = (t1 - t0) / reps;
+    if (acc == 1.2345) sink[0] = acc;
+}
 }  // namespace
 
 template <int MASK>
@@ -116,6 +150,28 @@ int main() {
     run<128>("bare potrf (no inv store, no pmin)", c, O, dc, sink);
     run<63 - 4 + 64>("all with p_potrf_rows instead of factor_rows", c, O, dc, sink);
     run<63 - 4 + 128>("all with bare potrf", c, O, dc, sink);
+    {
+        /* constants of a 1023-node tree, arbitrary finite values */
+        const int Nn = 1023, NX = 8, NZ = 11;
+        std::vector<double> hab((size_t)(Nn - 1) * NX * NZ), hb((size_t)Nn * NX), hc((size_t)Nn * 16 * 5);
+        for (size_t i = 0; i < hab.size(); i++) hab[i] = 0.01 * (double)((i * 13) % 17);
+        for (size_t i = 0; i < hb.size(); i++) hb[i] = 0.1;
+        for (size_t i = 0; i < hc.size(); i += 5) { hc[i] = 0.1; hc[i + 1] = 0.5; hc[i + 2] = 2.0; hc[i + 3] = -0.5; hc[i + 4] = 0.5; }
+        double *dab, *db, *dcst;
+        (void)hipMalloc(&dab, hab.size() * 8); (void)hipMalloc(&db, hb.size() * 8); (void)hipMalloc(&dcst, hc.size() * 8);
+        (void)hipMemcpy(dab, hab.data(), hab.size() * 8, hipMemcpyHostToDevice); (void)hipMemcpy(db, hb.data(), hb.size() * 8, hipMemcpyHostToDevice);
+        (void)hipMemcpy(dcst, hc.data(), hc.size() * 8, hipMemcpyHostToDevice);
+        PConst C; memset(&C, 0, sizeof(C)); C.AB = dab; C.b = db; C.cst = dcst; C.ctrl = c; C.Np = 511;
+        PSync Sy; memset(&Sy, 0, sizeof(Sy));
+        const size_t lds = PLds<8, 3, 2>::DOUBLES * sizeof(double);
+        long long h = 0;
+        for (int it = 0; it < 2; it++) { hipLaunchKernelGGL(sg_bench<0>, dim3(1), dim3(FW * WAVE), lds, 0, C, O, Sy, dc, 300, sink); (void)hipDeviceSynchronize(); }
+        (void)hipMemcpy(&h, dc, 8, hipMemcpyDeviceToHost);
+        printf("%-44s %6lld cycles\n", "stage sweep, 15 nodes (+ barrier)", h);
+        for (int it = 0; it < 2; it++) { hipLaunchKernelGGL(sg_bench<1>, dim3(1), dim3(FW * WAVE), lds, 0, C, O, Sy, dc, 300, sink); (void)hipDeviceSynchronize(); }
+        (void)hipMemcpy(&h, dc, 8, hipMemcpyDeviceToHost);
+        printf("%-44s %6lld cycles\n", "G + H, 7 blocks (+ barrier)", h);
+    }
     {
         PSync Sy; memset(&Sy, 0, sizeof(Sy));
         const size_t lds = PLds<8, 3, 2>::DOUBLES * sizeof(double);
