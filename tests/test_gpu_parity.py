@@ -266,6 +266,13 @@ FUSED_CASES = [
     ("spring_4_1_2_h5", lambda: P.spring_mass(md=2, Nr=5, Nh=5)),
     ("spring_4_1_3_h3", lambda: P.spring_mass(md=3, Nr=3, Nh=3)),
     ("chain_8_3_2_h6_tighter", lambda: P.linear_chain(2, 6, 6, ubound=0.05)),
+    # every instantiated (nx, nu, md), single-tier trees, tiers of one level, four tiers
+    ("chain_2_1_2_h8", lambda: P.linear_chain(2, 8, 8, nm=1, nu=1)),
+    ("chain_8_2_2_h5", lambda: P.linear_chain(2, 5, 5, nm=4, nu=2)),
+    ("chain_4_1_3_h5", lambda: P.linear_chain(3, 5, 5, nm=2)),
+    ("chain_8_3_2_h2", lambda: P.linear_chain(2, 2, 2)),
+    ("chain_8_3_2_h3", lambda: P.linear_chain(2, 3, 3)),
+    ("chain_8_3_2_h10", lambda: P.linear_chain(2, 10, 10)),
 ]
 
 
