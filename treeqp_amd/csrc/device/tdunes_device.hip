@@ -113,16 +113,44 @@ struct Opts {
 __device__ __forceinline__ bool phase_main(const Ctrl *c, int h) { return !c->done && c->iter == h && !c->ls_pending; }
 __device__ __forceinline__ bool phase_trial(const Ctrl *c, int h, int t) { return !c->done && c->iter == h && c->ls_pending && c->ls_iter == t; }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+/* Cross-lane sums without LDS round trips (all 64 lanes must be active):
+ *   dpp_mov<row_ror:n>  rotate inside each row of 16 lanes (one VALU op per 32-bit half),
+ *   v_permlane16/32_swap (gfx950) fold the rows.  Every lane ends with the full sum. */
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_sum(double v) {
+    v += dpp_mov<0x128>(v); v += dpp_mov<0x124>(v); v += dpp_mov<0x122>(v); v += dpp_mov<0x121>(v);
     return v;
 }
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, WAVE));
+__device__ __forceinline__ double row16_max(double v) {
+    v = fmax(v, dpp_mov<0x128>(v)); v = fmax(v, dpp_mov<0x124>(v)); v = fmax(v, dpp_mov<0x122>(v)); v = fmax(v, dpp_mov<0x121>(v));
     return v;
 }
+/* value of lane l combined with lanes l ^ 16, l ^ 32, l ^ 48 */
+template <bool IS_MAX = false>
+__device__ __forceinline__ double rows_fold(double v) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const double x0 = __hiloint2double((int)b[0], (int)a[0]), x1 = __hiloint2double((int)b[1], (int)a[1]);
+    const double x = IS_MAX ? fmax(x0, x1) : x0 + x1;
+    const unsigned xl = (unsigned)__double2loint(x), xh = (unsigned)__double2hiint(x);
+    auto c = __builtin_amdgcn_permlane32_swap(xl, xl, false, false);
+    auto d = __builtin_amdgcn_permlane32_swap(xh, xh, false, false);
+    const double y0 = __hiloint2double((int)d[0], (int)c[0]), y1 = __hiloint2double((int)d[1], (int)c[1]);
+    return IS_MAX ? fmax(y0, y1) : y0 + y1;
+}
+__device__ __forceinline__ double wsum(double v) { return rows_fold<false>(row16_sum(v)); }
+__device__ __forceinline__ double wmax(double v) { return rows_fold<true>(row16_max(v)); }
+
+/* historical names, used by the generic kernels: same fixed-order reductions (a ds_bpermute butterfly cost
+ * ~1.4 k cycles per call, five of them per node in the stage sweep) */
+__device__ __forceinline__ double wave_sum(double v) { return wsum(v); }
+__device__ __forceinline__ double wave_max(double v) { return wmax(v); }
 
 /* The generic kernels work one wavefront per node / block on a private LDS window.  Their bodies are
  * device functions so that the same code runs (a) as one launch per phase and tree level, one wave per
@@ -766,6 +794,8 @@ struct tqgpu_solver {
     int use_gpersist = 1;
     int *d_lvl_first = nullptr;
     size_t lds_gp_wave = 0;         /* doubles of LDS per wave of g_persist */
+    size_t lds_gp_total = 0;        /* bytes of dynamic LDS of g_persist (windows + state mirror) */
+    bool gp_in_lds = false, gp_const_in_lds = false;
     double *pab = nullptr, *pcst = nullptr;
     bool need_pack = true;          /* QP data changed since the constants were packed */
     /* writable aliases of the const inputs */
@@ -1380,6 +1410,24 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
         const size_t per_wave = (std::max(std::max(s->lds_stage, s->lds_hess), std::max(s->lds_factor, s->lds_forward)) + 7) / 8 + 2;
         s->lds_gp_wave = per_wave;
         s->gpersist_ok = widest <= 6 * GP_WAVES && per_wave * 8 * GP_WAVES <= 64 * 1024;
+        /* LDS mirror of the mutable state (tdunes_gpersist.hpp): 16 node-sized vectors (rounded up to even), 4 block arrays */
+        {
+            auto ev = [](size_t n) { return (n + 1) & ~(size_t)1; };
+            const size_t sx = (size_t)s->sum_nx, su = (size_t)s->sum_nu;
+            const size_t mirror = 11 * ev(sx) + 5 * ev(su) + 2 * ev((size_t)s->sum_W) + 2 * ev((size_t)s->sum_Ut) + 2 * ev((size_t)Nn) + ev(sx + Nn + 1) + ev(su) * 0;
+            const size_t tables = (13 * ((size_t)Nn + 3)) / 2 + 16;            /* int tables, in doubles */
+            s->lds_gp_total = (per_wave * GP_WAVES + mirror + tables + 8) * 8;
+            s->gp_in_lds = s->gpersist_ok && s->lds_gp_total <= 150 * 1024;
+            const size_t consts = (ev((size_t)s->sum_A) + ev((size_t)s->sum_B) + 5 * ev(sx) + 4 * ev(su)) * 8;
+            s->gp_const_in_lds = s->gp_in_lds && s->lds_gp_total + consts <= 150 * 1024;
+            if (s->gp_const_in_lds) s->lds_gp_total += consts;
+            if (!s->gp_in_lds) s->lds_gp_total = per_wave * GP_WAVES * 8;
+            else if (s->lds_gp_total > 64 * 1024 &&
+                     hipFuncSetAttribute(reinterpret_cast<const void *>(g_persist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_gp_total) != hipSuccess) {
+                (void)hipGetLastError();
+                s->gp_in_lds = false; s->lds_gp_total = per_wave * GP_WAVES * 8;
+            }
+        }
         if (s->gpersist_ok) {
             if (hipMalloc(&s->d_lvl_first, sizeof(int) * s->lvl_first.size()) != hipSuccess ||
                 hipMemcpy(s->d_lvl_first, s->lvl_first.data(), sizeof(int) * s->lvl_first.size(), hipMemcpyHostToDevice) != hipSuccess)
@@ -1627,7 +1675,9 @@ int solve_begin(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx) {
             s->psync.seq = s->launch_no << 16;
             GParams gp;
             gp.lvl_first = s->d_lvl_first; gp.lam_init = s->d_lam_init; gp.hres = s->h_res; gp.seq = s->psync.seq; gp.lds_wave = (int)s->lds_gp_wave;
-            hipLaunchKernelGGL(g_persist, dim3(1), dim3(GP_WAVES * WAVE), s->lds_gp_wave * 8 * GP_WAVES, st, T, D, O, gp); cx.launches++;
+            gp.in_lds = s->gp_in_lds ? 1 : 0; gp.sum_nx = s->sum_nx; gp.sum_nu = s->sum_nu; gp.sum_W = s->sum_W; gp.sum_Ut = s->sum_Ut;
+            gp.const_in_lds = s->gp_const_in_lds ? 1 : 0; gp.sum_A = s->sum_A; gp.sum_B = s->sum_B;
+            hipLaunchKernelGGL(g_persist, dim3(1), dim3(GP_WAVES * WAVE), s->lds_gp_total, st, T, D, O, gp); cx.launches++;
         } else rcx = launch_persist(s, O, cx.launches, 1);
         if (rcx != TQGPU_OK) return rcx;
         cx.first_launch = false; cx.prelaunched = true;

@@ -70,40 +70,6 @@ __device__ __forceinline__ double rdlane(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
-/* Cross-lane sums without LDS round trips (all 64 lanes must be active):
- *   dpp_mov<row_ror:n>  rotate inside each row of 16 lanes (one VALU op per 32-bit half),
- *   v_permlane16/32_swap (gfx950) fold the rows.  Every lane ends with the full sum. */
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double row16_sum(double v) {
-    v += dpp_mov<0x128>(v); v += dpp_mov<0x124>(v); v += dpp_mov<0x122>(v); v += dpp_mov<0x121>(v);
-    return v;
-}
-__device__ __forceinline__ double row16_max(double v) {
-    v = fmax(v, dpp_mov<0x128>(v)); v = fmax(v, dpp_mov<0x124>(v)); v = fmax(v, dpp_mov<0x122>(v)); v = fmax(v, dpp_mov<0x121>(v));
-    return v;
-}
-/* value of lane l combined with lanes l ^ 16, l ^ 32, l ^ 48 */
-template <bool IS_MAX = false>
-__device__ __forceinline__ double rows_fold(double v) {
-    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
-    auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-    auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-    const double x0 = __hiloint2double((int)b[0], (int)a[0]), x1 = __hiloint2double((int)b[1], (int)a[1]);
-    const double x = IS_MAX ? fmax(x0, x1) : x0 + x1;
-    const unsigned xl = (unsigned)__double2loint(x), xh = (unsigned)__double2hiint(x);
-    auto c = __builtin_amdgcn_permlane32_swap(xl, xl, false, false);
-    auto d = __builtin_amdgcn_permlane32_swap(xh, xh, false, false);
-    const double y0 = __hiloint2double((int)d[0], (int)c[0]), y1 = __hiloint2double((int)d[1], (int)c[1]);
-    return IS_MAX ? fmax(y0, y1) : y0 + y1;
-}
-__device__ __forceinline__ double wsum(double v) { return rows_fold<false>(row16_sum(v)); }
-__device__ __forceinline__ double wmax(double v) { return rows_fold<true>(row16_max(v)); }
-
 /* 1/sqrt(p) for p > 0, 0 otherwise (non-positive pivot -> zero column, as dpotrf_l) */
 __device__ __forceinline__ double pivot_rsqrt(double p) {
     double y = __builtin_amdgcn_rsq(p);

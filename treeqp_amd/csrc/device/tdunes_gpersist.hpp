@@ -24,17 +24,70 @@ struct GParams {
     HostRes *hres;               /* pinned host result block */
     unsigned seq;                /* launch number (completion word of the result block) */
     int lds_wave;                /* doubles of LDS window per wave */
+    int in_lds;                  /* 1: the mutable state of the solve is mirrored in LDS for the whole launch */
+    int const_in_lds;            /* 1: ... and so are the constants (A, B, b, weights, linear terms, bounds) */
+    int sum_nx, sum_nu, sum_W, sum_Ut, sum_A, sum_B;
 };
 
-__global__ void __launch_bounds__(GP_WAVES * WAVE) g_persist(Tree T, Data D, Opts O, GParams G) {
+/* The state the phases read and write (block matrices, factors, residuals, steps, duals, node variables) is
+ * small for the trees this kernel is for -- it fits the 160 KB of LDS next to the per-wave windows.  The
+ * generic bodies address it through ordinary (generic address space) pointers, so pointing those at an LDS
+ * mirror turns every dependent global round trip (~1 us each, several per block step) into an LDS access.
+ * Constants (A, B, b, weights, bounds, index tables) stay in global memory: read-only, cached. */
+__device__ __forceinline__ double *gp_take(double *&cursor, int n) { double *p = cursor; cursor += (n + 1) & ~1; return p; }
+
+/* The two descriptor structs hold ~60 pointers.  As kernel arguments (or locals) they would have to live in
+ * scalar registers for the whole kernel -- 120 SGPRs, more than a wave has -- and every use would be a spill
+ * reload.  They live in LDS instead: the bodies fetch the pointer they need when they need it. */
+__global__ void __launch_bounds__(GP_WAVES * WAVE) g_persist(Tree T_in, Data D_in, Opts O, GParams G) {
+    __shared__ Data sD;
+    __shared__ Tree sT;
+    Data D = D_in;
+    Tree T = T_in;
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     __shared__ double sh[GP_WAVES];
     __shared__ int flag;
     Ctrl *c = D.ctrl;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double *lds = lds_all + (size_t)wave * G.lds_wave;
+    if (G.in_lds) {
+        double *cur_p = lds_all + (size_t)GP_WAVES * G.lds_wave;
+        const int sx = G.sum_nx, su = G.sum_nu, Nn_ = T.Nn;
+        D.Qinv = gp_take(cur_p, sx); D.Rinv = gp_take(cur_p, su);
+        D.qmod = gp_take(cur_p, sx); D.rmod = gp_take(cur_p, su); D.x = gp_take(cur_p, sx); D.u = gp_take(cur_p, su);
+        D.xUnc = gp_take(cur_p, sx); D.uUnc = gp_take(cur_p, su); D.QinvCal = gp_take(cur_p, sx); D.RinvCal = gp_take(cur_p, su);
+        D.lam0 = gp_take(cur_p, sx); D.lam1 = gp_take(cur_p, sx); D.dlam = gp_take(cur_p, sx); D.res = gp_take(cur_p, sx); D.resMod = gp_take(cur_p, sx);
+        D.invd = gp_take(cur_p, sx);
+        D.W = gp_take(cur_p, G.sum_W); D.CholW = gp_take(cur_p, G.sum_W); D.Ut = gp_take(cur_p, G.sum_Ut); D.CholUt = gp_take(cur_p, G.sum_Ut);
+        D.fval = gp_take(cur_p, Nn_); D.part_err = gp_take(cur_p, sx + Nn_ + 1); D.part_dot = gp_take(cur_p, Nn_);
+        if (G.const_in_lds) {
+            /* the bodies walk short runtime-bounded loops with one load per trip: from global memory that is one
+             * cache latency per trip, from LDS a tenth of it */
+            double *cA = gp_take(cur_p, G.sum_A), *cB = gp_take(cur_p, G.sum_B), *cb = gp_take(cur_p, sx);
+            double *cQd = gp_take(cur_p, sx), *cq = gp_take(cur_p, sx), *cxl = gp_take(cur_p, sx), *cxu = gp_take(cur_p, sx);
+            double *cRd = gp_take(cur_p, su), *cr = gp_take(cur_p, su), *cul = gp_take(cur_p, su), *cuu = gp_take(cur_p, su);
+            for (int i = threadIdx.x; i < G.sum_A; i += GP_WAVES * WAVE) cA[i] = D_in.A[i];
+            for (int i = threadIdx.x; i < G.sum_B; i += GP_WAVES * WAVE) cB[i] = D_in.B[i];
+            for (int i = threadIdx.x; i < sx; i += GP_WAVES * WAVE) { cb[i] = D_in.b[i]; cQd[i] = D_in.Qd[i]; cq[i] = D_in.q[i]; cxl[i] = D_in.xmin[i]; cxu[i] = D_in.xmax[i]; }
+            for (int i = threadIdx.x; i < su; i += GP_WAVES * WAVE) { cRd[i] = D_in.Rd[i]; cr[i] = D_in.r[i]; cul[i] = D_in.umin[i]; cuu[i] = D_in.umax[i]; }
+            D.A = cA; D.B = cB; D.b = cb; D.Qd = cQd; D.q = cq; D.xmin = cxl; D.xmax = cxu; D.Rd = cRd; D.r = cr; D.umin = cul; D.umax = cuu;
+        }
+        /* the index tables too: every block step starts with a chain of dependent table look-ups */
+        int *ip = reinterpret_cast<int *>(cur_p);
+        const int n1 = Nn_ + 1;
+        const int *src[13] = {T_in.dad, T_in.nk, T_in.kid0, T_in.nx, T_in.nu, T_in.xoff, T_in.uoff, T_in.aoff, T_in.boff, T_in.pos, T_in.bdim, T_in.woff, T_in.utoff};
+        const int len[13] = {Nn_, Nn_, Nn_, Nn_, Nn_, n1, n1, n1, n1, Nn_, Nn_, n1, n1};
+        int *dst[13];
+        for (int a = 0; a < 13; a++) { dst[a] = ip; ip += (len[a] + 1) & ~1; }
+        for (int a = 0; a < 13; a++) for (int i = threadIdx.x; i < len[a]; i += GP_WAVES * WAVE) dst[a][i] = src[a][i];
+        T.dad = dst[0]; T.nk = dst[1]; T.kid0 = dst[2]; T.nx = dst[3]; T.nu = dst[4]; T.xoff = dst[5]; T.uoff = dst[6];
+        T.aoff = dst[7]; T.boff = dst[8]; T.pos = dst[9]; T.bdim = dst[10]; T.woff = dst[11]; T.utoff = dst[12];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { sD = D; sT = T; }
+    __syncthreads();
     const unsigned long long t_start = wall_clock64();
-    const int Nn = T.Nn, Np = T.Np, Nh = T.Nh;
+    const int Nn = T_in.Nn, Np = T_in.Np, Nh = T_in.Nh;
     /* diagnostic (TREEQP_AMD_STAMPS): wall clock per phase, summed over the solve: 0 init+first sweep, 1 G, 2 H,
      * 3 F backward, 4 F forward, 5 L */
     unsigned long long acc_t[6] = {0, 0, 0, 0, 0, 0}, t_prev = t_start;
@@ -45,18 +98,18 @@ __global__ void __launch_bounds__(GP_WAVES * WAVE) g_persist(Tree T, Data D, Opt
         c->done = 0; c->status = 0; c->iter = 0; c->cur = 0; c->ls_pending = 0; c->ls_iter = 0; c->ls_total = 0; c->ls_last = 0;
         c->restart_counter = 0; c->n_reg = 0; c->tau = 0.0; c->tauPrev = 0.0; c->fval0 = 0.0; c->fval = 0.0; c->dot = 0.0; c->err = 0.0;
     }
-    for (int i = threadIdx.x; i < T.xoff[Nn]; i += GP_WAVES * WAVE) D.lam0[i] = G.lam_init[i];
-    if (D.Qinv) {
-        for (int i = threadIdx.x; i < T.xoff[Nn]; i += GP_WAVES * WAVE) D.Qinv[i] = 1.0 / D.Qd[i];     /* k_init */
-        for (int i = threadIdx.x; i < T.uoff[Nn]; i += GP_WAVES * WAVE) D.Rinv[i] = 1.0 / D.Rd[i];
+    for (int i = threadIdx.x; i < sT.xoff[Nn]; i += GP_WAVES * WAVE) sD.lam0[i] = G.lam_init[i];
+    if (sD.Qinv) {
+        for (int i = threadIdx.x; i < sT.xoff[Nn]; i += GP_WAVES * WAVE) sD.Qinv[i] = 1.0 / sD.Qd[i];     /* k_init */
+        for (int i = threadIdx.x; i < sT.uoff[Nn]; i += GP_WAVES * WAVE) sD.Rinv[i] = 1.0 / sD.Rd[i];
     }
     __syncthreads();
 
     /* first sweep at lambda0 (phase S of iteration 0) and fval0 */
-    for (int k = wave; k < Nn; k += GP_WAVES) stage_body(T, D, 0, k, lane, lds);
+    for (int k = wave; k < Nn; k += GP_WAVES) stage_body(sT, sD, 0, k, lane, lds);
     __syncthreads();
     {
-        const double f = block_reduce<false>(D.fval, Nn, sh);
+        const double f = block_reduce<false>(sD.fval, Nn, sh);
         if (threadIdx.x == 0) { c->fval0 = f; c->fval = f; }
     }
     __syncthreads();
@@ -64,10 +117,10 @@ __global__ void __launch_bounds__(GP_WAVES * WAVE) g_persist(Tree T, Data D, Opt
 
     for (;;) {
         /* ---- G: dual gradient + termination test (dual_Newton_tree.c:519-543) ---- */
-        for (int k = 1 + wave; k < Nn; k += GP_WAVES) grad_body(T, D, O.termCondition, k, lane);
+        for (int k = 1 + wave; k < Nn; k += GP_WAVES) grad_body(sT, sD, O.termCondition, k, lane);
         __syncthreads();
         {
-            double err = (O.termCondition == 2) ? block_reduce<true>(D.part_err + 1, Nn - 1, sh) : block_reduce<false>(D.part_err + 1, Nn - 1, sh);
+            double err = (O.termCondition == 2) ? block_reduce<true>(sD.part_err + 1, Nn - 1, sh) : block_reduce<false>(sD.part_err + 1, Nn - 1, sh);
             if (threadIdx.x == 0) {
                 if (O.termCondition == 1) err = sqrt(err);
                 c->err = err;
@@ -80,7 +133,7 @@ __global__ void __launch_bounds__(GP_WAVES * WAVE) g_persist(Tree T, Data D, Opt
         if (flag) break;
 
         /* ---- H: block dual Hessian (:551-615) ---- */
-        for (int p = wave; p < Np; p += GP_WAVES) hess_body(T, D, p, lane, lds);
+        for (int p = wave; p < Np; p += GP_WAVES) hess_body(sT, sD, p, lane, lds);
         __syncthreads();
         GP_MARK(2);
 
@@ -88,20 +141,20 @@ __global__ void __launch_bounds__(GP_WAVES * WAVE) g_persist(Tree T, Data D, Opt
          * parent's block), then forward substitution (:641-805) ---- */
         for (int lvl = Nh - 1; lvl >= 0; lvl--) {
             const int first = G.lvl_first[lvl], count = G.lvl_first[lvl + 1] - first;
-            for (int b = wave; b < count; b += GP_WAVES) factor_body(T, D, O, first + b, lane, lds);
+            for (int b = wave; b < count; b += GP_WAVES) factor_body(sT, sD, O, first + b, lane, lds);
             __syncthreads();
         }
         GP_MARK(3);
         for (int lvl = 1; lvl < Nh; lvl++) {
             const int first = G.lvl_first[lvl], count = G.lvl_first[lvl + 1] - first;
-            for (int b = wave; b < count; b += GP_WAVES) forward_body(T, D, first + b, lane, lds);
+            for (int b = wave; b < count; b += GP_WAVES) forward_body(sT, sD, first + b, lane, lds);
             __syncthreads();
         }
         GP_MARK(4);
 
         /* ---- L: direction test, then Armijo backtracking; every trial is a full stage sweep (:922-1019) ---- */
         {
-            const double s = block_reduce<false>(D.part_dot, Np, sh);
+            const double s = block_reduce<false>(sD.part_dot, Np, sh);
             if (threadIdx.x == 0) {
                 const double dotp = -s;
                 c->dot = dotp;
@@ -113,10 +166,10 @@ __global__ void __launch_bounds__(GP_WAVES * WAVE) g_persist(Tree T, Data D, Opt
         __syncthreads();
         if (flag) break;
         for (;;) {
-            for (int k = wave; k < Nn; k += GP_WAVES) stage_body(T, D, 1, k, lane, lds);
+            for (int k = wave; k < Nn; k += GP_WAVES) stage_body(sT, sD, 1, k, lane, lds);
             __syncthreads();
-            const double f = block_reduce<false>(D.fval, Nn, sh);
-            if (threadIdx.x == 0) { ls_decide_tail(c, D, O, f); flag = c->ls_pending; }
+            const double f = block_reduce<false>(sD.fval, Nn, sh);
+            if (threadIdx.x == 0) { ls_decide_tail(c, sD, O, f); flag = c->ls_pending; }
             __syncthreads();
             if (!flag) break;
         }
@@ -126,9 +179,19 @@ __global__ void __launch_bounds__(GP_WAVES * WAVE) g_persist(Tree T, Data D, Opt
         if (flag) break;
         __syncthreads();
     }
-    if (O.stamps && threadIdx.x == 0) for (int i = 0; i < 6; i++) { D.stamps[2 * i] = acc_t[i]; D.stamps[2 * i + 1] = 1ull; }
+    if (O.stamps && threadIdx.x == 0) for (int i = 0; i < 6; i++) { sD.stamps[2 * i] = acc_t[i]; sD.stamps[2 * i + 1] = 1ull; }
 #undef GP_MARK
 
+    /* the solution goes back to global memory (what tqgpu_get_solution and a warm-started next solve read) */
+    __syncthreads();
+    if (G.in_lds) {
+        const int sx = G.sum_nx, su = G.sum_nu;
+        for (int i = threadIdx.x; i < sx; i += GP_WAVES * WAVE) {
+            D_in.x[i] = sD.x[i]; D_in.xUnc[i] = sD.xUnc[i]; D_in.qmod[i] = sD.qmod[i]; D_in.QinvCal[i] = sD.QinvCal[i];
+            D_in.lam0[i] = sD.lam0[i]; D_in.lam1[i] = sD.lam1[i]; D_in.dlam[i] = sD.dlam[i]; D_in.res[i] = sD.res[i];
+        }
+        for (int i = threadIdx.x; i < su; i += GP_WAVES * WAVE) { D_in.u[i] = sD.u[i]; D_in.uUnc[i] = sD.uUnc[i]; D_in.rmod[i] = sD.rmod[i]; D_in.RinvCal[i] = sD.RinvCal[i]; }
+    }
     /* verdict to the host */
     __syncthreads();
     if (threadIdx.x == 0) {
