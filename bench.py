@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", choices=["batch", "shard"], default="batch", help="N > 1: independent trees (weak) or one sharded tree (strong)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--trees", type=int, default=1, help="independent trees per GPU solved by one batched call per step (throughput mode; default 1 = the latency metric)")
     args = ap.parse_args()
 
@@ -90,8 +91,15 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            # rehearsal: every rank on the devices that exist (round-robin), collectives on host tensors
+            local_rank = local_rank % max(1, torch.cuda.device_count())
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(args.backend)
+    red_dev = "cuda" if args.backend == "nccl" else "cpu"
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
@@ -162,9 +170,9 @@ def main():
     tot_iters, tmax = float(iters), elapsed
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        n = torch.tensor([float(iters)], dtype=torch.float64, device="cuda")
+        n = torch.tensor([float(iters)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(n, op=dist.ReduceOp.SUM)
         tmax = float(t.item())
         # batch: every rank solved its own tree; shard: all ranks worked on the same iterations
