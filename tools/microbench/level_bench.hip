@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(FW * WAVE) fwd_bench(long long *cycles, int re
             const int nb = U::width(t);
             if (wave < nb) {
                 const int loc = U::first(t) + wave;
-                dotp += p_forward<NX, NU, MD>(Sy, L, loc, loc, lane, (lds_cptr)(L.dl + (t ? (U::first(t - 1) + wave / MD) * D + (wave % MD) * NX : 0)), false, false, 0u);
+                dotp += p_forward<NX, NU, MD>(Sy, L, loc, 8 * (2 * loc + 1), loc, lane, (lds_cptr)(L.dl + (t ? (U::first(t - 1) + wave / MD) * D + (wave % MD) * NX : 0)), false, false, 0u);
             }
             lds_barrier();
         }
@@ -108,8 +108,8 @@ __global__ void __launch_bounds__(FW * WAVE) sg_bench(PConst C, Opts O, PSync Sy
             for (int loc0 = wave; loc0 < nbt; loc0 += 2 * FW) {
                 const int loc1 = loc0 + FW;
                 GhRegs<NX, NU, MD> g0, g1;
-                p_gh_load<NX, NU, MD>(C, Sy, L, p_slot_node<NX, NU, MD>(loc0, l0, s), loc0, false, 1u, lane, g0);
-                if (loc1 < nbt) p_gh_load<NX, NU, MD>(C, Sy, L, p_slot_node<NX, NU, MD>(loc1, l0, s), loc1, false, 1u, lane, g1);
+                p_gh_load<NX, NU, MD>(C, Sy, L, p_slot_node<NX, NU, MD>(loc0, l0, s, C), loc0, false, 1u, lane, g0);
+                if (loc1 < nbt) p_gh_load<NX, NU, MD>(C, Sy, L, p_slot_node<NX, NU, MD>(loc1, l0, s, C), loc1, false, 1u, lane, g1);
                 acc += p_gh_compute<NX, NU, MD>(L, loc0, lane, g0, O.termCondition);
                 if (loc1 < nbt) acc += p_gh_compute<NX, NU, MD>(L, loc1, lane, g1, O.termCondition);
             }

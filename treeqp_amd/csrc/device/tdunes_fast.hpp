@@ -47,8 +47,8 @@ struct Uni {
     static constexpr int KS = (NZ + 3) / 4;  /* MFMA k-steps                    */
     static constexpr int LDW = D + 1;        /* LDS row stride (bank spread)    */
     static constexpr int SCH = NX * NX + NX; /* Schur hand-off record: S (NX x NX) then v (NX) */
-    static constexpr int TH = (MD == 2) ? 3 : ((MD <= 4) ? 2 : 1);     /* tier height: MD^(TH-1) <= FW */
-    static constexpr int NBT = (MD == 2) ? 7 : (1 + MD);               /* blocks of a full tier subtree */
+    static constexpr int TH = (MD == 1) ? 8 : ((MD == 2) ? 3 : ((MD <= 4) ? 2 : 1));     /* tier height: MD^(TH-1) <= FW; chains (MD == 1): 8 levels per tier */
+    static constexpr int NBT = (MD == 1) ? 8 : ((MD == 2) ? 7 : (1 + MD));               /* blocks of a full tier subtree */
     static constexpr int WAVE_LDS = (D + 1) * LDW + D + NX + 8;        /* per-wave scratch (doubles) */
     static_assert(D % 4 == 0 && NX < 16, "Schur MFMA tile needs D % 4 == 0 and NX < 16");
     static constexpr int TIER_LDS = NBT * SCH + NBT * D + FW * WAVE_LDS + 16;   /* doubles per workgroup */

@@ -76,7 +76,15 @@ struct PConst {
     Ctrl *ctrl;
     const PDump *dump;
     int Np;                 /* number of parent nodes                                                              */
+    /* multistage trees (setup_multistage_tree(md, Nr, Nh), Nr < Nh: branching for Nr stages, then one child per
+     * node): the first nB nodes (levels < Nr) are numbered like a complete md-ary tree, below them every level
+     * has S = md^Nr nodes and the child of node k is k + S.  Uniform complete trees: S = 0. */
+    int S, nB, Nr;
 };
+
+/* first child of node k in the GLOBAL numbering, for a tier instantiated with branching MD (MD == 1: chain part) */
+template <int MD>
+__device__ __forceinline__ int kid0g(int k, const PConst &C) { return MD == 1 ? k + C.S : MD * k + 1; }
 
 /* hand-over buffers of the persistent path (zeroed once at creation, never reset) */
 struct PSync {
@@ -140,8 +148,9 @@ struct PLds {
 
 /* heap slot -> node / block index: slot q of the tier subtree s whose first block level is l0 */
 template <int NX, int NU, int MD>
-__device__ __forceinline__ int p_slot_node(int q, int l0, int s) {
+__device__ __forceinline__ int p_slot_node(int q, int l0, int s, const PConst &C) {
     using U = Uni<NX, NU, MD>;
+    if (MD == 1) return C.nB + (l0 - C.Nr + q) * C.S + s;        /* chain part: slot = level offset, s = scenario */
     int t = 0;
     while (q >= U::first(t + 1)) t++;
     return U::first(l0 + t) + s * U::width(t) + (q - U::first(t));
@@ -165,9 +174,9 @@ __device__ __forceinline__ void p_gh_load(const PConst &C, const PSync &Sy, cons
     const bool live = row < D;
     const int rowc = live ? row : 0;                         /* dead rows load row 0 and are masked */
     const int cidx = rowc / NX, r = rowc - cidx * NX;
-    const int k = U::kid0(p) + cidx;
+    const int k = kid0g<MD>(p, C) + cidx;
     const double *AB = C.AB + (size_t)(k - 1) * NX * NZ + r;
-    const int bo = U::bo(p);
+    const int bo = NX * kid0g<MD>(p, C);
     lds_cptr own = L.node_(loc);                             /* [x | u] then the clipped inverse Hessian, NZ apart */
 #pragma unroll
     for (int s = 0; s < U::KS; s++) {
@@ -380,9 +389,9 @@ __device__ __forceinline__ void p_schur(PLds<NX, NU, MD> &L, int loc, int lane, 
 /* forward step of block `loc` from LDS; the solution stays in LDS (dl).
  * from_parent: the block is my subtree root, the step of its owner node's duals comes from the parent
  * workgroup (tagged words, polled).  to_children: the block's children are tier subtree roots of the
- * tier below: they get a tagged copy of the solution. */
+ * tier below: they get a tagged copy of the solution.  ii: global block (= owner node), bo: offset of its duals. */
 template <int NX, int NU, int MD>
-__device__ __forceinline__ double p_forward(const PSync &Sy, PLds<NX, NU, MD> &L, int ii, int loc, int lane, lds_cptr delta_lds,
+__device__ __forceinline__ double p_forward(const PSync &Sy, PLds<NX, NU, MD> &L, int ii, int bo, int loc, int lane, lds_cptr delta_lds,
                                             bool from_parent, bool to_children, unsigned tag) {
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D;
@@ -430,7 +439,7 @@ __device__ __forceinline__ double p_forward(const PSync &Sy, PLds<NX, NU, MD> &L
     const double mine = s * inv;
     double pd = 0.0;
     if (lane < D) {
-        if (to_children && ok) st_tag(Sy.dlt + (size_t)(U::bo(ii) + lane) * 2, mine, tag);
+        if (to_children && ok) st_tag(Sy.dlt + (size_t)(bo + lane) * 2, mine, tag);
         if (ok) L.dl[loc * D + lane] = mine;              /* a step computed from a failed poll must not replace the last good one (it is written back on leaving) */
         pd = L.res[loc * D + lane] * mine;
     }
@@ -452,7 +461,7 @@ __device__ __forceinline__ double p_stage16(const PConst &C, const PSync &Sy, PL
     static_assert(NX + NU <= 16 && D <= 16, "16-lane stage needs nx+nu <= 16 and d <= 16");
     const bool parent = active && k < C.Np;
     const int nuk = parent ? NU : 0;
-    const int ko = U::bo(k);
+    const int ko = NX * kid0g<MD>(k, C);
     const bool isx = t < NX, live = active && t < NX + nuk;
     /* branch-free loads: every lane reads from a valid (clamped) address and masks afterwards */
     const bool pk = parent && t < D, ox = active && isx && k > 0;
@@ -466,7 +475,7 @@ __device__ __forceinline__ double p_stage16(const PConst &C, const PSync &Sy, PL
     double col[MD][NX];
 #pragma unroll
     for (int cc = 0; cc < MD; cc++) {
-        const int kid = pl ? U::kid0(k) + cc : 1;
+        const int kid = pl ? kid0g<MD>(k, C) + cc : 1;
         const double *cp = C.AB + (size_t)(kid - 1) * NX * NZ + (size_t)(pl ? t : 0) * NX;      /* column t of [A | B] */
 #pragma unroll
         for (int i = 0; i < NX; i++) col[cc][i] = cp[i];
@@ -526,6 +535,7 @@ __device__ __forceinline__ double p_stage16(const PConst &C, const PSync &Sy, PL
 struct PGeom {
     int n_tiers;
     int l0[8], l1[8], grid[8], wg0[8];      /* per tier: block levels [l0,l1), subtrees, first workgroup id */
+    int chain[8];                           /* multistage trees: the tier lies in the chain part (one block per level) */
     int G;
     const int *wg_of_block;                 /* blockIdx.x -> workgroup id: families of tier subtrees share an XCD (hardware
                                                places workgroup b on XCD b % 8), so most hand-overs stay inside one L2 */
@@ -588,7 +598,7 @@ __device__ __forceinline__ double p_stage_owned(const PConst &C, const PSync &Sy
     for (int base = 0; base < nown; base += FW * 4) {
         const int q = base + wave * 4 + grp;
         const bool active = q < nown;
-        const int k = active ? p_slot_node<NX, NU, MD>(q, l0, s) : 0;
+        const int k = active ? p_slot_node<NX, NU, MD>(q, l0, s, C) : 0;
         fsum += p_stage16<NX, NU, MD>(C, Sy, L, active ? q : 0, k, t16, gl, step, cb, active, init, to_parent, tag);
     }
     return rows_fold<false>(fsum);       /* every lane of a 16-lane group holds its group's sum */
@@ -633,24 +643,19 @@ __device__ __forceinline__ bool p_gather3(const PSync &Sy, PLds<NX, NU, MD> &L, 
     return true;
 }
 
+/* the life of one workgroup = one tier subtree: tier `tier`, subtree (complete part) or scenario (chain part) `s` */
 template <int NX, int NU, int MD>
-__global__ void __launch_bounds__(FW * WAVE) f_persist(PConst C, Opts O, PGeom Gm, PSync Sy, int prologue) {
+__device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeom &Gm, const PSync &Sy, int prologue, int wg, int tier, int s, double *lds_all) {
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D, NZ = U::NZ;
-    extern __shared__ __attribute__((aligned(16))) double lds_all[];
     Ctrl *c = C.ctrl;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     PLds<NX, NU, MD> L(lds_all, wave);
-    const int wg = Gm.wg_of_block[blockIdx.x];
-    /* my tier / subtree */
-    int tier = 0;
-    for (int i = 0; i < Gm.n_tiers; i++) if (wg >= Gm.wg0[i]) tier = i;
-    const int s = wg - Gm.wg0[tier];
     const int l0 = Gm.l0[tier], th = Gm.l1[tier] - l0;
     const bool is_top = tier == Gm.n_tiers - 1, is_bottom = tier == 0;
     const int nbt = U::first(th);                                      /* my blocks */
     const int nown = nbt + (is_bottom ? U::width(th) : 0);             /* nodes I own */
-    const int root_blk = U::first(l0) + s;                             /* subtree root block (= node) */
+    const int root_blk = p_slot_node<NX, NU, MD>(0, l0, s, C);         /* subtree root block (= node) */
     const unsigned long long t_start = wall_clock64();
     int cur = 0;
     unsigned nd = 0u;          /* stage sweeps (= {fval, dot} reductions) of this launch so far */
@@ -673,13 +678,13 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(PConst C, Opts O, PGeom G
         const double *lsrc = prologue ? dp->lam_init : (cur ? dp->lam1 : dp->lam0);
         for (int i = threadIdx.x; i < nbt * D; i += FW * WAVE) {
             const int loc = i / D, t = i - loc * D;
-            L.lamb_(cur, loc)[t] = lsrc[U::bo(p_slot_node<NX, NU, MD>(loc, l0, s)) + t];
+            L.lamb_(cur, loc)[t] = lsrc[NX * kid0g<MD>(p_slot_node<NX, NU, MD>(loc, l0, s, C), C) + t];
         }
         if (threadIdx.x < NX) L.lamroot[cur * NX + threadIdx.x] = root_blk > 0 ? lsrc[NX * root_blk + threadIdx.x] : 0.0;
         if (!prologue) {
             for (int i = threadIdx.x; i < nown * 16; i += FW * WAVE) {
                 const int q = i >> 4, t = i & 15;
-                const int k = p_slot_node<NX, NU, MD>(q, l0, s);
+                const int k = p_slot_node<NX, NU, MD>(q, l0, s, C);
                 lds_ptr ns = L.node_(q);
                 if (t < NX) { ns[t] = dp->x[NX * k + t]; ns[NZ + t] = dp->QinvCal[NX * k + t]; }
                 else if (t < NZ && k < C.Np) { ns[t] = dp->u[NU * k + t - NX]; ns[NZ + t] = dp->RinvCal[NU * k + t - NX]; }
@@ -718,8 +723,8 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(PConst C, Opts O, PGeom G
             for (int loc0 = wave; loc0 < nbt; loc0 += 2 * FW) {
                 const int loc1 = loc0 + FW;
                 GhRegs<NX, NU, MD> g0, g1;
-                p_gh_load<NX, NU, MD>(C, Sy, L, p_slot_node<NX, NU, MD>(loc0, l0, s), loc0, !is_bottom && loc0 >= nint, nd, lane, g0);
-                if (loc1 < nbt) p_gh_load<NX, NU, MD>(C, Sy, L, p_slot_node<NX, NU, MD>(loc1, l0, s), loc1, !is_bottom && loc1 >= nint, nd, lane, g1);
+                p_gh_load<NX, NU, MD>(C, Sy, L, p_slot_node<NX, NU, MD>(loc0, l0, s, C), loc0, !is_bottom && loc0 >= nint, nd, lane, g0);
+                if (loc1 < nbt) p_gh_load<NX, NU, MD>(C, Sy, L, p_slot_node<NX, NU, MD>(loc1, l0, s, C), loc1, !is_bottom && loc1 >= nint, nd, lane, g1);
                 double v = p_gh_compute<NX, NU, MD>(L, loc0, lane, g0, O.termCondition);
                 err = (O.termCondition == 2) ? fmax(err, v) : err + v;
                 if (loc1 < nbt) {
@@ -786,13 +791,13 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(PConst C, Opts O, PGeom G
             for (int t = th - 1; t >= 0; t--) {
                 const int nb = U::width(t);
                 if (wave < nb) {
-                    const int ii = U::first(l0 + t) + s * nb + wave, loc = U::first(t) + wave;
+                    const int loc = U::first(t) + wave, ii = p_slot_node<NX, NU, MD>(loc, l0, s, C);
                     const bool is_root = is_top && t == 0;
                     bool ok = true;
                     p_load_rows<NX, NU, MD>(L, loc, lane, is_root, Tc);
                     if (t < th - 1) sub_children<NX, NU, MD>((lds_cptr)(L.sch + (U::first(t + 1) + MD * wave) * U::SCH), lane, Tc);
                     else if (!is_bottom) {
-                        ok = p_sub_children_tagged<NX, NU, MD>(Sy, Sy.sch + (size_t)U::kid0(ii) * U::SCH * 2, tag_e, lane, Tc);
+                        ok = p_sub_children_tagged<NX, NU, MD>(Sy, Sy.sch + (size_t)kid0g<MD>(ii, C) * U::SCH * 2, tag_e, lane, Tc);
                         ok = __all(ok);
                         if (!ok && lane == 0) *L.abort = 1;
                     }
@@ -822,7 +827,7 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(PConst C, Opts O, PGeom G
                         }
                         const double mine = sv * myinv;
                         if (lane < D) {
-                            if (th == 1 && !is_bottom && ok) st_tag(Sy.dlt + (size_t)(U::bo(0) + lane) * 2, mine, tag_e);
+                            if (th == 1 && !is_bottom && ok) st_tag(Sy.dlt + (size_t)(NX * kid0g<MD>(0, C) + lane) * 2, mine, tag_e);
                             L.dl[lane] = mine; dotp = L.res[lane] * mine;
                         }
                         lds_fence();
@@ -840,10 +845,10 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(PConst C, Opts O, PGeom G
         for (int t = (is_top ? 1 : 0); t < th; t++) {
             const int nb = U::width(t);
             if (wave < nb) {
-                const int ii = U::first(l0 + t) + s * nb + wave, loc = U::first(t) + wave;
+                const int loc = U::first(t) + wave, ii = p_slot_node<NX, NU, MD>(loc, l0, s, C), bo = NX * kid0g<MD>(ii, C);
                 const bool to_children = !is_bottom && t == th - 1;
-                if (t == 0) dotp += p_forward<NX, NU, MD>(Sy, L, ii, loc, lane, (lds_cptr)L.dl, true, to_children, tag_e);
-                else dotp += p_forward<NX, NU, MD>(Sy, L, ii, loc, lane, (lds_cptr)(L.dl + (U::first(t - 1) + wave / MD) * D + (wave % MD) * NX), false, to_children, tag_e);
+                if (t == 0) dotp += p_forward<NX, NU, MD>(Sy, L, ii, bo, loc, lane, (lds_cptr)L.dl, true, to_children, tag_e);
+                else dotp += p_forward<NX, NU, MD>(Sy, L, ii, bo, loc, lane, (lds_cptr)(L.dl + (U::first(t - 1) + wave / MD) * D + (wave % MD) * NX), false, to_children, tag_e);
             }
             lds_barrier();
             if (t == 0 && *L.abort) { gone = true; break; }            /* the parent never delivered: the launch is over */
@@ -885,7 +890,7 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(PConst C, Opts O, PGeom G
         if (nd > 0u) {
             for (int i = threadIdx.x; i < nown * 16; i += FW * WAVE) {
                 const int q = i >> 4, t = i & 15;
-                const int k = p_slot_node<NX, NU, MD>(q, l0, s);
+                const int k = p_slot_node<NX, NU, MD>(q, l0, s, C);
                 lds_cptr ns = L.node_(q);
                 if (t < NX) {
                     const int o = NX * k + t;
@@ -898,16 +903,40 @@ __global__ void __launch_bounds__(FW * WAVE) f_persist(PConst C, Opts O, PGeom G
             double *ldst = cur ? dp->lam1 : dp->lam0;
             for (int i = threadIdx.x; i < nbt * D; i += FW * WAVE) {
                 const int loc = i / D, t = i - loc * D;
-                ldst[U::bo(p_slot_node<NX, NU, MD>(loc, l0, s)) + t] = L.lamb_(cur, loc)[t];
+                ldst[NX * kid0g<MD>(p_slot_node<NX, NU, MD>(loc, l0, s, C), C) + t] = L.lamb_(cur, loc)[t];
             }
         }
         if (have_dl) {
             for (int i = threadIdx.x; i < nbt * D; i += FW * WAVE) {
                 const int loc = i / D, t = i - loc * D;
-                dp->dlam[U::bo(p_slot_node<NX, NU, MD>(loc, l0, s)) + t] = L.dl[loc * D + t];
+                dp->dlam[NX * kid0g<MD>(p_slot_node<NX, NU, MD>(loc, l0, s, C), C) + t] = L.dl[loc * D + t];
             }
         }
     }
+}
+
+template <int NX, int NU, int MD>
+__global__ void __launch_bounds__(FW * WAVE) f_persist(PConst C, Opts O, PGeom Gm, PSync Sy, int prologue) {
+    extern __shared__ __attribute__((aligned(16))) double lds_all[];
+    const int wg = Gm.wg_of_block[blockIdx.x];
+    int tier = 0;
+    for (int i = 0; i < Gm.n_tiers; i++) if (wg >= Gm.wg0[i]) tier = i;
+    p_run<NX, NU, MD>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
+}
+
+/* multistage trees (branching for Nr stages, then one child per node -- the reference's setup_multistage_tree
+ * with Nr < Nh, its standard robust-horizon shape): the tiers of the branching part run as above, every scenario
+ * chain below is one more tier subtree with ONE block per level (instantiation MD = 1: blocks of nx rows).  A
+ * chain workgroup spreads G + H and the stage sweep over its four waves; its backward / forward sweeps are one
+ * wave walking down the chain, which is what a chain is. */
+template <int NX, int NU, int MD>
+__global__ void __launch_bounds__(FW * WAVE) f_mpersist(PConst C, Opts O, PGeom Gm, PSync Sy, int prologue) {
+    extern __shared__ __attribute__((aligned(16))) double lds_all[];
+    const int wg = Gm.wg_of_block[blockIdx.x];
+    int tier = 0;
+    for (int i = 0; i < Gm.n_tiers; i++) if (wg >= Gm.wg0[i]) tier = i;
+    if (Gm.chain[tier]) p_run<NX, NU, 1>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
+    else p_run<NX, NU, MD>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
 }
 
 /* packed constants of the persistent path (run whenever the QP data changed): [A | B] per edge and
