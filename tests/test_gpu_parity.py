@@ -276,6 +276,54 @@ FUSED_CASES = [
 ]
 
 
+# multistage trees (branching for Nr stages, then one child per node): the reference's setup_multistage_tree(md, Nr, Nh)
+MSTAGE_CASES = [
+    ("c1_spring_4_1_3_r2_h10", lambda: P.spring_mass()),                              # BASELINE C1
+    ("spring_4_1_3_r1_h4", lambda: P.spring_mass(md=3, Nr=1, Nh=4)),
+    ("spring_4_1_2_r3_h13", lambda: P.spring_mass(md=2, Nr=3, Nh=13)),                # chains of 10 levels: two stacked chain tiers
+    ("chain_8_3_2_r2_h6", lambda: P.linear_chain(2, 2, 6)),
+    ("chain_8_3_2_r4_h5", lambda: P.linear_chain(2, 4, 5)),                           # one chain level only
+    ("chain_8_2_2_r3_h8_tight", lambda: P.linear_chain(2, 3, 8, nm=4, nu=2, ubound=0.1)),
+]
+
+
+@pytest.mark.parametrize("name,make", MSTAGE_CASES, ids=[c[0] for c in MSTAGE_CASES])
+def test_multistage_tree_persistent_path(gpu, orc, name, make):
+    p = make()
+    flat = oracle_flat_from_lti(orc, p)
+    ref = orc.solve(flat, lambda0=p.lambda0)
+    rf, sf, _ = _solve_flat_tq(gpu, flat, p.lambda0, "auto")
+    rg, sg, _ = _solve_flat_tq(gpu, flat, p.lambda0, "generic")
+    g = gpu.TqGpu(flat["nk"], flat["nx"], flat["nu"])
+    assert g.path == 2, "multistage trees take the persistent single-launch path"
+    g.close()
+    assert rf["status"] == rg["status"] == ref["status"] == 0
+    assert rf["iter"] == rg["iter"] == ref["iter"] and rf["ls_total"] == rg["ls_total"] == ref["ls_total"]
+    assert rf["n_launches"] <= 3 < rg["n_launches"]                             # first solve: reciprocal weights + packed constants + THE launch
+    for sol in (sf, sg):
+        assert_solution_close(sol, ref, TOL)
+        assert orc.max_kkt(flat, sol) < 1e-8
+    assert_solution_close(sf, sg, TOL)
+
+
+def test_multistage_tree_backtracking_and_options(gpu, orc):
+    """Far start: Armijo backtracking ends the launch, the host runs the extra trials and relaunches; then ALWAYS regularisation."""
+    p = P.spring_mass(md=3, Nr=2, Nh=7)
+    flat = oracle_flat_from_lti(orc, p)
+    rng = np.random.Generator(np.random.PCG64(11))
+    lam0 = 5.0 * rng.standard_normal(len(p.lambda0))
+    ref = orc.solve(flat, lambda0=lam0)
+    assert ref["status"] == 0 and ref["ls_total"] > ref["iter"], "fixture should need backtracking"
+    rf, sf, _ = _solve_flat_tq(gpu, flat, lam0, "auto")
+    assert rf["status"] == 0 and rf["iter"] == ref["iter"] and rf["ls_total"] == ref["ls_total"]
+    assert_solution_close(sf, ref, 1e-9)
+    for opts in (dict(regType=1, regValue=1e-8), dict(termCondition=1), dict(maxIter=2)):
+        ref = orc.solve(flat, orc.default_opts(**opts), p.lambda0)
+        rf, sf, _ = _solve_flat_tq(gpu, flat, p.lambda0, "auto", **opts)
+        assert rf["status"] == ref["status"] and rf["iter"] == ref["iter"]
+        assert_solution_close(sf, ref, 1e-9, keys=("x", "u", "lam"))
+
+
 def _solve_flat_tq(gpu, flat, lambda0, path, **opts):
     os.environ["TREEQP_AMD_PATH"] = path
     try:
@@ -482,7 +530,7 @@ def test_batched_multi_tree_solve_matches_single_solves(gpu, orc):
         singles.append((g.solve(), g.solution()))
         g.close()
     mirrors = [gpu.TqGpu(f["nk"], f["nx"], f["nu"]).upload(f, p.lambda0) for p, f in zip(cases, flats)]
-    assert sorted(m.path for m in mirrors) == [2, 2, 2, 2, 2, 3]                # the spring-mass example tree is irregular: single-workgroup kernel
+    assert sorted(m.path for m in mirrors) == [2, 2, 2, 2, 2, 2]                # uniform and multistage trees: one persistent launch each
     for _ in range(2):                                                          # twice: hand-over tags must not collide across launches
         res = gpu.solve_batch(mirrors)
     for m, r, (r1, s1), f in zip(mirrors, res, singles, flats):

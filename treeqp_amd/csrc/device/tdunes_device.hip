@@ -817,6 +817,9 @@ struct tqgpu_solver {
     int fast = -1;            /* index into the instantiation table, -1: generic path only */
     int fNX = 0, fNU = 0, fMD = 0;
     int n_tiers = 0;          /* tiers of block levels, index 0 = bottom */
+    bool mstage = false;      /* multistage tree (branching for Nr stages, then chains): persistent kernel f_mpersist only */
+    int ms_Nr = 0, ms_S = 0, ms_nB = 0;
+    std::vector<int> tier_chain;
     std::vector<int> tier_l0, tier_l1, tier_grid;
     size_t lds_fast = 0, lds_fstage = 0;
     int use_fast = 1;         /* can be switched off (TREEQP_AMD_PATH=generic) */
@@ -947,6 +950,57 @@ void fast_geometry(int idx, int &TH, size_t &tier_lds, size_t &stage_lds) {
 #undef X
 }
 
+/* (NX, NU, MD) instantiations of the multistage persistent kernel: the chain part works on blocks of NX rows,
+ * which the MFMA Schur tile wants to be a multiple of 4 */
+#define MSTAGE_TABLE(X) X(0, 8, 3, 2) X(1, 4, 1, 2) X(2, 4, 1, 3) X(4, 8, 2, 2)
+
+/* multistage tree?  (setup_multistage_tree(md, Nr, Nh) with 1 <= Nr < Nh: every node above stage Nr has md
+ * children, every parent from stage Nr on has one; uniform nx, nu) */
+void detect_multistage(tqgpu_solver *s) {
+    s->mstage = false;
+    const int Nn = s->Nn, NX = s->nx[0], NU = s->nu[0], MD = s->nk[0], Nh = s->Nh;
+    if (Nh < 2 || MD < 2 || NX % 4 != 0) return;
+    int Nr = 0;
+    while (Nr < Nh) {
+        bool all = true;
+        for (int k = s->lvl_first[Nr]; k < s->lvl_first[Nr + 1]; k++) if (s->nk[k] != MD) { all = false; break; }
+        if (!all) break;
+        Nr++;
+    }
+    if (Nr < 1 || Nr >= Nh) return;
+    for (int k = 0; k < Nn; k++) {
+        if (s->nx[k] != NX) return;
+        if (k < s->Np) { if (s->nu[k] != NU) return; if (k >= s->lvl_first[Nr] && s->nk[k] != 1) return; }
+        else if (s->nu[k] != 0) return;
+    }
+    int idx = -1;
+#define X(i, nx, nu, md) if (NX == nx && NU == nu && MD == md) idx = i;
+    MSTAGE_TABLE(X)
+#undef X
+    if (idx < 0) return;
+    int S = 1;
+    for (int l = 0; l < Nr; l++) S *= MD;
+    s->fast = idx; s->fNX = NX; s->fNU = NU; s->fMD = MD;
+    s->mstage = true; s->ms_Nr = Nr; s->ms_S = S; s->ms_nB = s->lvl_first[Nr];
+    int TH = 1;
+    fast_geometry(idx, TH, s->lds_fast, s->lds_fstage);
+    s->tier_l0.clear(); s->tier_l1.clear(); s->tier_grid.clear(); s->tier_chain.clear();
+    /* chain part bottom-up in tiers of at most 8 levels (Uni<..., 1>::TH), then the branching part in tiers of TH levels */
+    for (int l1 = Nh; l1 > Nr;) {
+        const int l0 = std::max(Nr, l1 - 8);
+        s->tier_l0.push_back(l0); s->tier_l1.push_back(l1); s->tier_grid.push_back(S); s->tier_chain.push_back(1);
+        l1 = l0;
+    }
+    for (int l1 = Nr; l1 > 0;) {
+        const int l0 = std::max(0, l1 - TH);
+        int grid = 1;
+        for (int l = 0; l < l0; l++) grid *= MD;
+        s->tier_l0.push_back(l0); s->tier_l1.push_back(l1); s->tier_grid.push_back(grid); s->tier_chain.push_back(0);
+        l1 = l0;
+    }
+    s->n_tiers = (int)s->tier_l0.size();
+}
+
 /* uniform complete tree? (every node nx, every parent nu + md children, one leaf depth) */
 void detect_fast(tqgpu_solver *s) {
     s->fast = -1;
@@ -965,12 +1019,12 @@ void detect_fast(tqgpu_solver *s) {
     /* block levels 0 .. Nh-1 grouped bottom-up into tiers of TH levels; the top tier takes the rest */
     const int Nh = s->Nh;
     s->n_tiers = (Nh + TH - 1) / TH;
-    s->tier_l0.clear(); s->tier_l1.clear(); s->tier_grid.clear();
+    s->tier_l0.clear(); s->tier_l1.clear(); s->tier_grid.clear(); s->tier_chain.clear();
     for (int i = 0; i < s->n_tiers; i++) {
         const int l1 = Nh - i * TH, l0 = std::max(0, l1 - TH);
         int grid = 1;
         for (int l = 0; l < l0; l++) grid *= MD;
-        s->tier_l0.push_back(l0); s->tier_l1.push_back(l1); s->tier_grid.push_back(grid);
+        s->tier_l0.push_back(l0); s->tier_l1.push_back(l1); s->tier_grid.push_back(grid); s->tier_chain.push_back(0);
     }
 }
 
@@ -1170,20 +1224,33 @@ int setup_persist(tqgpu_solver *s, int device) {
     PGeom &G = s->geom;
     G.n_tiers = s->n_tiers;
     int wg = 0;
-    for (int i = 0; i < s->n_tiers; i++) { G.l0[i] = s->tier_l0[i]; G.l1[i] = s->tier_l1[i]; G.grid[i] = s->tier_grid[i]; G.wg0[i] = wg; wg += s->tier_grid[i]; }
+    for (int i = 0; i < s->n_tiers; i++) { G.l0[i] = s->tier_l0[i]; G.l1[i] = s->tier_l1[i]; G.grid[i] = s->tier_grid[i]; G.chain[i] = s->tier_chain[i]; G.wg0[i] = wg; wg += s->tier_grid[i]; }
     G.G = wg;
     int per_cu = 0;
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
-    switch (s->fast) {
+    if (!s->mstage) {
+        switch (s->fast) {
 #define X(idx, nx, nu, md)                                                                                                   \
     case idx:                                                                                                                \
         s->lds_persist = PLds<nx, nu, md>::DOUBLES * sizeof(double);                                                         \
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f_persist<nx, nu, md>, FW * WAVE, s->lds_persist));    \
         break;
-        FAST_TABLE(X)
+            FAST_TABLE(X)
 #undef X
-        default: break;
+            default: break;
+        }
+    } else {
+        switch (s->fast) {
+#define X(idx, nx, nu, md)                                                                                                   \
+    case idx:                                                                                                                \
+        s->lds_persist = std::max(PLds<nx, nu, md>::DOUBLES, PLds<nx, nu, 1>::DOUBLES) * sizeof(double);                     \
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f_mpersist<nx, nu, md>, FW * WAVE, s->lds_persist));   \
+        break;
+            MSTAGE_TABLE(X)
+#undef X
+            default: break;
+        }
     }
     /* every workgroup must be resident at once (they wait for each other); keep one block per CU of
      * margin against the occupancy query over-reporting (MI355X guide, "Residency and cooperative launch") */
@@ -1246,6 +1313,7 @@ int setup_persist(tqgpu_solver *s, int device) {
     PDump *dd = reinterpret_cast<PDump *>(pc + n_ab + n_cst);
     HIP_TRY(hipMemcpy(dd, &hd, sizeof(PDump), hipMemcpyHostToDevice));
     s->pconst.AB = s->pab; s->pconst.b = D.b; s->pconst.cst = s->pcst; s->pconst.ctrl = D.ctrl; s->pconst.dump = dd; s->pconst.Np = s->Np;
+    s->pconst.S = s->mstage ? s->ms_S : 0; s->pconst.nB = s->mstage ? s->ms_nB : s->Np; s->pconst.Nr = s->mstage ? s->ms_Nr : s->Nh;
     s->need_pack = true;
     s->persist_ok = true;
     return TQGPU_OK;
@@ -1263,11 +1331,20 @@ int launch_persist(tqgpu_solver *s, const Opts &O, int &launches, int prologue) 
         hipLaunchKernelGGL(k_pack_persist, dim3((n + 255) / 256), dim3(256), 0, st, s->Nn, s->Np, s->nx[0], s->nu[0], D, s->pab, s->pcst); launches++;
         s->need_pack = false;
     }
-    switch (s->fast) {
+    if (!s->mstage) {
+        switch (s->fast) {
 #define X(idx, nx, nu, md) case idx: hipLaunchKernelGGL((f_persist<nx, nu, md>), dim3(s->geom.G), dim3(FW * WAVE), s->lds_persist, st, s->pconst, O, s->geom, s->psync, prologue); break;
-        FAST_TABLE(X)
+            FAST_TABLE(X)
 #undef X
-        default: break;
+            default: break;
+        }
+    } else {
+        switch (s->fast) {
+#define X(idx, nx, nu, md) case idx: hipLaunchKernelGGL((f_mpersist<nx, nu, md>), dim3(s->geom.G), dim3(FW * WAVE), s->lds_persist, st, s->pconst, O, s->geom, s->psync, prologue); break;
+            MSTAGE_TABLE(X)
+#undef X
+            default: break;
+        }
     }
     launches++;
     return TQGPU_OK;
@@ -1310,6 +1387,7 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
     int rc = build_tables(s);
     if (rc != TQGPU_OK) { delete s; return rc; }
     detect_fast(s);
+    if (s->fast < 0) detect_multistage(s);
     {
         const char *env = getenv("TREEQP_AMD_PATH");
         if (env && strcmp(env, "generic") == 0) { s->use_fast = 0; s->use_gpersist = 0; }
@@ -1458,12 +1536,17 @@ extern "C" void tqgpu_destroy(tqgpu_solver *s) {
     delete s;
 }
 
+/* which path a mirror takes: persistent single launch (uniform or multistage trees), tiered launches (uniform
+ * trees only), single-workgroup persistent (small trees of any shape), launch per level */
+static bool persist_capable(const tqgpu_solver *s) { return s->fast >= 0 && s->use_fast && s->persist_ok && s->use_persist && s->nranks == 1; }
+static bool tiered_capable(const tqgpu_solver *s) { return s->fast >= 0 && s->use_fast && !s->mstage; }
 static bool uses_gpersist(const tqgpu_solver *s) {
-    return s->gpersist_ok && s->use_gpersist && !s->dense && s->nranks == 1 && !(s->fast >= 0 && s->use_fast);
+    return s->gpersist_ok && s->use_gpersist && !s->dense && s->nranks == 1 && !persist_capable(s) && !tiered_capable(s);
 }
 extern "C" int tqgpu_uses_fused_path(const tqgpu_solver *s) {
     if (!s) return 0;
-    if (s->fast >= 0 && s->use_fast) return s->persist_ok && s->use_persist && s->nranks == 1 ? 2 : 1;
+    if (persist_capable(s)) return 2;
+    if (tiered_capable(s)) return 1;
     return uses_gpersist(s) ? 3 : 0;
 }
 
@@ -1641,8 +1724,8 @@ int solve_begin(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx) {
     }
     s->iter_times.assign((size_t)std::max(o->maxIter, 1), NAN);
 
-    cx.fast = s->fast >= 0 && s->use_fast;
-    cx.persist = cx.fast && s->persist_ok && s->use_persist && s->nranks == 1 && !o->profile && o->maxIter > 0;
+    cx.fast = tiered_capable(s);
+    cx.persist = persist_capable(s) && !o->profile && o->maxIter > 0;
     cx.gpersist = !cx.persist && uses_gpersist(s) && !o->profile && o->maxIter > 0;
     if (cx.gpersist) cx.persist = true;                  /* same host flow: one launch, verdict through the result block */
     cx.ring = (int)(s->solve_no % EV_RING);
@@ -1803,7 +1886,7 @@ extern "C" int tqgpu_solve_batch(tqgpu_solver **solvers, int n, const tqgpu_opts
         int used = 0, j = i;
         for (; j < n; j++) {
             tqgpu_solver *s = solvers[j];
-            const bool persist_like = s->fast >= 0 && s->use_fast && s->persist_ok && s->use_persist && s->nranks == 1 && !o->profile && o->maxIter > 0;
+            const bool persist_like = persist_capable(s) && !o->profile && o->maxIter > 0;
             const bool gp_like = !persist_like && uses_gpersist(s) && !o->profile && o->maxIter > 0;
             const int need = persist_like ? s->geom.G : (gp_like ? 1 : s->co_capacity + 1);   /* launch-per-level mirrors go alone */
             if (j > i && (s->device != dev || used + need > s->co_capacity)) break;
@@ -1920,7 +2003,7 @@ extern "C" int tqgpu_shard_init(tqgpu_solver *s, int rank, int nranks, const voi
     if (!s || nranks < 1 || rank < 0 || rank >= nranks) return fail(TQGPU_EINVAL, "tqgpu_shard_init: bad arguments");
     HIP_TRY(hipSetDevice(s->device));
     if (nranks == 1) { s->nranks = 1; s->rank = 0; return TQGPU_OK; }
-    if (s->fast < 0 || !s->use_fast) return fail(TQGPU_EUNSUPPORTED, "sharding needs the fused uniform-tree path");
+    if (s->fast < 0 || !s->use_fast || s->mstage) return fail(TQGPU_EUNSUPPORTED, "sharding needs the fused uniform-tree path");
     s->nranks = nranks; s->rank = rank;
     int rc = shard_build_lists(s);
     if (rc) { s->nranks = 1; s->rank = 0; return rc; }
