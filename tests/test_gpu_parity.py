@@ -80,6 +80,37 @@ def test_x0_eliminated_spring_mass(gpu, orc):
     s.destroy()
 
 
+@pytest.mark.parametrize("make", [lambda: P.spring_mass(xmax1=0.2), lambda: P.linear_chain(2, 5, 5), lambda: P.linear_chain(2, 2, 6)],
+                         ids=["c1_multistage", "chain_uniform", "chain_multistage"])
+def test_x0_eliminated_trees_take_the_persistent_path(gpu, orc, make):
+    """nx[0] = 0 (tree_qp_in_eliminate_x0) on an otherwise uniform / multistage tree: embedded with phantom root
+    states, solved by one persistent launch; dimensions and solution at the ABI are those of the eliminated QP."""
+    p = make()
+    qp = product_qp_from_lti(gpu, p, eliminate_x0=True)
+    flat = qp.flat()
+    assert flat["nx"][0] == 0
+    ref = orc.solve(flat, lambda0=p.lambda0)
+    g = gpu.TqGpu(flat["nk"], flat["nx"], flat["nu"]).upload(flat, p.lambda0)
+    assert g.path == 2 and g.sum_nx == int(np.sum(flat["nx"]))
+    r = g.solve()
+    sol = g.solution()
+    g.close()
+    os.environ["TREEQP_AMD_PATH"] = "generic"
+    try:
+        gg = gpu.TqGpu(flat["nk"], flat["nx"], flat["nu"]).upload(flat, p.lambda0)
+    finally:
+        os.environ.pop("TREEQP_AMD_PATH", None)
+    assert gg.path == 0
+    rg = gg.solve()
+    sg = gg.solution()
+    gg.close()
+    assert r["status"] == rg["status"] == ref["status"] == 0
+    assert abs(r["iter"] - ref["iter"]) <= 2 and abs(rg["iter"] - ref["iter"]) <= 2
+    for sl in (sol, sg):
+        assert_solution_close(sl, ref, 1e-9)
+        assert orc.max_kkt(flat, sl) < 1e-8
+
+
 FLAT_CASES = [
     ("thesis", lambda: P.thesis_example()),
     ("irregular_dims", lambda: P.irregular_clipping_qp()),

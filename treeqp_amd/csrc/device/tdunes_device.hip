@@ -817,6 +817,7 @@ struct tqgpu_solver {
     int fast = -1;            /* index into the instantiation table, -1: generic path only */
     int fNX = 0, fNU = 0, fMD = 0;
     int n_tiers = 0;          /* tiers of block levels, index 0 = bottom */
+    int x_pad = 0, A_pad = 0; /* phantom root states of an x0-eliminated tree embedded in a uniform one (doubles in front of x-sized arrays / of A) */
     bool mstage = false;      /* multistage tree (branching for Nr stages, then chains): persistent kernel f_mpersist only */
     int ms_Nr = 0, ms_S = 0, ms_nB = 0;
     std::vector<int> tier_chain;
@@ -1388,6 +1389,17 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
     if (rc != TQGPU_OK) { delete s; return rc; }
     detect_fast(s);
     if (s->fast < 0) detect_multistage(s);
+    if (s->fast < 0 && nx[0] == 0 && Nn > 1 && nx[1] > 0 && !(getenv("TREEQP_AMD_PATH") && strcmp(getenv("TREEQP_AMD_PATH"), "generic") == 0)) {
+        /* x0 eliminated (tree_qp_in_eliminate_x0: nx[0] = 0, the form every MPC caller solves).  If the tree would be
+         * uniform / multistage with a full root node, give the root nx phantom states pinned to zero (bounds [0, 0],
+         * unit weight, no linear term, zero A columns for the root's children): the same QP, and it takes the
+         * persistent path.  The phantom entries sit in front of every x-sized array (A: in front of the first edges)
+         * and never leave the device: the setters / getters below skip them. */
+        s->nx[0] = nx[1];
+        if (build_tables(s) == TQGPU_OK) { detect_fast(s); if (s->fast < 0) detect_multistage(s); }
+        if (s->fast >= 0) { s->x_pad = nx[1]; s->A_pad = nk[0] * nx[1] * nx[1]; }
+        else { s->nx[0] = 0; s->fast = -1; s->mstage = false; if ((rc = build_tables(s)) != TQGPU_OK) { delete s; return rc; } }
+    }
     {
         const char *env = getenv("TREEQP_AMD_PATH");
         if (env && strcmp(env, "generic") == 0) { s->use_fast = 0; s->use_gpersist = 0; }
@@ -1471,6 +1483,11 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
     s->use_fast_orig = s->use_fast;
     s->d_mu_x = at<double>(base, o_mux); s->d_mu_u = at<double>(base, o_muu);
     s->d_lam_init = at<double>(base, o_lami);
+    if (s->x_pad) {
+        /* phantom root states: weight 1, everything else zero (the slab is zeroed) */
+        std::vector<double> ones((size_t)s->x_pad, 1.0);
+        if (hipMemcpy(s->Qd, ones.data(), sizeof(double) * ones.size(), hipMemcpyHostToDevice) != hipSuccess) return cleanup_fail(fail(TQGPU_ENODEVICE, "hipMemcpy failed"));
+    }
 
     if ((rc = allow_lds(k_stage, s->lds_stage)) || (rc = allow_lds(k_hess, s->lds_hess)) ||
         (rc = allow_lds(k_factor, s->lds_factor)) || (rc = allow_lds(k_forward, s->lds_forward)))
@@ -1561,10 +1578,10 @@ extern "C" int tqgpu_get_stamps(tqgpu_solver *s, unsigned long long *out, int ca
 
 extern "C" int tqgpu_dims(const tqgpu_solver *s, int *sum_nx, int *sum_nu, int *sum_lam, int *sum_A, int *sum_B) {
     if (!s) return fail(TQGPU_EINVAL, "null solver");
-    if (sum_nx) *sum_nx = s->sum_nx;
+    if (sum_nx) *sum_nx = s->sum_nx - s->x_pad;
     if (sum_nu) *sum_nu = s->sum_nu;
     if (sum_lam) *sum_lam = s->sum_lam;
-    if (sum_A) *sum_A = s->sum_A;
+    if (sum_A) *sum_A = s->sum_A - s->A_pad;
     if (sum_B) *sum_B = s->sum_B;
     return TQGPU_OK;
 }
@@ -1578,7 +1595,7 @@ extern "C" int tqgpu_dims(const tqgpu_solver *s, int *sum_nx, int *sum_nu, int *
 extern "C" int tqgpu_set_dynamics(tqgpu_solver *s, const double *A, const double *B, const double *b) {
     if (!s) return fail(TQGPU_EINVAL, "null solver");
     HIP_TRY(hipSetDevice(s->device));
-    H2D(s->A, A, s->sum_A); H2D(s->B, B, s->sum_B);
+    H2D(s->A + s->A_pad, A, s->sum_A - s->A_pad); H2D(s->B, B, s->sum_B);
     H2D(s->b + s->nx0, b, s->sum_lam);              /* node-indexed on the device: root slot unused */
     HIP_TRY(hipStreamSynchronize(s->stream));       /* the caller may reuse its buffers */
     s->need_pack = true;
@@ -1588,7 +1605,7 @@ extern "C" int tqgpu_set_dynamics(tqgpu_solver *s, const double *A, const double
 extern "C" int tqgpu_set_objective_diag(tqgpu_solver *s, const double *Qd, const double *Rd, const double *q, const double *r) {
     if (!s) return fail(TQGPU_EINVAL, "null solver");
     HIP_TRY(hipSetDevice(s->device));
-    H2D(s->Qd, Qd, s->sum_nx); H2D(s->Rd, Rd, s->sum_nu); H2D(s->q, q, s->sum_nx); H2D(s->r, r, s->sum_nu);
+    H2D(s->Qd + s->x_pad, Qd, s->sum_nx - s->x_pad); H2D(s->Rd, Rd, s->sum_nu); H2D(s->q + s->x_pad, q, s->sum_nx - s->x_pad); H2D(s->r, r, s->sum_nu);
     HIP_TRY(hipStreamSynchronize(s->stream));
     s->need_init = true;
     s->need_pack = true;
@@ -1607,8 +1624,16 @@ extern "C" int tqgpu_set_objective_dense(tqgpu_solver *s, const double *Q, const
     std::vector<double> H((size_t)std::max(s->poff[s->Nn], 1), 0.0);
     size_t oq = 0, orr = 0, os = 0;
     for (int k = 0; k < s->Nn; k++) {
-        const int nx = s->nx[k], nu = s->nu[k], nz = nx + nu;
+        const int nu = s->nu[k], nz = s->nx[k] + nu;
         double *Hk = H.data() + s->poff[k];
+        if (k == 0 && s->x_pad) {
+            /* phantom root states: identity weight, no coupling; the caller's node 0 has no Q and no S */
+            for (int i = 0; i < s->x_pad; i++) Hk[i + (size_t)i * nz] = 1.0;
+            for (int j = 0; j < nu; j++) for (int i = 0; i < nu; i++) Hk[s->x_pad + i + (size_t)(s->x_pad + j) * nz] = R ? R[orr + i + (size_t)j * nu] : 0.0;
+            orr += (size_t)nu * nu;
+            continue;
+        }
+        const int nx = s->nx[k];
         for (int j = 0; j < nx; j++) for (int i = 0; i < nx; i++) Hk[i + (size_t)j * nz] = Q[oq + i + (size_t)j * nx];
         for (int j = 0; j < nu; j++) for (int i = 0; i < nu; i++) Hk[nx + i + (size_t)(nx + j) * nz] = R ? R[orr + i + (size_t)j * nu] : 0.0;
         for (int j = 0; j < nx; j++) for (int i = 0; i < nu; i++) {          /* S is nu x nx */
@@ -1619,8 +1644,8 @@ extern "C" int tqgpu_set_objective_dense(tqgpu_solver *s, const double *Q, const
         oq += (size_t)nx * nx; orr += (size_t)nu * nu; os += (size_t)nu * nx;
     }
     H2D(s->d_Hd, H.data(), s->poff[s->Nn]);
-    H2D(s->q, q, s->sum_nx); H2D(s->r, r, s->sum_nu);
-    HIP_TRY(hipMemsetAsync(s->Qd, 0, sizeof(double) * (size_t)std::max(s->sum_nx, 1), s->stream));
+    H2D(s->q + s->x_pad, q, s->sum_nx - s->x_pad); H2D(s->r, r, s->sum_nu);
+    if (s->sum_nx - s->x_pad > 0) HIP_TRY(hipMemsetAsync(s->Qd + s->x_pad, 0, sizeof(double) * (size_t)(s->sum_nx - s->x_pad), s->stream));
     HIP_TRY(hipMemsetAsync(s->Rd, 0, sizeof(double) * (size_t)std::max(s->sum_nu, 1), s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     s->dense = true; s->need_dense_init = true; s->D.dense = 1;
@@ -1631,7 +1656,7 @@ extern "C" int tqgpu_set_objective_dense(tqgpu_solver *s, const double *Q, const
 extern "C" int tqgpu_set_bounds(tqgpu_solver *s, const double *xmin, const double *xmax, const double *umin, const double *umax) {
     if (!s) return fail(TQGPU_EINVAL, "null solver");
     HIP_TRY(hipSetDevice(s->device));
-    H2D(s->xmin, xmin, s->sum_nx); H2D(s->xmax, xmax, s->sum_nx); H2D(s->umin, umin, s->sum_nu); H2D(s->umax, umax, s->sum_nu);
+    H2D(s->xmin + s->x_pad, xmin, s->sum_nx - s->x_pad); H2D(s->xmax + s->x_pad, xmax, s->sum_nx - s->x_pad); H2D(s->umin, umin, s->sum_nu); H2D(s->umax, umax, s->sum_nu);
     HIP_TRY(hipStreamSynchronize(s->stream));
     s->need_pack = true;
     return TQGPU_OK;
@@ -2113,9 +2138,9 @@ extern "C" int tqgpu_get_solution(tqgpu_solver *s, double *x, double *u, double 
         hipLaunchKernelGGL(k_export_mu, dim3((n + 255) / 256), dim3(256), 0, st, s->sum_nx, s->sum_nu, D, s->d_mu_x, s->d_mu_u);
     }
 #define D2H(dst, src, count) do { if ((dst) && (count) > 0) HIP_TRY(hipMemcpyAsync((dst), (src), sizeof(double) * (size_t)(count), hipMemcpyDeviceToHost, st)); } while (0)
-    D2H(x, D.x, s->sum_nx); D2H(u, D.u, s->sum_nu);
+    D2H(x, D.x + s->x_pad, s->sum_nx - s->x_pad); D2H(u, D.u, s->sum_nu);
     D2H(lam, lamc + s->nx0, s->sum_lam); D2H(dlam, D.dlam + s->nx0, s->sum_lam);
-    D2H(mu_x, s->d_mu_x, s->sum_nx); D2H(mu_u, s->d_mu_u, s->sum_nu);
+    D2H(mu_x, s->d_mu_x + s->x_pad, s->sum_nx - s->x_pad); D2H(mu_u, s->d_mu_u, s->sum_nu);
 #undef D2H
     HIP_TRY(hipStreamSynchronize(st));
     return TQGPU_OK;
