@@ -81,6 +81,12 @@ int tqgpu_set_objective_diag(tqgpu_solver *s, const double *Qd, const double *Rd
  * S (nu x nx) column major, then q, r.  Bounds are ignored while it is selected. */
 int tqgpu_set_objective_dense(tqgpu_solver *s, const double *Q, const double *R, const double *S, const double *q, const double *r);
 int tqgpu_set_bounds(tqgpu_solver *s, const double *xmin, const double *xmax, const double *umin, const double *umax);
+/* Everything above in one call (NULL = leave alone) plus the starting duals: compared with a pinned host mirror of
+ * what the device holds, only what changed is uploaded, without synchronisation.  This is what the drop-in
+ * treeqp_tdunes_solve uses, which -- like the reference, dual_Newton_tree.c:1142-1160 -- re-reads qp_in at every solve. */
+int tqgpu_set_problem(tqgpu_solver *s, const double *A, const double *B, const double *b,
+                      const double *Qd, const double *Rd, const double *q, const double *r,
+                      const double *xmin, const double *xmax, const double *umin, const double *umax, const double *lambda);
 int tqgpu_set_lambda(tqgpu_solver *s, const double *lambda);   /* NULL = zeros */
 
 int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *opts, tqgpu_result *res);

@@ -212,6 +212,34 @@ def test_mpc_loop_updates_x0_after_elimination(gpu, orc):
     s.destroy()
 
 
+def test_resolve_after_changing_each_input_array(gpu, orc):
+    """treeqp_tdunes_solve re-reads qp_in at every call (dual_Newton_tree.c:1142-1160); the device mirror uploads
+    only what changed -- every class of change (b, q/r, Q/R, bounds, A/B) must reach the device."""
+    p = P.linear_chain(2, 5, 5)
+    qp = product_qp_from_lti(gpu, p)
+    s = gpu.TdunesSolver(qp)
+    rng = np.random.default_rng(3)
+
+    def check():
+        s.set_dual_initialization(np.zeros_like(p.lambda0))
+        assert s.solve() == 0
+        flat = qp.flat()
+        ref = orc.solve(flat, lambda0=None)
+        assert ref["status"] == 0 and qp.info["iter"] == ref["iter"]
+        assert_solution_close(qp.solution(), ref, TOL)
+
+    check()
+    check()                                                          # nothing changed
+    n, m = p.nx, p.nu
+    A0, B0 = p.A[: n * n], p.B[: n * m]
+    qp.set_edge_dynamics(3, A0, B0, 0.1 * rng.standard_normal(n)); check()                      # b only
+    qp.set_node_objective_diag(5, p.Qd, p.Rd, 0.2 * rng.standard_normal(n), 0.2 * rng.standard_normal(m)); check()   # q, r
+    qp.set_node_objective_diag(2, 3.0 * p.Qd, 0.5 * p.Rd, np.zeros(n), np.zeros(m)); check()    # Q, R (new stage inverses)
+    qp.set_node_bounds(1, -2.5 * np.ones(n), 2.5 * np.ones(n), -0.1 * np.ones(m), 0.1 * np.ones(m)); check()
+    qp.set_edge_dynamics(7, 0.9 * A0, 1.1 * B0, np.zeros(n)); check()                            # A, B
+    s.destroy()
+
+
 # --- full BASELINE sizes: size-independent properties ------------------------------------------
 
 @pytest.mark.parametrize("make", [lambda: P.linear_chain(2, 11, 11)], ids=["c3_chain_4095"])

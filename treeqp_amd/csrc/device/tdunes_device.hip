@@ -757,13 +757,6 @@ __global__ void __launch_bounds__(WAVE) k_ls_decide_parts(Data D, Opts O, const 
 #include "tdunes_persist.hpp"
 #include "tdunes_gpersist.hpp"
 
-/* export_mu (clipping.c:386-399): mu = Q .* (xUnc - x) */
-__global__ void k_export_mu(int n_x, int n_u, Data D, double *mu_x, double *mu_u) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_x) mu_x[i] = D.dense ? 0.0 : D.Qd[i] * fma(-1.0, D.x[i], D.xUnc[i]);      /* dense stage solver: unconstrained */
-    if (i < n_u) mu_u[i] = D.dense ? 0.0 : D.Rd[i] * fma(-1.0, D.u[i], D.uUnc[i]);
-}
-
 }  // namespace
 
 /* ============================================================================================ */
@@ -817,6 +810,11 @@ struct tqgpu_solver {
     int fast = -1;            /* index into the instantiation table, -1: generic path only */
     int fNX = 0, fNU = 0, fMD = 0;
     int n_tiers = 0;          /* tiers of block levels, index 0 = bottom */
+    /* pinned host mirrors: the inputs in slab layout (compare-and-copy uploads of what changed, no synchronisation),
+     * the solution in one piece */
+    char *h_in = nullptr; size_t in_off0 = 0, in_bytes = 0; bool in_valid = false;
+    double *h_lam = nullptr; bool lam_valid = false;
+    double *d_out = nullptr, *h_out = nullptr; size_t out_doubles = 0;
     int x_pad = 0, A_pad = 0; /* phantom root states of an x0-eliminated tree embedded in a uniform one (doubles in front of x-sized arrays / of A) */
     bool mstage = false;      /* multistage tree (branching for Nr stages, then chains): persistent kernel f_mpersist only */
     int ms_Nr = 0, ms_S = 0, ms_nB = 0;
@@ -1369,6 +1367,20 @@ void launch_generic_iteration(tqgpu_solver *s, const Opts &O, int h, int &launch
     hipLaunchKernelGGL(k_ls_decide, dim3(1), dim3(256), 0, st, T, D, O, h, 1, 0); launches++;
 }
 
+/* solution export in one piece: out = [x | u | lam | dlam | mu_x | mu_u] (x and mu_x without the phantom root
+ * states), mu = Q .* (xUnc - x) (export_mu, clipping.c:386-399) */
+__global__ void k_export_all(int n_x, int n_u, int n_lam, int x_pad, int nx0, Data D, const double *lamc, double *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double *ox = out, *ou = ox + n_x, *ol = ou + n_u, *od = ol + n_lam, *omx = od + n_lam, *omu = omx + n_x;
+    if (i < n_x) {
+        const int j = i + x_pad;
+        ox[i] = D.x[j];
+        omx[i] = D.dense ? 0.0 : D.Qd[j] * fma(-1.0, D.x[j], D.xUnc[j]);
+    }
+    if (i < n_u) { ou[i] = D.u[i]; omu[i] = D.dense ? 0.0 : D.Rd[i] * fma(-1.0, D.u[i], D.uUnc[i]); }
+    if (i < n_lam) { ol[i] = lamc[nx0 + i]; od[i] = D.dlam[nx0 + i]; }
+}
+
 }  // namespace
 
 extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *nk, const int *nx, const int *nu) {
@@ -1483,6 +1495,13 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
     s->use_fast_orig = s->use_fast;
     s->d_mu_x = at<double>(base, o_mux); s->d_mu_u = at<double>(base, o_muu);
     s->d_lam_init = at<double>(base, o_lami);
+    s->in_off0 = o_A; s->in_bytes = o_Qinv - o_A;
+    s->out_doubles = 2 * (size_t)(s->sum_nx - s->x_pad) + 2 * (size_t)s->sum_nu + 2 * (size_t)s->sum_lam;
+    if (hipHostMalloc((void **)&s->h_in, std::max<size_t>(s->in_bytes, 8), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **)&s->h_lam, sizeof(double) * (size_t)std::max(s->sum_nx, 1), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **)&s->h_out, sizeof(double) * std::max<size_t>(s->out_doubles, 1), hipHostMallocDefault) != hipSuccess ||
+        hipMalloc(&s->d_out, sizeof(double) * std::max<size_t>(s->out_doubles, 1)) != hipSuccess)
+        return cleanup_fail(fail(TQGPU_ENOMEM, "allocation of the host mirrors failed"));
     if (s->x_pad) {
         /* phantom root states: weight 1, everything else zero (the slab is zeroed) */
         std::vector<double> ones((size_t)s->x_pad, 1.0);
@@ -1547,6 +1566,10 @@ extern "C" void tqgpu_destroy(tqgpu_solver *s) {
     if (s->sync_slab) (void)hipFree(s->sync_slab);
     if (s->pconst_slab) (void)hipFree(s->pconst_slab);
     if (s->wg_map) (void)hipFree(s->wg_map);
+    if (s->h_in) (void)hipHostFree(s->h_in);
+    if (s->h_lam) (void)hipHostFree(s->h_lam);
+    if (s->h_out) (void)hipHostFree(s->h_out);
+    if (s->d_out) (void)hipFree(s->d_out);
     if (s->d_lvl_first) (void)hipFree(s->d_lvl_first);
     if (s->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(s->comm);
     if (s->slab) (void)hipFree(s->slab);
@@ -1595,6 +1618,7 @@ extern "C" int tqgpu_dims(const tqgpu_solver *s, int *sum_nx, int *sum_nu, int *
 extern "C" int tqgpu_set_dynamics(tqgpu_solver *s, const double *A, const double *B, const double *b) {
     if (!s) return fail(TQGPU_EINVAL, "null solver");
     HIP_TRY(hipSetDevice(s->device));
+    s->in_valid = false;
     H2D(s->A + s->A_pad, A, s->sum_A - s->A_pad); H2D(s->B, B, s->sum_B);
     H2D(s->b + s->nx0, b, s->sum_lam);              /* node-indexed on the device: root slot unused */
     HIP_TRY(hipStreamSynchronize(s->stream));       /* the caller may reuse its buffers */
@@ -1605,6 +1629,7 @@ extern "C" int tqgpu_set_dynamics(tqgpu_solver *s, const double *A, const double
 extern "C" int tqgpu_set_objective_diag(tqgpu_solver *s, const double *Qd, const double *Rd, const double *q, const double *r) {
     if (!s) return fail(TQGPU_EINVAL, "null solver");
     HIP_TRY(hipSetDevice(s->device));
+    s->in_valid = false;
     H2D(s->Qd + s->x_pad, Qd, s->sum_nx - s->x_pad); H2D(s->Rd, Rd, s->sum_nu); H2D(s->q + s->x_pad, q, s->sum_nx - s->x_pad); H2D(s->r, r, s->sum_nu);
     HIP_TRY(hipStreamSynchronize(s->stream));
     s->need_init = true;
@@ -1643,6 +1668,7 @@ extern "C" int tqgpu_set_objective_dense(tqgpu_solver *s, const double *Q, const
         }
         oq += (size_t)nx * nx; orr += (size_t)nu * nu; os += (size_t)nu * nx;
     }
+    s->in_valid = false;
     H2D(s->d_Hd, H.data(), s->poff[s->Nn]);
     H2D(s->q + s->x_pad, q, s->sum_nx - s->x_pad); H2D(s->r, r, s->sum_nu);
     if (s->sum_nx - s->x_pad > 0) HIP_TRY(hipMemsetAsync(s->Qd + s->x_pad, 0, sizeof(double) * (size_t)(s->sum_nx - s->x_pad), s->stream));
@@ -1656,6 +1682,7 @@ extern "C" int tqgpu_set_objective_dense(tqgpu_solver *s, const double *Q, const
 extern "C" int tqgpu_set_bounds(tqgpu_solver *s, const double *xmin, const double *xmax, const double *umin, const double *umax) {
     if (!s) return fail(TQGPU_EINVAL, "null solver");
     HIP_TRY(hipSetDevice(s->device));
+    s->in_valid = false;
     H2D(s->xmin + s->x_pad, xmin, s->sum_nx - s->x_pad); H2D(s->xmax + s->x_pad, xmax, s->sum_nx - s->x_pad); H2D(s->umin, umin, s->sum_nu); H2D(s->umax, umax, s->sum_nu);
     HIP_TRY(hipStreamSynchronize(s->stream));
     s->need_pack = true;
@@ -1666,9 +1693,55 @@ extern "C" int tqgpu_set_lambda(tqgpu_solver *s, const double *lambda) {
     if (!s) return fail(TQGPU_EINVAL, "null solver");
     HIP_TRY(hipSetDevice(s->device));
     /* kept in a resident buffer: every tqgpu_solve starts from it (device-to-device copy) */
+    s->lam_valid = false;
     if (lambda) { H2D(s->d_lam_init + s->nx0, lambda, s->sum_lam); }
     else HIP_TRY(hipMemsetAsync(s->d_lam_init, 0, sizeof(double) * (size_t)s->sum_nx, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
+    return TQGPU_OK;
+}
+/* The whole clipping QP (and the starting duals) in one call, for callers that hand over all their data before every
+ * solve (treeqp_tdunes_solve re-reads qp_in each time, dual_Newton_tree.c:1142-1160): every array is compared with
+ * the pinned host mirror of what the device holds and only what changed is copied and uploaded -- asynchronously,
+ * from pinned memory, with no synchronisation (the solve is stream-ordered behind it).  An MPC loop that only
+ * moves x0 re-uploads b (and r) and nothing else.  NULL arrays are left alone. */
+extern "C" int tqgpu_set_problem(tqgpu_solver *s, const double *A, const double *B, const double *b,
+                                 const double *Qd, const double *Rd, const double *q, const double *r,
+                                 const double *xmin, const double *xmax, const double *umin, const double *umax, const double *lambda) {
+    if (!s) return fail(TQGPU_EINVAL, "null solver");
+    HIP_TRY(hipSetDevice(s->device));
+    if (s->dense) { s->dense = false; s->D.dense = 0; s->use_fast = s->use_fast_orig; s->in_valid = false; s->need_init = true; s->need_pack = true; }
+    char *slab = static_cast<char *>(s->slab);
+    bool any_pack = false, any_init = false;
+    auto put = [&](double *dev, const double *src, int count, bool pack, bool init) -> int {
+        if (!src || count <= 0) return TQGPU_OK;
+        char *mir = s->h_in + ((reinterpret_cast<char *>(dev) - slab) - (ptrdiff_t)s->in_off0);
+        const size_t bytes = sizeof(double) * (size_t)count;
+        if (s->in_valid && memcmp(mir, src, bytes) == 0) return TQGPU_OK;
+        memcpy(mir, src, bytes);
+        HIP_TRY(hipMemcpyAsync(dev, mir, bytes, hipMemcpyHostToDevice, s->stream));
+        any_pack |= pack; any_init |= init;
+        return TQGPU_OK;
+    };
+    int rc;
+    const int nxe = s->sum_nx - s->x_pad;
+    if ((rc = put(s->A + s->A_pad, A, s->sum_A - s->A_pad, true, false)) || (rc = put(s->B, B, s->sum_B, true, false)) ||
+        (rc = put(s->b + s->nx0, b, s->sum_lam, false, false)) ||
+        (rc = put(s->Qd + s->x_pad, Qd, nxe, true, true)) || (rc = put(s->Rd, Rd, s->sum_nu, true, true)) ||
+        (rc = put(s->q + s->x_pad, q, nxe, true, false)) || (rc = put(s->r, r, s->sum_nu, true, false)) ||
+        (rc = put(s->xmin + s->x_pad, xmin, nxe, true, false)) || (rc = put(s->xmax + s->x_pad, xmax, nxe, true, false)) ||
+        (rc = put(s->umin, umin, s->sum_nu, true, false)) || (rc = put(s->umax, umax, s->sum_nu, true, false)))
+        return rc;
+    s->in_valid = A && B && b && Qd && Rd && q && r && xmin && xmax && umin && umax ? true : s->in_valid;
+    if (any_init) s->need_init = true;
+    if (any_pack) s->need_pack = true;
+    if (lambda && s->sum_lam > 0) {
+        const size_t bytes = sizeof(double) * (size_t)s->sum_lam;
+        if (!s->lam_valid || memcmp(s->h_lam, lambda, bytes) != 0) {
+            memcpy(s->h_lam, lambda, bytes);
+            HIP_TRY(hipMemcpyAsync(s->d_lam_init + s->nx0, s->h_lam, bytes, hipMemcpyHostToDevice, s->stream));
+            s->lam_valid = true;
+        }
+    }
     return TQGPU_OK;
 }
 #undef H2D
@@ -2132,17 +2205,20 @@ extern "C" int tqgpu_get_solution(tqgpu_solver *s, double *x, double *u, double 
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t st = s->stream;
     const Data &D = s->D;
+    /* one packing kernel, one download into pinned memory, one synchronisation (ordered behind the solve on the stream) */
     const double *lamc = s->h_ctrl->cur ? D.lam1 : D.lam0;
-    if (mu_x || mu_u) {
-        const int n = std::max(s->sum_nx, s->sum_nu);
-        hipLaunchKernelGGL(k_export_mu, dim3((n + 255) / 256), dim3(256), 0, st, s->sum_nx, s->sum_nu, D, s->d_mu_x, s->d_mu_u);
-    }
-#define D2H(dst, src, count) do { if ((dst) && (count) > 0) HIP_TRY(hipMemcpyAsync((dst), (src), sizeof(double) * (size_t)(count), hipMemcpyDeviceToHost, st)); } while (0)
-    D2H(x, D.x + s->x_pad, s->sum_nx - s->x_pad); D2H(u, D.u, s->sum_nu);
-    D2H(lam, lamc + s->nx0, s->sum_lam); D2H(dlam, D.dlam + s->nx0, s->sum_lam);
-    D2H(mu_x, s->d_mu_x + s->x_pad, s->sum_nx - s->x_pad); D2H(mu_u, s->d_mu_u, s->sum_nu);
-#undef D2H
+    const int nxe = s->sum_nx - s->x_pad, nue = s->sum_nu, nl = s->sum_lam;
+    const int n = std::max(std::max(nxe, nue), std::max(nl, 1));
+    hipLaunchKernelGGL(k_export_all, dim3((n + 255) / 256), dim3(256), 0, st, nxe, nue, nl, s->x_pad, s->nx0, D, lamc, s->d_out);
+    HIP_TRY(hipMemcpyAsync(s->h_out, s->d_out, sizeof(double) * std::max<size_t>(s->out_doubles, 1), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    const double *ox = s->h_out, *ou = ox + nxe, *ol = ou + nue, *od = ol + nl, *omx = od + nl, *omu = omx + nxe;
+    if (x && nxe > 0) memcpy(x, ox, sizeof(double) * (size_t)nxe);
+    if (u && nue > 0) memcpy(u, ou, sizeof(double) * (size_t)nue);
+    if (lam && nl > 0) memcpy(lam, ol, sizeof(double) * (size_t)nl);
+    if (dlam && nl > 0) memcpy(dlam, od, sizeof(double) * (size_t)nl);
+    if (mu_x && nxe > 0) memcpy(mu_x, omx, sizeof(double) * (size_t)nxe);
+    if (mu_u && nue > 0) memcpy(mu_u, omu, sizeof(double) * (size_t)nue);
     return TQGPU_OK;
 }
 

@@ -372,8 +372,8 @@ return_t treeqp_tdunes_solve(const tree_qp_in *qp_in, tree_qp_out *qp_out,
     const double *umax = flat_of_vecs(qp_in->umax, Nn, &stage);
     assert(stage <= work->stage + work->stage_doubles);
 
-    DEV_CALL(tqgpu_set_dynamics(work->device, A, B, b));
     if (work->denseStageSolver) {
+        DEV_CALL(tqgpu_set_dynamics(work->device, A, B, b));
         /* flat Q, R, S in the order of tree_qp_in_set_ltv_objective_colmajor; bounds are re-checked, not uploaded */
         double *Qf = stage; for (int k = 0; k < Nn; k++) for (int j = 0; j < qp_in->nx[k]; j++) for (int i = 0; i < qp_in->nx[k]; i++) *stage++ = BLASFEO_DMATEL(&qp_in->Q[k], i, j);
         double *Rf = stage; for (int k = 0; k < Nn; k++) for (int j = 0; j < qp_in->nu[k]; j++) for (int i = 0; i < qp_in->nu[k]; i++) *stage++ = BLASFEO_DMATEL(&qp_in->R[k], i, j);
@@ -381,12 +381,12 @@ return_t treeqp_tdunes_solve(const tree_qp_in *qp_in, tree_qp_out *qp_out,
         assert(stage <= work->stage + work->stage_doubles);
         for (int k = 0; k < Nn; k++) require_dense_unconstrained(qp_in, k);
         DEV_CALL(tqgpu_set_objective_dense(work->device, Qf, Rf, Sf, q, r));
+        /* warm start from whatever slambda holds (set_dual_initialization or the previous solve) */
+        DEV_CALL(tqgpu_set_lambda(work->device, flat_of_vecs(work->slambda, Np, &stage)));
     } else {
-        DEV_CALL(tqgpu_set_objective_diag(work->device, Qd, Rd, q, r));
-        DEV_CALL(tqgpu_set_bounds(work->device, xmin, xmax, umin, umax));
+        /* one call: only what changed since the last solve is uploaded (no synchronisation) */
+        DEV_CALL(tqgpu_set_problem(work->device, A, B, b, Qd, Rd, q, r, xmin, xmax, umin, umax, flat_of_vecs(work->slambda, Np, &stage)));
     }
-    /* warm start from whatever slambda holds (set_dual_initialization or the previous solve) */
-    DEV_CALL(tqgpu_set_lambda(work->device, flat_of_vecs(work->slambda, Np, &stage)));
 
     tqgpu_opts dopts;
     dopts.maxIter = opts->maxIter;
@@ -403,6 +403,7 @@ return_t treeqp_tdunes_solve(const tree_qp_in *qp_in, tree_qp_out *qp_out,
     dopts.profile = (penv && atoi(penv) > 0) ? 1 : 0;
 
     double interface_time = treeqp_toc(&interface_tmr);
+    const double t_upload = interface_time;
 
     /* --- Newton loop on the device */
     treeqp_tic(&solver_tmr);
@@ -436,6 +437,9 @@ return_t treeqp_tdunes_solve(const tree_qp_in *qp_in, tree_qp_out *qp_out,
     qp_out->info.iter = res.iter;
     qp_out->info.solver_time = solver_time;
     qp_out->info.interface_time = interface_time + treeqp_toc(&interface_tmr);
+    if (getenv("TREEQP_AMD_HOSTPROF"))
+        fprintf(stderr, "[treeqp_amd] solve: staging+upload %.1f us, device solve %.1f us, download+export %.1f us\n",
+                1e6 * t_upload, 1e6 * solver_time, 1e6 * (qp_out->info.interface_time - t_upload));
     if (res.iter == opts->maxIter) status = TREEQP_MAXIMUM_ITERATIONS_REACHED;
     qp_out->info.total_time = treeqp_toc(&total_tmr);
 
