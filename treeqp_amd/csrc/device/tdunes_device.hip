@@ -1271,7 +1271,8 @@ int setup_persist(tqgpu_solver *s, int device) {
     s->psync.errs = s->psync.parts + n_parts;
     s->psync.halt = reinterpret_cast<unsigned *>(s->psync.errs + n_errs);
     s->psync.timeout = s->psync.halt + 32;
-    s->psync.seq = 0;
+    s->psync.cmd = s->psync.errs + n_errs + 24;          /* same 256-byte block: halt | timeout | cmd */
+    s->psync.seq = 0; s->psync.trip = 0;
     /* XCD-aware placement: the hardware deals workgroups round-robin over the 8 XCDs (workgroup b -> XCD b % 8)
      * and every XCD has its own L2.  A tier subtree talks to its parent and its children only, so whole
      * families go to one XCD: each subtree of the lowest tier with at most 8 subtrees picks an XCD, everything

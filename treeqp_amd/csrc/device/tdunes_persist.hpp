@@ -93,9 +93,11 @@ struct PSync {
     u64 *ndt;               /* [nodes][2 NX][2]  x then QinvCal of a tier subtree root node            */
     u64 *parts;             /* [G][2][2]         per-workgroup {fval, dot}                             */
     u64 *errs;              /* [G][2]            per-workgroup termination partial                     */
+    u64 *cmd;               /* [2]               top -> everybody: the trial of pass `tag` was rejected, value = tau - tauPrev of the next one */
     unsigned *halt;         /* == seq: the top workgroup ended this launch                            */
     unsigned *timeout;      /* sticky: a bounded spin gave up                                         */
     unsigned seq;           /* launch number << 16 (low 16 bits of the number are never 0)            */
+    unsigned trip;          /* tag of the pass the workgroup is in (kernel-local copy only)           */
 };
 
 __device__ __forceinline__ void st_tag(u64 *p, double v, unsigned tag) {
@@ -112,14 +114,37 @@ __device__ __forceinline__ double ld_tag(const u64 *p, unsigned tag, bool &ok) {
  * independent, so they are in flight together); a poll iteration is then one memory latency long and needs
  * no sleep.  `over` = halt word == launch number or timeout word set; false = give up. */
 struct PollGuard {
-    unsigned h, tmo;
-    __device__ __forceinline__ void load(const PSync &Sy) { h = __hip_atomic_load(Sy.halt, RLX, AGENT); tmo = __hip_atomic_load(Sy.timeout, RLX, AGENT); }
+    unsigned h, tmo, cm;
+    __device__ __forceinline__ void load(const PSync &Sy) {
+        h = __hip_atomic_load(Sy.halt, RLX, AGENT); tmo = __hip_atomic_load(Sy.timeout, RLX, AGENT);
+        cm = (unsigned)(__hip_atomic_load(Sy.cmd + 1, RLX, AGENT) >> 32);
+    }
     __device__ __forceinline__ bool go_on(const PSync &Sy, u64 t0) const {
-        if (h == Sy.seq || tmo) return false;
+        if (h == Sy.seq || tmo || cm == Sy.trip) return false;
         if (wall_clock64() - t0 > 50000000ull) { __hip_atomic_store(Sy.timeout, 1u, RLX, AGENT); return false; }   /* 0.5 s at 100 MHz */
         return true;
     }
 };
+/* why a poll gave up: 1 = the launch is over (halt / timeout), 2 = the top workgroup rejected the trial this pass
+ * was built on (the pass is dropped, another trial follows) */
+__device__ __forceinline__ int p_abort_code(const PSync &Sy) {
+    const unsigned h = __hip_atomic_load(Sy.halt, RLX, AGENT), tmo = __hip_atomic_load(Sy.timeout, RLX, AGENT);
+    const unsigned cm = (unsigned)(__hip_atomic_load(Sy.cmd + 1, RLX, AGENT) >> 32);
+    return (h == Sy.seq || tmo || cm != Sy.trip) ? 1 : 2;
+}
+/* the step factor of the next trial, posted by the top workgroup with the tag of the dropped pass */
+__device__ __forceinline__ double p_read_cmd(const PSync &Sy, bool &ok) {
+    const u64 t0 = wall_clock64();
+    double v;
+    for (;;) {
+        ok = true;
+        v = ld_tag(Sy.cmd, Sy.trip, ok);
+        const unsigned h = __hip_atomic_load(Sy.halt, RLX, AGENT), tmo = __hip_atomic_load(Sy.timeout, RLX, AGENT);
+        if (ok || h == Sy.seq || tmo) break;
+        if (wall_clock64() - t0 > 50000000ull) { __hip_atomic_store(Sy.timeout, 1u, RLX, AGENT); break; }
+    }
+    return v;
+}
 
 template <int NX, int NU, int MD>
 struct PLds {
@@ -200,7 +225,7 @@ __device__ __forceinline__ void p_gh_load(const PConst &C, const PSync &Sy, cons
             pg.load(Sy);
             if (ok || !pg.go_on(Sy, t0)) break;
         }
-        if (!ok) *L.abort = 1;
+        if (!ok) *L.abort = p_abort_code(Sy);
     } else if (foreign) { const PDump *dp = C.dump; xv = dp->x[bo + rowc]; qv = dp->QinvCal[bo + rowc]; }   /* relaunch: staged by earlier kernels */
     else { lds_cptr kid = L.node_(MD * loc + 1 + cidx); xv = kid[r]; qv = kid[NZ + r]; }
     const double bv = C.b[bo + rowc];
@@ -412,7 +437,7 @@ __device__ __forceinline__ double p_forward(const PSync &Sy, PLds<NX, NU, MD> &L
             if (ok || !pg.go_on(Sy, t0)) break;
         }
         ok = __all(ok);
-        if (!ok) *L.abort = 1;                            /* the launch is over: nothing below may leave the workgroup */
+        if (!ok) *L.abort = p_abort_code(Sy);             /* the launch is over or the pass is dropped: nothing below may leave the workgroup */
         if (lane == 0 && ok) {                            /* the subtree root's own step: the stage sweep reads it from LDS */
 #pragma unroll
             for (int r = 0; r < NX; r++) L.droot[r] = dv[r];
@@ -645,8 +670,10 @@ __device__ __forceinline__ bool p_gather3(const PSync &Sy, PLds<NX, NU, MD> &L, 
 
 /* the life of one workgroup = one tier subtree: tier `tier`, subtree (complete part) or scenario (chain part) `s` */
 template <int NX, int NU, int MD>
-__device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeom &Gm, const PSync &Sy, int prologue, int wg, int tier, int s, double *lds_all) {
+__device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeom &Gm, const PSync &Sy_in, int prologue, int wg, int tier, int s, double *lds_all) {
     using U = Uni<NX, NU, MD>;
+    PSync Sy = Sy_in;
+    Sy.trip = 0u;
     constexpr int D = U::D, NZ = U::NZ;
     Ctrl *c = C.ctrl;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -710,8 +737,14 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
         if (threadIdx.x == 0) post_parts();
     }
 
+    /* one trip = one PASS: G + H at the point of the latest stage sweep, then -- if the top workgroup accepts
+     * that point -- backward sweep, forward sweep and the first trial of the next line search; if it rejects
+     * it (Armijo test failed, more trials to go) the pass is dropped after G + H and the trip ends with the
+     * next trial of the same line search instead.  Tags count passes, the control block counts iterations. */
     for (unsigned e = 1u;; e++) {
         const unsigned tag_e = Sy.seq | e;
+        Sy.trip = tag_e;
+        int verdict = 0;                                                  /* 2: this pass is dropped, another trial follows */
 
         int sl = 0;
         pstamp(C, O, e, tier, s, sl++);                                   /* 0: iteration start */
@@ -755,12 +788,17 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
                     if (nd > 0u) {
                         if (prologue && nd == 1u) { c->fval0 = fa; c->fval = fa; }
                         else {
-                            c->tau = 1.0; c->tauPrev = 0.0; c->ls_iter = 1; c->ls_pending = 1;
-                            if (ls_not_descent(c, -da)) code = 1;
+                            bool bad = false;
+                            if (!c->ls_pending) {                               /* first trial of a line search */
+                                c->tau = 1.0; c->tauPrev = 0.0; c->ls_iter = 1; c->ls_pending = 1;
+                                bad = ls_not_descent(c, -da);
+                            }
+                            if (bad) code = 1;
                             else {
                                 const PDump *dp = C.dump;
                                 ls_decide_tail(c, dp->ls_log, dp->ls_log_cap, O, fa);
-                                code = (c->done || c->ls_pending) ? 1 : 0;      /* finished, or more trials: the host takes over */
+                                code = c->done ? 1 : (c->ls_pending ? 2 : 0);   /* finished / another trial / accepted */
+                                if (code == 2) st_tag(Sy.cmd, c->tau - c->tauPrev, tag_e);   /* line_search :985-987: lambda moves by (tau - tauPrev) dlambda */
                             }
                         }
                     }
@@ -776,17 +814,18 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
                 leave = *L.flag;
                 __syncthreads();
             }
-            if (leave) {
+            if (leave == 1) {
                 if (threadIdx.x == 0) __hip_atomic_store(Sy.halt, Sy.seq, RLX, AGENT);
                 break;
             }
+            verdict = leave;
         }
         pstamp(C, O, e, tier, s, sl++);                                   /* 2: verdicts (top) */
 
         /* ---- backward sweep ---- */
         bool gone = false;
         double dotp = 0.0;                                /* per-lane terms of res' * dlam over my blocks */
-        {
+        if (verdict != 2) {
             double Tc[D];
             for (int t = th - 1; t >= 0; t--) {
                 const int nb = U::width(t);
@@ -799,7 +838,7 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
                     else if (!is_bottom) {
                         ok = p_sub_children_tagged<NX, NU, MD>(Sy, Sy.sch + (size_t)kid0g<MD>(ii, C) * U::SCH * 2, tag_e, lane, Tc);
                         ok = __all(ok);
-                        if (!ok && lane == 0) *L.abort = 1;
+                        if (!ok && lane == 0) *L.abort = p_abort_code(Sy);
                     }
                     p_factor_rows<NX, NU, MD>(c, O, lane, Tc);
                     if (!is_root) {
@@ -834,15 +873,15 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
                     }
                 }
                 lds_barrier();
-                if (t == th - 1 && !is_bottom && *L.abort) { gone = true; break; }    /* a child never delivered: the launch is over */
+                if (t == th - 1 && !is_bottom && *L.abort) { gone = true; break; }    /* a child never delivered: the launch is over, or the pass is dropped */
                 pstamp(C, O, e, tier, s, sl++);                           /* 3.. : one per backward level */
             }
         }
-        if (gone) break;
+        if (gone) { if (*L.abort == 2) { verdict = 2; gone = false; } else break; }
         pstamp(C, O, e, tier, s, sl++);                                   /* backward done */
 
         /* ---- forward sweep (my subtree root first waits for the parent workgroup's step) ---- */
-        for (int t = (is_top ? 1 : 0); t < th; t++) {
+        for (int t = (is_top ? 1 : 0); t < th && verdict != 2; t++) {
             const int nb = U::width(t);
             if (wave < nb) {
                 const int loc = U::first(t) + wave, ii = p_slot_node<NX, NU, MD>(loc, l0, s, C), bo = NX * kid0g<MD>(ii, C);
@@ -851,18 +890,33 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
                 else dotp += p_forward<NX, NU, MD>(Sy, L, ii, bo, loc, lane, (lds_cptr)(L.dl + (U::first(t - 1) + wave / MD) * D + (wave % MD) * NX), false, to_children, tag_e);
             }
             lds_barrier();
-            if (t == 0 && *L.abort) { gone = true; break; }            /* the parent never delivered: the launch is over */
+            if (t == 0 && *L.abort) { gone = true; break; }            /* the parent never delivered: the launch is over, or the pass is dropped */
             if (t == 0) pstamp(C, O, e, tier, s, sl++);                   /* parent's step arrived + first level */
         }
-        if (gone) break;
-        have_dl = true;
-        dotp = wsum(dotp);
-        if (lane == 0) L.part[4 * wave + 1] = dotp;
+        if (gone) { if (*L.abort == 2) { verdict = 2; gone = false; } else break; }
+        double step = 1.0;
+        if (verdict == 2) {
+            /* the trial this pass was built on was rejected: drop the pass (it only touched per-iteration LDS data
+             * and hand-over words tagged with this pass) and move the duals by (tau - tauPrev) * step instead */
+            bool okc;
+            step = p_read_cmd(Sy, okc);
+            okc = __all(okc);
+            if (!okc && lane == 0) *L.abort = 1;
+            __syncthreads();
+            if (*L.abort == 1) break;
+            __syncthreads();
+            if (threadIdx.x == 0) *L.abort = 0;
+            __syncthreads();
+        } else {
+            have_dl = true;
+            dotp = wsum(dotp);
+            if (lane == 0) L.part[4 * wave + 1] = dotp;
+        }
         pstamp(C, O, e, tier, s, sl++);                                   /* forward done */
 
-        /* ---- first trial (tau = 1) on the nodes this workgroup owns; then straight on to the next
-         * iteration at the trial point: the top workgroup checks that it was accepted ---- */
-        const double fsum = p_stage_owned<NX, NU, MD>(C, Sy, L, l0, nown, s, wave, lane, 1.0, cur, false, !is_top, Sy.seq | (nd + 1u));
+        /* ---- next trial (after a full pass: the first one, tau = 1) on the nodes this workgroup owns; then straight
+         * on to the next pass at the trial point: the top workgroup checks that it was accepted ---- */
+        const double fsum = p_stage_owned<NX, NU, MD>(C, Sy, L, l0, nown, s, wave, lane, step, cur, false, !is_top, Sy.seq | (nd + 1u));
         if (lane == 0) L.part[4 * wave + 2] = fsum;
         __syncthreads();
         nd += 1u;
