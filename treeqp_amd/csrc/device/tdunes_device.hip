@@ -1263,7 +1263,8 @@ int setup_persist(tqgpu_solver *s, int device) {
     const int nx0 = s->nx[0];
     const size_t n_sch = (size_t)s->Nn * (nx0 * nx0 + nx0) * 2, n_dlt = (size_t)s->sum_nx * 2, n_ndt = (size_t)s->Nn * 2 * nx0 * 2;
     const size_t n_parts = (size_t)G.G * 4, n_errs = (size_t)G.G * 2;
-    const size_t bytes = (n_sch + n_dlt + n_ndt + n_parts + n_errs + 32) * sizeof(unsigned long long);
+    const size_t n_bparts = (size_t)G.G * 16;
+    const size_t bytes = (n_sch + n_dlt + n_ndt + n_parts + n_errs + 32 + n_bparts) * sizeof(unsigned long long);
     HIP_TRY(hipMalloc(&s->sync_slab, bytes));
     HIP_TRY(hipMemset(s->sync_slab, 0, bytes));
     unsigned long long *w = static_cast<unsigned long long *>(s->sync_slab);
@@ -1271,7 +1272,9 @@ int setup_persist(tqgpu_solver *s, int device) {
     s->psync.errs = s->psync.parts + n_parts;
     s->psync.halt = reinterpret_cast<unsigned *>(s->psync.errs + n_errs);
     s->psync.timeout = s->psync.halt + 32;
-    s->psync.cmd = s->psync.errs + n_errs + 24;          /* same 256-byte block: halt | timeout | cmd */
+    s->psync.cmd = s->psync.errs + n_errs + 24;          /* same 256-byte block: halt | timeout | cmd | vrd */
+    s->psync.vrd = s->psync.errs + n_errs + 28;
+    s->psync.bparts = s->psync.errs + n_errs + 32;
     s->psync.seq = 0; s->psync.trip = 0;
     /* XCD-aware placement: the hardware deals workgroups round-robin over the 8 XCDs (workgroup b -> XCD b % 8)
      * and every XCD has its own L2.  A tier subtree talks to its parent and its children only, so whole
