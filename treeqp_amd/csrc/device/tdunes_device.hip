@@ -755,6 +755,7 @@ __global__ void __launch_bounds__(WAVE) k_ls_decide_parts(Data D, Opts O, const 
 
 #include "tdunes_fast.hpp"
 #include "tdunes_persist.hpp"
+#include "tdunes_wide.hpp"
 #include "tdunes_gpersist.hpp"
 
 }  // namespace
@@ -769,6 +770,8 @@ struct tqgpu_solver {
     std::vector<int> nk, nx, nu, dad, stage, kid0, xoff, uoff, aoff, boff, pos, bdim, woff, utoff, lvl_first;
     int sum_nx = 0, sum_nu = 0, sum_lam = 0, sum_A = 0, sum_B = 0, sum_W = 0, sum_Ut = 0, nx0 = 0;
     size_t lds_stage = 0, lds_hess = 0, lds_factor = 0, lds_forward = 0, lds_dense = 0;
+    bool wide = false;              /* larger blocks (16 < d <= 64): workgroup-per-block MFMA kernels (tdunes_wide.hpp) */
+    size_t lds_hess_w = 0, lds_factor_w = 0, lds_forward_w = 0;
     bool dense = false, need_dense_init = false;   /* dense unconstrained stage solver selected (generic path only) */
     double *d_Hd = nullptr;      /* writable alias of Data.Hd */
     std::vector<int> poff;
@@ -919,6 +922,17 @@ int build_tables(tqgpu_solver *s) {
             s->lds_factor = std::max(s->lds_factor, (ld * d + d + 2) * sizeof(double));
             s->lds_forward = std::max(s->lds_forward, ((d | 1) * d + d + s->nx[k] + 2) * sizeof(double));
         }
+    }
+    {
+        int dmax = 0, rmax = 0;
+        for (int k = 0; k < s->Np; k++) {
+            const int d = s->bdim[k], R = d + 1 + (k > 0 ? s->nx[k] : 0), nz = s->nx[k] + s->nu[k];
+            dmax = std::max(dmax, d); rmax = std::max(rmax, R);
+            s->lds_hess_w = std::max(s->lds_hess_w, wide_lds_hess(d, nz));
+            s->lds_factor_w = std::max(s->lds_factor_w, wide_lds_factor(d, R));
+            s->lds_forward_w = std::max(s->lds_forward_w, wide_lds_forward(d));
+        }
+        s->wide = dmax > 16 && dmax <= 64 && rmax <= 128;
     }
     const size_t lim = 160 * 1024;
     if (s->lds_factor > lim || s->lds_hess > lim)
@@ -1357,14 +1371,21 @@ void launch_generic_iteration(tqgpu_solver *s, const Opts &O, int h, int &launch
     const Tree &T = s->T; const Data &D = s->D; hipStream_t st = s->stream;
     hipLaunchKernelGGL(k_grad, dim3(T.Nn - 1), dim3(WAVE), 0, st, T, D, O.termCondition, h); launches++;
     hipLaunchKernelGGL(k_check, dim3(1), dim3(256), 0, st, T, D, O, h); launches++;
-    hipLaunchKernelGGL(k_hess, dim3(T.Np), dim3(WAVE), s->lds_hess, st, T, D, h); launches++;
+    const bool wide = s->wide && !s->dense;
+    if (wide) hipLaunchKernelGGL(k_hess_w, dim3(T.Np), dim3(WT), s->lds_hess_w, st, T, D, h);
+    else hipLaunchKernelGGL(k_hess, dim3(T.Np), dim3(WAVE), s->lds_hess, st, T, D, h);
+    launches++;
     for (int lvl = T.Nh - 1; lvl >= 0; lvl--) {
         const int first = s->lvl_first[lvl], count = s->lvl_first[lvl + 1] - first;
-        hipLaunchKernelGGL(k_factor, dim3(count), dim3(WAVE), s->lds_factor, st, T, D, O, first, h); launches++;
+        if (wide) hipLaunchKernelGGL(k_factor_w, dim3(count), dim3(WT), s->lds_factor_w, st, T, D, O, first, h);
+        else hipLaunchKernelGGL(k_factor, dim3(count), dim3(WAVE), s->lds_factor, st, T, D, O, first, h);
+        launches++;
     }
     for (int lvl = 1; lvl < T.Nh; lvl++) {
         const int first = s->lvl_first[lvl], count = s->lvl_first[lvl + 1] - first;
-        hipLaunchKernelGGL(k_forward, dim3(count), dim3(WAVE), s->lds_forward, st, T, D, first, h); launches++;
+        if (wide) hipLaunchKernelGGL(k_forward_w, dim3(count), dim3(WT), s->lds_forward_w, st, T, D, first, h);
+        else hipLaunchKernelGGL(k_forward, dim3(count), dim3(WAVE), s->lds_forward, st, T, D, first, h);
+        launches++;
     }
     hipLaunchKernelGGL(k_ls_begin, dim3(1), dim3(256), 0, st, T, D, h); launches++;
     hipLaunchKernelGGL(k_stage, dim3(T.Nn), dim3(WAVE), s->lds_stage, st, T, D, 1, h, 1); launches++;
@@ -1514,6 +1535,8 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
 
     if ((rc = allow_lds(k_stage, s->lds_stage)) || (rc = allow_lds(k_hess, s->lds_hess)) ||
         (rc = allow_lds(k_factor, s->lds_factor)) || (rc = allow_lds(k_forward, s->lds_forward)))
+        return cleanup_fail(rc);
+    if (s->wide && ((rc = allow_lds(k_hess_w, s->lds_hess_w)) || (rc = allow_lds(k_factor_w, s->lds_factor_w)) || (rc = allow_lds(k_forward_w, s->lds_forward_w))))
         return cleanup_fail(rc);
     if (s->fast >= 0) {
         hipDeviceProp_t prop;
