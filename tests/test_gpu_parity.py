@@ -240,6 +240,35 @@ def test_resolve_after_changing_each_input_array(gpu, orc):
     s.destroy()
 
 
+# --- larger dual Hessian blocks: the workgroup-per-block MFMA kernels (tdunes_wide.hpp) ---------
+
+@pytest.mark.parametrize("nx,nu,md,levels", [(10, 4, 3, 3), (16, 4, 3, 3), (20, 10, 2, 4), (20, 10, 3, 4), (21, 5, 3, 3), (9, 3, 2, 5)],
+                         ids=["d30", "d48_two_wave_panel", "d40", "d60_c4_blocks", "d63", "d18"])
+def test_wide_block_kernels_match_oracle(gpu, orc, nx, nu, md, levels):
+    """16 < d <= 64: padded 16 x 16 tiles, register panels (one or two waves of rows), MFMA trailing updates."""
+    f = P.random_clipping_qp(nx=nx, nu=nu, md=md, levels=levels)
+    ref = orc.solve(f.as_dict(), orc.default_opts(**f.opts))
+    g = gpu.TqGpu(f.nk, f.nx, f.nu).upload(f.as_dict(), f.lambda0)
+    assert g.path == 0
+    r = g.solve(**f.opts)
+    assert r["status"] == ref["status"] == 0 and r["iter"] == ref["iter"] == 1
+    assert_solution_close(g.solution(), ref, 1e-9, keys=("x", "u", "lam"))
+    g.close()
+
+
+@pytest.mark.parametrize("reg", [1, 2], ids=["always", "on_the_fly"])
+def test_wide_block_kernels_regularisation(gpu, orc, reg):
+    """Bounded problem with d = 24 blocks (C5 class) under ALWAYS / ON_THE_FLY Levenberg-Marquardt on the wide kernels."""
+    f = P.pruned_chain_qp()
+    opts = dict(f.opts); opts.update(regType=reg, regValue=1e-6, regTol=1e-6)
+    ref = orc.solve(f.as_dict(), orc.default_opts(**opts), lambda0=f.lambda0)
+    g = gpu.TqGpu(f.nk, f.nx, f.nu).upload(f.as_dict(), f.lambda0)
+    r = g.solve(**opts)
+    assert r["status"] == ref["status"] == 0 and r["iter"] == ref["iter"] and r["ls_total"] == ref["ls_total"]
+    assert_solution_close(g.solution(), ref, 1e-8, keys=("x", "u", "lam"))
+    g.close()
+
+
 # --- full BASELINE sizes: size-independent properties ------------------------------------------
 
 @pytest.mark.parametrize("make", [lambda: P.linear_chain(2, 11, 11)], ids=["c3_chain_4095"])

@@ -64,7 +64,13 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
 struct Tree {            /* device pointers, passed by value */
     int Nn, Np, Nh, nx0;
     const int *dad, *nk, *kid0, *nx, *nu, *xoff, *uoff, *aoff, *boff, *pos, *bdim, *woff, *utoff;
+    /* everything the workgroup-per-block kernels need to know about node k in ONE 128-byte record (a dependent
+     * chain of table look-ups costs a global round trip, ~2.4 us, per hop):
+     * [0] bdim [1] nx [2] nu [3] nk [4] kid0 [5] xoff [6] uoff [7] xoff[kid0] [8] woff [9] utoff [10] dad [11] pos
+     * [12] bdim[dad] [13] woff[dad] [16 + 3u ..] nx, aoff, boff of child u < 4 */
+    const int *desc;
 };
+#define DESC_INTS 32
 
 struct Ctrl {
     int done;            /* all work finished (converged / max iterations / failure)        */
@@ -831,6 +837,7 @@ struct tqgpu_solver {
     PSync psync{};
     PConst pconst{};
     void *sync_slab = nullptr;
+    int *d_desc = nullptr;
     size_t sync_words_bytes = 0, lds_persist = 0;
     /* sharded mode */
     int nranks = 1, rank = 0, part_top = -1;      /* part_top: highest partitioned tier */
@@ -926,10 +933,10 @@ int build_tables(tqgpu_solver *s) {
     {
         int dmax = 0, rmax = 0;
         for (int k = 0; k < s->Np; k++) {
-            const int d = s->bdim[k], R = d + 1 + (k > 0 ? s->nx[k] : 0), nz = s->nx[k] + s->nu[k];
-            dmax = std::max(dmax, d); rmax = std::max(rmax, R);
+            const int d = s->bdim[k], nxi = k > 0 ? s->nx[k] : 0, nz = s->nx[k] + s->nu[k];
+            dmax = std::max(dmax, d); rmax = std::max(rmax, wide_rows(d, nxi));
             s->lds_hess_w = std::max(s->lds_hess_w, wide_lds_hess(d, nz));
-            s->lds_factor_w = std::max(s->lds_factor_w, wide_lds_factor(d, R));
+            s->lds_factor_w = std::max(s->lds_factor_w, wide_lds_factor(d, nxi));
             s->lds_forward_w = std::max(s->lds_forward_w, wide_lds_forward(d));
         }
         s->wide = dmax > 16 && dmax <= 64 && rmax <= 128;
@@ -1500,6 +1507,19 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
     T.nx = at<int>(base, o_nx); T.nu = at<int>(base, o_nu); T.xoff = at<int>(base, o_xoff); T.uoff = at<int>(base, o_uoff);
     T.aoff = at<int>(base, o_aoff); T.boff = at<int>(base, o_boff); T.pos = at<int>(base, o_pos);
     T.bdim = at<int>(base, o_bdim); T.woff = at<int>(base, o_woff); T.utoff = at<int>(base, o_utoff);
+    {
+        std::vector<int> desc((size_t)DESC_INTS * Nn, 0);
+        for (int k = 0; k < Nn; k++) {
+            int *e = &desc[(size_t)DESC_INTS * k];
+            const int k0 = s->nk[k] > 0 ? s->kid0[k] : 0, dd = k > 0 ? s->dad[k] : 0;
+            e[0] = s->bdim[k]; e[1] = s->nx[k]; e[2] = s->nu[k]; e[3] = s->nk[k]; e[4] = k0; e[5] = s->xoff[k]; e[6] = s->uoff[k];
+            e[7] = s->xoff[k0]; e[8] = s->woff[k]; e[9] = s->utoff[k]; e[10] = dd; e[11] = s->pos[k]; e[12] = s->bdim[dd]; e[13] = s->woff[dd];
+            for (int u = 0; u < 4 && u < s->nk[k]; u++) { e[16 + 3 * u] = s->nx[k0 + u]; e[17 + 3 * u] = s->aoff[k0 + u]; e[18 + 3 * u] = s->boff[k0 + u]; }
+        }
+        if (hipMalloc(&s->d_desc, desc.size() * I) != hipSuccess || hipMemcpy(s->d_desc, desc.data(), desc.size() * I, hipMemcpyHostToDevice) != hipSuccess)
+            return cleanup_fail(fail(TQGPU_ENOMEM, "hipMalloc failed for the node records"));
+        T.desc = s->d_desc;
+    }
     Data &D = s->D;
     s->A = at<double>(base, o_A); s->B = at<double>(base, o_B); s->b = at<double>(base, o_b);
     s->Qd = at<double>(base, o_Qd); s->Rd = at<double>(base, o_Rd); s->q = at<double>(base, o_q); s->r = at<double>(base, o_r);
@@ -1593,6 +1613,7 @@ extern "C" void tqgpu_destroy(tqgpu_solver *s) {
     if (s->sync_slab) (void)hipFree(s->sync_slab);
     if (s->pconst_slab) (void)hipFree(s->pconst_slab);
     if (s->wg_map) (void)hipFree(s->wg_map);
+    if (s->d_desc) (void)hipFree(s->d_desc);
     if (s->h_in) (void)hipHostFree(s->h_in);
     if (s->h_lam) (void)hipHostFree(s->h_lam);
     if (s->h_out) (void)hipHostFree(s->h_out);

@@ -11,10 +11,14 @@
  *   - F:  blocked right-looking tall Cholesky, panel width 16.  A panel is factorised in REGISTERS, one row
  *     per lane, pivot rows broadcast by v_readlane (p_potrf_rows<16>: lanes 0..15 hold the diagonal tile,
  *     lanes 16..63 forty-eight rows below it; further rows go to further waves, which repeat the diagonal
- *     tile); the trailing update T22 -= L21 L21' is four MFMAs per 16 x 16 tile.  d = 60: ~9 us per level
- *     instead of ~72 us for the column-by-column LDS version;
+ *     tile); the trailing update T22 -= L21 L21' is four MFMAs per 16 x 16 tile, the Schur complement into the
+ *     parent X X' likewise.  d = 60: ~15 us of factorisation per block instead of ~72 us for the
+ *     column-by-column LDS version;
  *   - substitutions (root solve, forward sweep) keep the vector in registers, one entry per lane, and
- *     broadcast z_k by v_readlane: one LDS read and one FMA per step, no barrier.
+ *     broadcast z_k by v_readlane: one LDS read and one FMA per step, no barrier;
+ *   - a dependent global round trip costs ~2.4 us here (data written by other XCDs), so every kernel reads ONE
+ *     128-byte node record (Tree::desc) instead of walking the index tables, and issues all its data loads as one
+ *     batch of clamped, branch-free loads (LOADS_DONE keeps the optimiser from re-serialising them).
  * Reference: calculate_hessian_blocks / build W (dual_Newton_tree.c:531-760), factorise + substitute
  * (:763-913).  Results differ from the wave-per-block kernels by summation order only.
  */
@@ -23,63 +27,127 @@
 #define WW 4
 #define WT (WW * WAVE)
 
+#ifdef TQ_WIDE_STAMPS
+#define WSTAMP(slot) do { if (first == 0 && threadIdx.x == 0) { D.stamps[2 * (slot)] = clock64(); D.stamps[2 * (slot) + 1] = wall_clock64(); } } while (0)
+#else
+#define WSTAMP(slot) do { } while (0)
+#endif
+
+/* keeps a batch of independent global loads a batch: the optimiser otherwise sinks each (clamped, unconditional) load
+ * under the predicate that masks its result, one branch and one full wait per load */
+#define LOADS_DONE() asm volatile("" ::: "memory")
+
 __device__ __forceinline__ int up16(int v) { return (v + 15) & ~15; }
 __device__ __forceinline__ int wide_ld(int rows_padded) { return rows_padded | 16; }
+
+/* z <- L^-T z for one wave, entry j of z on lane j (d <= 64): the strictly-lower part of column `lane` of L is
+ * fetched into registers in one go, then every step is two readlanes and one FMA -- no memory in the chain.
+ * L column major in LDS with leading dimension ld; myinv = 1 / L[lane][lane].  Returns the solution entry. */
+__device__ __forceinline__ double wide_backsolve(const double *L, int ld, int d, int lane, double z, double myinv) {
+    const int lc = lane < d ? lane : 0;
+    double Lc[64];
+#pragma unroll
+    for (int k = 1; k < 64; k++) {
+        const bool use = k < d && k > lane;
+        const double v = L[(use ? k : 0) + (size_t)lc * ld];
+        Lc[k] = use ? -v : 0.0;
+    }
+#pragma unroll
+    for (int k = 63; k >= 1; k--) {
+        if (k < d) {
+            const double zk = rdlane(z * myinv, k);
+            z = fma(Lc[k], zk, z);
+        }
+    }
+    return z * myinv;
+}
 
 /* ------------------------------------------------------------------------------------------ */
 /* H                                                                                          */
 /* ------------------------------------------------------------------------------------------ */
 __global__ void __launch_bounds__(WT) k_hess_w(Tree T, Data D, int h) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    if (!phase_main(D.ctrl, h)) return;
     const int p = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int d = T.bdim[p], nxp = T.nx[p], nup = T.nu[p], nz = nxp + nup;
+    int e[28];
+#pragma unroll
+    for (int i = 0; i < 28; i++) e[i] = T.desc[(size_t)DESC_INTS * p + i];       /* node record: requested together with the control block */
+    if (!phase_main(D.ctrl, h)) return;
+    const int d = e[0], nxp = e[1], nup = e[2], nz = nxp + nup;
     const int dp = up16(d), kz = (nz + 3) & ~3, ldc = wide_ld(dp);
     double *Cs = lds, *CP = lds + (size_t)ldc * kz;
-    const int k0 = T.kid0[p], ko = T.xoff[k0];
-    const double *Qc = D.QinvCal + T.xoff[p], *Rc = D.RinvCal + T.uoff[p];
+    const int k0 = e[4], ko = e[7];
+    const double *Qc = D.QinvCal + e[5], *Rc = D.RinvCal + e[6];
     for (int e = tid; e < 2 * ldc * kz; e += WT) lds[e] = 0.0;
     __syncthreads();
-    int rowoff = 0;
-    for (int cc = 0; cc < T.nk[p]; cc++) {
-        const int kid = k0 + cc, nxc = T.nx[kid];
-        const double *A = D.A + T.aoff[kid], *B = D.B + T.boff[kid];
-        for (int e = tid; e < nxc * nz; e += WT) {
-            const int i = e % nxc, col = e / nxc;
-            const double a = col < nxp ? A[i + (size_t)col * nxc] : B[i + (size_t)(col - nxp) * nxc];
-            const double pc = col < nxp ? Qc[col] : Rc[col - nxp];
-            Cs[rowoff + i + (size_t)col * ldc] = a;
-            CP[rowoff + i + (size_t)col * ldc] = a * pc;
+    /* children's [A B] rows: rows on the lanes, columns dealt over the waves; branch-free (clamped) loads, up to four
+     * children x eight columns in flight per thread */
+    const int nkp = e[3];
+    for (int cc0 = 0, rowoff0 = 0; cc0 < nkp; cc0 += 4) {
+        int nxc[4], ro[4];
+        const double *Ap[4], *Bp[4];
+        int rowoff = rowoff0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int kid = k0 + (cc0 + u < nkp ? cc0 + u : cc0);
+            const bool rec = cc0 == 0;                                            /* the first four children are in the record */
+            nxc[u] = cc0 + u < nkp ? (rec ? e[16 + 3 * u] : T.nx[kid]) : 0; ro[u] = rowoff; rowoff += nxc[u];
+            Ap[u] = D.A + (rec ? e[17 + 3 * u] : T.aoff[kid]); Bp[u] = D.B + (rec ? e[18 + 3 * u] : T.boff[kid]);
         }
-        rowoff += nxc;
+        for (int c0 = 0; c0 < nz; c0 += 8 * WW) {
+            double a[4][8], pc[8];
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                const int col = c0 + wave + WW * m;
+                const int cs = col < nz ? col : 0;
+                pc[m] = cs < nxp ? Qc[cs] : Rc[cs - nxp];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const bool ok = lane < nxc[u] && col < nz;
+                    const int i = ok ? lane : 0, cu = ok ? cs : 0, nxu = nxc[u] > 0 ? nxc[u] : 1;
+                    const double *src = cu < nxp ? Ap[u] + i + (size_t)cu * nxu : Bp[u] + i + (size_t)(cu - nxp) * nxu;
+                    a[u][m] = *(nxc[u] > 0 ? src : Qc);
+                }
+            }
+            LOADS_DONE();
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                const int col = c0 + wave + WW * m;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (lane < nxc[u] && col < nz) { Cs[ro[u] + lane + (size_t)col * ldc] = a[u][m]; CP[ro[u] + lane + (size_t)col * ldc] = a[u][m] * pc[m]; }
+                }
+            }
+        }
+        rowoff0 = rowoff;
     }
     __syncthreads();
     /* lower tiles (I >= J); computed transposed (A = tile J of CP, B = tile I of C) so that a lane's results lie in
      * one row of W and lanes run down a column: coalesced stores */
     const int nt = dp >> 4, r = lane & 15, g = lane >> 4;
-    double *W = D.W + T.woff[p];
+    double *W = D.W + e[8];
     int t = 0;
     for (int J = 0; J < nt; J++) {
         for (int I = J; I < nt; I++, t++) {
             if ((t & (WW - 1)) != wave) continue;
+            const int i = 16 * I + r;
+            const double qd = D.QinvCal[ko + (i < d ? i : 0)];          /* diagonal term, in flight during the MFMAs */
             f64x4 acc = {0.0, 0.0, 0.0, 0.0};
             for (int s = 0; s < kz; s += 4) {
                 const double a = CP[16 * J + r + (size_t)(s + g) * ldc];
                 const double b = Cs[16 * I + r + (size_t)(s + g) * ldc];
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
             }
-            const int i = 16 * I + r;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int j = 16 * J + g + 4 * q;
-                if (i < d && j <= i) W[i + (size_t)j * d] = acc[q] + (i == j ? D.QinvCal[ko + i] : 0.0);
+                if (i < d && j <= i) W[i + (size_t)j * d] = acc[q] + (i == j ? qd : 0.0);
             }
         }
     }
     if (p > 0) {
-        double *Ut = D.Ut + T.utoff[p];
-        for (int e = tid; e < nxp * d; e += WT) {
-            const int i = e % nxp, rr = e / nxp;
+        double *Ut = D.Ut + e[9];
+        for (int f = tid; f < nxp * d; f += WT) {
+            const int i = f % nxp, rr = f / nxp;
             Ut[i + (size_t)rr * nxp] = -1.0 * CP[rr + (size_t)i * ldc];
         }
     }
@@ -91,31 +159,58 @@ __global__ void __launch_bounds__(WT) k_hess_w(Tree T, Data D, int h) {
 __global__ void __launch_bounds__(WT) k_factor_w(Tree T, Data D, Opts O, int first, int h) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ int small_flag;
+    const int ii = first + blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int e[14];
+#pragma unroll
+    for (int i = 0; i < 14; i++) e[i] = T.desc[(size_t)DESC_INTS * ii + i];      /* node record: requested together with the control block */
     if (!phase_main(D.ctrl, h)) return;
     Ctrl *c = D.ctrl;
-    const int ii = first + blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int d = T.bdim[ii], nxi = ii > 0 ? T.nx[ii] : 0;
-    const int R = d + 1 + nxi, dp = up16(d), Rp = up16(R), ld = wide_ld(Rp);
+    const int d = e[0], nxi = ii > 0 ? e[1] : 0;
+    /* rows in LDS: 0..d-1 the block, d..dp-1 identity padding (so that the padding columns stay inert), dp the right-hand
+     * side, dp+1.. the Ut rows */
+    const int dp = up16(d), R = dp + 1 + nxi, Rp = up16(R), ld = wide_ld(Rp);
     double *Tm = lds;                           /* ld x dp, column major */
-    const double *W = D.W + T.woff[ii];
-    const int bo = T.xoff[T.kid0[ii]];
-    const double *Ut = D.Ut + T.utoff[ii];
+    const double *W = D.W + e[8];
+    const int bo = e[7];
+    const double *Ut = D.Ut + e[9];
     const int r16 = lane & 15, g = lane >> 4;
-
+    double *Lout = D.CholW + e[8], *CUt = D.CholUt + e[9];
+    const int pos = e[11], ddim = e[12], xo = e[5];
+    double *Wd = D.W + e[13];
+    const int nt2 = ii > 0 ? (nxi + 1 + 15) >> 4 : 0;
+    WSTAMP(0);
     for (int pass = 0; pass < 2; pass++) {
         const double shift = (O.regType == 1 || pass == 1) ? O.regValue : 0.0;         /* ddiare */
         if (tid == 0) small_flag = 0;
-        for (int e = tid; e < ld * dp; e += WT) {
-            const int i = e % ld, j = e / ld;
-            double v = 0.0;
-            if (j < d) {
-                if (i < d) { if (i >= j) v = W[i + (size_t)j * d] + (i == j ? shift : 0.0); }
-                else if (i == d) v = D.resMod[bo + j];
-                else if (i < R) v = Ut[(i - d - 1) + (size_t)j * nxi];
-            } else if (i == j) v = 1.0;                                                /* padding columns: unit pivots */
-            Tm[i + (size_t)j * ld] = v;
+        /* rows on the lanes, columns dealt over the waves (j = wave + 4 m); 32-bit offsets from uniform bases, addresses
+         * clamped instead of branched, so that all 32 loads of a thread are in flight together (the block was written
+         * by other XCDs: ~2.4 us per dependent round trip).  Part A: the block itself (lower triangle), part B: the
+         * right-hand side row and the Ut rows (LDS rows dp + rr, rr = lane). */
+        {
+            double va[16], vb[16];
+            const int rr = lane;
+            const double *bbase = rr == 0 ? D.resMod + bo : Ut + (rr - 1);
+            const int bstride = rr == 0 ? 1 : nxi;
+            const bool brow = rr <= nxi;
+#pragma unroll
+            for (int m = 0; m < 16; m++) {
+                const int j = wave + WW * m;
+                const bool oka = lane < d && j < d && lane >= j, okb = brow && j < d;
+                va[m] = W[oka ? lane + j * d : 0];
+                vb[m] = bbase[okb ? j * bstride : 0];
+            }
+            LOADS_DONE();
+#pragma unroll
+            for (int m = 0; m < 16; m++) {
+                const int j = wave + WW * m;
+                const bool oka = lane < d && j < d && lane >= j, okb = brow && j < d;
+                const double xa = oka ? va[m] + (lane == j ? shift : 0.0) : ((lane == j && lane >= d) ? 1.0 : 0.0);   /* padding: identity */
+                if (lane < dp && j < dp) Tm[lane + j * ld] = xa;
+                if (dp + rr < Rp && j < dp) Tm[dp + rr + j * ld] = okb ? vb[m] : 0.0;
+            }
         }
         __syncthreads();
+        WSTAMP(1);
         for (int kb = 0; kb < dp; kb += 16) {
             /* ---- panel kb: rows kb.. , columns kb..kb+15, one row per lane, in registers ---- */
             const int nbelow = Rp - kb - 16;
@@ -129,6 +224,7 @@ __global__ void __launch_bounds__(WT) k_factor_w(Tree T, Data D, Opts O, int fir
                 for (int j = 0; j < 16; j++) { const double v = Tm[row + (size_t)(kb + j) * ld]; Tr[j] = valid ? v : 0.0; }
             }
             __syncthreads();                       /* every wave holds its copy of the diagonal tile before wave 0 overwrites it */
+            WSTAMP(2 + 3 * (kb >> 4));
             if (mine) {
                 const double pmin = p_potrf_rows<16>(Tr, lane);
                 if (valid && (wave == 0 || !diag)) {
@@ -138,6 +234,7 @@ __global__ void __launch_bounds__(WT) k_factor_w(Tree T, Data D, Opts O, int fir
                 if (wave == 0 && lane == 0 && pmin <= O.regTol * O.regTol) small_flag = 1;   /* sqrt(pivot) <= regTol, incl. non-positive pivots */
             }
             __syncthreads();
+            WSTAMP(3 + 3 * (kb >> 4));
             /* ---- trailing update: tile (I, J) -= P_I P_J', J > kb/16, I >= J; transposed product so that the lanes
              * of a C access run down a column of the tile ---- */
             const int ct = dp >> 4, rt = Rp >> 4, kt = kb >> 4;
@@ -159,55 +256,80 @@ __global__ void __launch_bounds__(WT) k_factor_w(Tree T, Data D, Opts O, int fir
                 }
             }
             __syncthreads();
+            WSTAMP(4 + 3 * (kb >> 4));
         }
+        WSTAMP(14);
         /* on-the-fly Levenberg-Marquardt: any diagonal entry <= regTol -> shift and refactorise */
         if (O.regType != 2 || pass == 1 || !small_flag) break;
         __syncthreads();
         if (tid == 0) atomicAdd(&c->n_reg, 1);
     }
 
-    /* outputs: factor, reciprocal diagonal */
-    double *L = D.CholW + T.woff[ii];
-    for (int e = tid; e < d * d; e += WT) {
-        const int i = e % d, j = e / d;
-        if (i >= j) L[i + (size_t)j * d] = Tm[i + (size_t)j * ld];
+    /* destination values of the Schur update (nobody else touches them during this launch), requested before the
+     * outputs are written so that part of their latency is hidden; same tile walk as the update below (at most 15
+     * lower tiles: 4 per wave).  (Requested at kernel start they cost 32 registers across the factorisation and
+     * one workgroup per CU less.) */
+    double pre[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) {
+        int J = 0, rem = wave + WW * mt;
+        while (J < nt2 && rem >= nt2 - J) { rem -= nt2 - J; J++; }      /* tile number -> (I, J), lower tiles column by column */
+        const int gi = 16 * (J + rem) + r16;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int gj = 16 * J + g + 4 * q;
+            const bool ok = J < nt2 && gi >= 1 && gi <= nxi && gj <= gi;
+            const double *src = !ok ? D.resMod + xo : (gj == 0 ? D.resMod + xo + gi - 1 : Wd + (pos + gi - 1) + (size_t)(pos + gj - 1) * ddim);
+            pre[mt][q] = *src;
+        }
     }
-    for (int j = tid; j < d; j += WT) { const double l = Tm[j + (size_t)j * ld]; D.invd[bo + j] = l > 0.0 ? 1.0 / l : 0.0; }
+    const double rv0 = D.res[bo + (lane < d ? lane : 0)];        /* root: residual for res' * dlam, requested early */
+    LOADS_DONE();
+    /* outputs: factor (rows on the lanes, columns dealt over the waves), reciprocal diagonal, backward solution, CholUt */
+    for (int j = wave; j < d; j += WW) {
+        if (lane < d && lane >= j) Lout[lane + j * d] = Tm[lane + j * ld];
+        if (ii > 0 && lane >= 1 && lane <= nxi) CUt[(lane - 1) + j * nxi] = Tm[dp + lane + j * ld];
+    }
+    for (int j = tid; j < d; j += WT) {
+        const double l = Tm[j + j * ld];
+        D.invd[bo + j] = l > 0.0 ? 1.0 / l : 0.0;
+        if (ii > 0) D.dlam[bo + j] = Tm[dp + j * ld];
+    }
 
     if (ii > 0) {
-        for (int j = tid; j < d; j += WT) D.dlam[bo + j] = Tm[d + (size_t)j * ld];
-        double *CUt = D.CholUt + T.utoff[ii];
-        for (int e = tid; e < nxi * d; e += WT) {
-            const int i = e % nxi, j = e / nxi;
-            CUt[i + (size_t)j * nxi] = Tm[d + 1 + i + (size_t)j * ld];
-        }
-        /* Schur complement into the parent's diagonal sub-block and right-hand side */
-        const int dd = T.dad[ii], pos = T.pos[ii], ddim = T.bdim[dd];
-        double *Wd = D.W + T.woff[dd];
-        for (int e = tid; e < nxi * nxi; e += WT) {
-            const int i = e % nxi, j = e / nxi;
-            if (i < j) continue;
-            double a0 = 0.0, a1 = 0.0;
-            int cidx = 0;
-            for (; cidx + 1 < d; cidx += 2) {
-                a0 = fma(Tm[d + 1 + i + (size_t)cidx * ld], Tm[d + 1 + j + (size_t)cidx * ld], a0);
-                a1 = fma(Tm[d + 1 + i + (size_t)(cidx + 1) * ld], Tm[d + 1 + j + (size_t)(cidx + 1) * ld], a1);
+        /* Schur complement into the parent's diagonal sub-block and right-hand side: G = Xt Xt', Xt = rows dp .. R-1
+         * (the backward solution y, then Ut L^-T); G[i][0] goes to resMod, G[i][j] (i >= j >= 1) to the parent's W.
+         * MFMA tiles over the padded columns (zeros beyond d); the destination values were fetched at the start. */
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) {
+            int J = 0, rem = wave + WW * mt;
+            while (J < nt2 && rem >= nt2 - J) { rem -= nt2 - J; J++; }
+            if (J >= nt2) continue;
+            const int I = J + rem;
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+            const int ra = dp + 16 * J + r16, rb = dp + 16 * I + r16;
+            const bool oka = ra < R, okb = rb < R;
+            for (int k = 0; k < dp; k += 4) {
+                const double a = Tm[(oka ? ra : 0) + (size_t)(k + g) * ld], b = Tm[(okb ? rb : 0) + (size_t)(k + g) * ld];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(oka ? a : 0.0, okb ? b : 0.0, acc, 0, 0, 0);
             }
-            if (cidx < d) a0 = fma(Tm[d + 1 + i + (size_t)cidx * ld], Tm[d + 1 + j + (size_t)cidx * ld], a0);
-            Wd[(pos + i) + (size_t)(pos + j) * ddim] -= a0 + a1;
-        }
-        const int xo = T.xoff[ii];
-        for (int i = tid; i < nxi; i += WT) {
-            double acc = 0.0;
-            for (int cidx = 0; cidx < d; cidx++) acc = fma(Tm[d + 1 + i + (size_t)cidx * ld], Tm[d + (size_t)cidx * ld], acc);
-            D.resMod[xo + i] -= acc;
+            const int gi = 16 * I + r16;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int gj = 16 * J + g + 4 * q;
+                if (gi >= 1 && gi <= nxi && gj <= gi) {
+                    if (gj == 0) D.resMod[xo + gi - 1] = pre[mt][q] - acc[q];
+                    else Wd[(pos + gi - 1) + (size_t)(pos + gj - 1) * ddim] = pre[mt][q] - acc[q];
+                }
+            }
         }
     } else if (wave == 0) {
         /* root: dlam_0 = L^-T (L^-1 resMod_0), the vector in registers (entry j on lane j) */
         const int lc = lane < d ? lane : 0;
         const double l = Tm[lc + (size_t)lc * ld];
         const double myinv = l > 0.0 ? 1.0 / l : 0.0;
-        double z = lane < d ? Tm[d + (size_t)lc * ld] : 0.0;
+        /* (one block per solve: the plain loop, not wide_backsolve's 64-register column) */
+        double z = lane < d ? Tm[dp + (size_t)lc * ld] : 0.0;
         for (int k = d - 1; k >= 1; k--) {
             const double lk = Tm[k + (size_t)lc * ld];
             const double zk = rdlane(z * myinv, k);
@@ -215,10 +337,11 @@ __global__ void __launch_bounds__(WT) k_factor_w(Tree T, Data D, Opts O, int fir
         }
         const double mine = z * myinv;
         double pd = 0.0;
-        if (lane < d) { D.dlam[bo + lane] = mine; pd = D.res[bo + lane] * mine; }
+        if (lane < d) { D.dlam[bo + lane] = mine; pd = rv0 * mine; }
         pd = wave_sum(pd);
         if (lane == 0) D.part_dot[0] = pd;
     }
+    WSTAMP(15);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -226,43 +349,51 @@ __global__ void __launch_bounds__(WT) k_factor_w(Tree T, Data D, Opts O, int fir
 /* ------------------------------------------------------------------------------------------ */
 __global__ void __launch_bounds__(WT) k_forward_w(Tree T, Data D, int first, int h) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    if (!phase_main(D.ctrl, h)) return;
     const int ii = first + blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int d = T.bdim[ii], nxi = T.nx[ii], ld = d | 1;
+    int e[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) e[i] = T.desc[(size_t)DESC_INTS * ii + i];      /* node record: requested together with the control block */
+    if (!phase_main(D.ctrl, h)) return;
+    const int d = e[0], nxi = e[1], ld = d | 1;
     double *L = lds;                      /* ld x d, lower part */
-    double *zz = lds + (size_t)ld * d;    /* d : right-hand side */
-    const int bo = T.xoff[T.kid0[ii]], xo = T.xoff[ii];
-    const double *Lg = D.CholW + T.woff[ii];
-    for (int e = tid; e < d * d; e += WT) {
-        const int i = e % d, j = e / d;
-        if (i >= j) L[i + (size_t)j * ld] = Lg[i + (size_t)j * d];
-    }
-    const double *CUt = D.CholUt + T.utoff[ii];
-    for (int j = tid; j < d; j += WT) {
+    double *zz = lds + (size_t)ld * d;    /* WW x 64 : per-wave partials of CholUt' * dlam_dad */
+    const int bo = e[7], xo = e[5];
+    const double *Lg = D.CholW + e[8];
+    const int lc = lane < d ? lane : 0;
+    /* everything this workgroup reads from global memory is requested up front (the data was written by other XCDs:
+     * ~2.4 us per dependent round trip): the factor (rows on the lanes, columns dealt over the waves), this wave's
+     * share of CholUt and of the parent's step, the reciprocal diagonal, the backward solution, the residual */
+    double v[16], cu[16], dl[16];
+#pragma unroll
+    for (int m = 0; m < 16; m++) { const int j = wave + WW * m; const bool ok = lane < d && j < d && lane >= j; v[m] = Lg[ok ? lane + (size_t)j * d : 0]; }
+    const double *CUt = D.CholUt + e[9] + (size_t)lc * nxi;
+#pragma unroll
+    for (int m = 0; m < 16; m++) { const int i = wave + WW * m; const bool ok = i < nxi; cu[m] = CUt[ok ? i : 0]; dl[m] = D.dlam[xo + (ok ? i : 0)]; }
+    const double myinv = D.invd[bo + lc], yv = D.dlam[bo + lc], rv = D.res[bo + lc];
+    LOADS_DONE();
+#pragma unroll
+    for (int m = 0; m < 16; m++) { const int j = wave + WW * m; if (lane < d && j < d && lane >= j) L[lane + (size_t)j * ld] = v[m]; }
+    {
         double a0 = 0.0, a1 = 0.0;
-        int i = 0;
-        for (; i + 1 < nxi; i += 2) { a0 = fma(CUt[i + (size_t)j * nxi], D.dlam[xo + i], a0); a1 = fma(CUt[i + 1 + (size_t)j * nxi], D.dlam[xo + i + 1], a1); }
-        if (i < nxi) a0 = fma(CUt[i + (size_t)j * nxi], D.dlam[xo + i], a0);
-        zz[j] = fma(-1.0, a0 + a1, D.dlam[bo + j]);
+#pragma unroll
+        for (int m = 0; m < 16; m += 2) {
+            a0 = fma(wave + WW * m < nxi ? cu[m] : 0.0, dl[m], a0);
+            a1 = fma(wave + WW * (m + 1) < nxi ? cu[m + 1] : 0.0, dl[m + 1], a1);
+        }
+        zz[wave * 64 + lane] = a0 + a1;
     }
     __syncthreads();
     if (wave != 0) return;
-    const int lc = lane < d ? lane : 0;
-    const double myinv = D.invd[bo + lc];
-    double z = lane < d ? zz[lc] : 0.0;
-    for (int k = d - 1; k >= 1; k--) {
-        const double lk = L[k + (size_t)lc * ld];
-        const double zk = rdlane(z * myinv, k);
-        z = fma(lane < k ? -lk : 0.0, zk, z);
-    }
-    const double mine = z * myinv;
+    const double rhs = lane < d ? fma(-1.0, (zz[lane] + zz[64 + lane]) + (zz[128 + lane] + zz[192 + lane]), yv) : 0.0;
+    const double mine = wide_backsolve(L, ld, d, lane, rhs, myinv);
     double pd = 0.0;
-    if (lane < d) { D.dlam[bo + lane] = mine; pd = D.res[bo + lane] * mine; }
+    if (lane < d) { D.dlam[bo + lane] = mine; pd = rv * mine; }
     pd = wave_sum(pd);
     if (lane == 0) D.part_dot[ii] = pd;
 }
 
 /* LDS a block of dimension d (tall matrix of R rows, nz parent columns) needs in the wide kernels */
 static inline size_t wide_lds_hess(int d, int nz) { const int dp = (d + 15) & ~15, kz = (nz + 3) & ~3; return (size_t)2 * (dp | 16) * kz * sizeof(double); }
-static inline size_t wide_lds_factor(int d, int R) { const int dp = (d + 15) & ~15, Rp = (R + 15) & ~15; return (size_t)(Rp | 16) * dp * sizeof(double); }
-static inline size_t wide_lds_forward(int d) { return ((size_t)(d | 1) * d + d + 2) * sizeof(double); }
+static inline int wide_rows(int d, int nxi) { const int dp = (d + 15) & ~15; return (dp + 1 + nxi + 15) & ~15; }      /* padded rows of the tall matrix */
+static inline size_t wide_lds_factor(int d, int nxi) { const int dp = (d + 15) & ~15; return (size_t)(wide_rows(d, nxi) | 16) * dp * sizeof(double); }
+static inline size_t wide_lds_forward(int d) { return ((size_t)(d | 1) * d + WW * 64 + 2) * sizeof(double); }
