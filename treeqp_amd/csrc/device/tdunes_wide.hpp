@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(WT) k_hess_w(Tree T, Data D, int h) {
     const int p = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int e[28];
 #pragma unroll
-    for (int i = 0; i < 28; i++) e[i] = T.desc[(size_t)DESC_INTS * p + i];       /* node record: requested together with the control block */
+    for (int i = 0; i < 28; i++) e[i] = T.desc[DESC_INTS * p + i];       /* node record: requested together with the control block */
     if (!phase_main(D.ctrl, h)) return;
     const int d = e[0], nxp = e[1], nup = e[2], nz = nxp + nup;
     const int dp = up16(d), kz = (nz + 3) & ~3, ldc = wide_ld(dp);
@@ -79,46 +79,39 @@ __global__ void __launch_bounds__(WT) k_hess_w(Tree T, Data D, int h) {
     const double *Qc = D.QinvCal + e[5], *Rc = D.RinvCal + e[6];
     for (int e = tid; e < 2 * ldc * kz; e += WT) lds[e] = 0.0;
     __syncthreads();
-    /* children's [A B] rows: rows on the lanes, columns dealt over the waves; branch-free (clamped) loads, up to four
-     * children x eight columns in flight per thread */
+    /* children's [A B] rows: rows on the lanes, columns dealt over the waves; branch-free (clamped) loads with 32-bit
+     * offsets, eight in flight per thread and child (more in flight costs registers, i.e. workgroups per CU, and this
+     * launch is one block per parent: throughput matters more than one block's latency) */
     const int nkp = e[3];
-    for (int cc0 = 0, rowoff0 = 0; cc0 < nkp; cc0 += 4) {
-        int nxc[4], ro[4];
-        const double *Ap[4], *Bp[4];
-        int rowoff = rowoff0;
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int kid = k0 + (cc0 + u < nkp ? cc0 + u : cc0);
-            const bool rec = cc0 == 0;                                            /* the first four children are in the record */
-            nxc[u] = cc0 + u < nkp ? (rec ? e[16 + 3 * u] : T.nx[kid]) : 0; ro[u] = rowoff; rowoff += nxc[u];
-            Ap[u] = D.A + (rec ? e[17 + 3 * u] : T.aoff[kid]); Bp[u] = D.B + (rec ? e[18 + 3 * u] : T.boff[kid]);
-        }
+    for (int cc = 0, rowoff = 0; cc < nkp; cc++) {
+        const int kid = k0 + cc;
+        const bool rec = cc < 4;                                                  /* the first four children are in the record */
+        /* (static indices: a dynamically indexed register array would live in scratch memory) */
+        const int rnx = cc == 0 ? e[16] : cc == 1 ? e[19] : cc == 2 ? e[22] : e[25];
+        const int rao = cc == 0 ? e[17] : cc == 1 ? e[20] : cc == 2 ? e[23] : e[26];
+        const int rbo = cc == 0 ? e[18] : cc == 1 ? e[21] : cc == 2 ? e[24] : e[27];
+        const int nxc = rec ? rnx : T.nx[kid];
+        const double *A = D.A + (rec ? rao : T.aoff[kid]), *B = D.B + (rec ? rbo : T.boff[kid]);
+        const bool rowok = lane < nxc;
+        const int i = rowok ? lane : 0;
         for (int c0 = 0; c0 < nz; c0 += 8 * WW) {
-            double a[4][8], pc[8];
+            double a[8], pc[8];
 #pragma unroll
             for (int m = 0; m < 8; m++) {
                 const int col = c0 + wave + WW * m;
-                const int cs = col < nz ? col : 0;
-                pc[m] = cs < nxp ? Qc[cs] : Rc[cs - nxp];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const bool ok = lane < nxc[u] && col < nz;
-                    const int i = ok ? lane : 0, cu = ok ? cs : 0, nxu = nxc[u] > 0 ? nxc[u] : 1;
-                    const double *src = cu < nxp ? Ap[u] + i + (size_t)cu * nxu : Bp[u] + i + (size_t)(cu - nxp) * nxu;
-                    a[u][m] = *(nxc[u] > 0 ? src : Qc);
-                }
+                const int cs = (rowok && col < nz) ? col : 0;
+                const bool st = cs < nxp;
+                a[m] = (st ? A : B)[i + (st ? cs : cs - nxp) * nxc];
+                pc[m] = (st ? Qc : Rc)[st ? cs : cs - nxp];
             }
             LOADS_DONE();
 #pragma unroll
             for (int m = 0; m < 8; m++) {
                 const int col = c0 + wave + WW * m;
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    if (lane < nxc[u] && col < nz) { Cs[ro[u] + lane + (size_t)col * ldc] = a[u][m]; CP[ro[u] + lane + (size_t)col * ldc] = a[u][m] * pc[m]; }
-                }
+                if (rowok && col < nz) { Cs[rowoff + i + col * ldc] = a[m]; CP[rowoff + i + col * ldc] = a[m] * pc[m]; }
             }
         }
-        rowoff0 = rowoff;
+        rowoff += nxc;
     }
     __syncthreads();
     /* lower tiles (I >= J); computed transposed (A = tile J of CP, B = tile I of C) so that a lane's results lie in
