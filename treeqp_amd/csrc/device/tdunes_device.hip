@@ -1374,10 +1374,16 @@ int launch_persist(tqgpu_solver *s, const Opts &O, int &launches, int prologue) 
     return TQGPU_OK;
 }
 
-void launch_generic_iteration(tqgpu_solver *s, const Opts &O, int h, int &launches) {
+/* one Newton iteration on the generic path = its termination test (gradient + check) and the rest (Newton system, step,
+ * first trial); `parts` bit 0 / bit 1 select them.  The host enqueues the iteration it expects to be the last one
+ * (warm: as many as the previous solve needed) without the rest: ~17 launches that would only find `done` set. */
+void launch_generic_iteration(tqgpu_solver *s, const Opts &O, int h, int &launches, int parts = 3) {
     const Tree &T = s->T; const Data &D = s->D; hipStream_t st = s->stream;
-    hipLaunchKernelGGL(k_grad, dim3(T.Nn - 1), dim3(WAVE), 0, st, T, D, O.termCondition, h); launches++;
-    hipLaunchKernelGGL(k_check, dim3(1), dim3(256), 0, st, T, D, O, h); launches++;
+    if (parts & 1) {
+        hipLaunchKernelGGL(k_grad, dim3(T.Nn - 1), dim3(WAVE), 0, st, T, D, O.termCondition, h); launches++;
+        hipLaunchKernelGGL(k_check, dim3(1), dim3(256), 0, st, T, D, O, h); launches++;
+    }
+    if (!(parts & 2)) return;
     const bool wide = s->wide && !s->dense;
     if (wide) hipLaunchKernelGGL(k_hess_w, dim3(T.Np), dim3(WT), s->lds_hess_w, st, T, D, h);
     else hipLaunchKernelGGL(k_hess, dim3(T.Np), dim3(WAVE), s->lds_hess, st, T, D, h);
@@ -1935,6 +1941,8 @@ int solve_end(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, tqgpu_result *
     if (finished) { HIP_TRY(hipStreamSynchronize(st)); memset(s->h_ctrl, 0, sizeof(Ctrl)); s->h_ctrl->status = 1; }
     if (o->profile) HIP_TRY(hipEventRecord(s->iter_ev[0], st));
     int chunk = s->last_iter > 0 ? std::min(s->last_iter + 1, 16) : s->chunk;
+    bool predicted = s->last_iter > 0 && !fast && !persist;     /* the chunk is a prediction: its last iteration should only find convergence */
+    int rest_due = -1;                                          /* iteration whose termination test ran, whose step did not */
     while (!finished) {
         const int n = persist ? 0 : std::min(chunk, o->maxIter - h);
         if (persist) {
@@ -1947,9 +1955,15 @@ int solve_end(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, tqgpu_result *
             }
             cx.prelaunched = false;
         }
+        int deferred = -1;
         for (int i = 0; i < n; i++) {
             if (fast) { int rcx = launch_fast_iteration(s, O, h + i, launches); if (rcx != TQGPU_OK) return rcx; }
-            else launch_generic_iteration(s, O, h + i, launches);
+            else {
+                int parts = 3;
+                if (rest_due == h + i) parts &= ~1;                                   /* its test already ran */
+                if (predicted && i == n - 1) { parts &= ~2; deferred = h + i; }
+                if (parts) launch_generic_iteration(s, O, h + i, launches, parts);
+            }
             if (o->profile && ev_idx + 1 < (int)s->iter_ev.size()) HIP_TRY(hipEventRecord(s->iter_ev[++ev_idx], st));
         }
         /* persistent path: the verdict comes through the result block in pinned host memory */
@@ -1970,6 +1984,8 @@ int solve_end(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, tqgpu_result *
         h = s->h_ctrl->iter;
         finished = s->h_ctrl->done != 0;
         chunk = s->chunk;
+        predicted = false;
+        rest_due = (!finished && deferred == h) ? h : -1;
         if (persist && !finished && !cx.gpersist) {
             tail_done = false;
             unsigned tmo = 0;
