@@ -628,3 +628,23 @@ def test_batched_multi_tree_solve_matches_single_solves(gpu, orc):
             assert np.array_equal(sol[k], s1[k])                                # same kernels, same data: bit-identical
         assert orc.max_kkt(f, sol) < 1e-8
         m.close()
+
+
+def test_batch_of_pruned_trees_is_one_launch(gpu, orc):
+    """C5 class (fault_tolerance.c:486-530 keeps one QP per configuration): a batch of independent pruned scenario trees goes
+    out as ONE launch, one workgroup per tree; every member must match its own single solve and the oracle."""
+    fs = [P.pruned_chain_qp(seed=7 + i) for i in range(6)]
+    ms = [gpu.TqGpu(f.nk, f.nx, f.nu).upload(f.as_dict(), f.lambda0) for f in fs]
+    opts = fs[0].opts
+    single = [m.solve(**opts) for m in ms]
+    sols = [m.solution() for m in ms]
+    res = gpu.solve_batch(ms, **opts)
+    for f, m, r1, s1, rb in zip(fs, ms, single, sols, res):
+        ref = orc.solve(f.as_dict(), orc.default_opts(**opts), lambda0=f.lambda0)
+        assert rb["status"] == ref["status"] == 0 and rb["iter"] == ref["iter"] == r1["iter"] and rb["ls_total"] == ref["ls_total"]
+        assert rb["n_launches"] == 1
+        sb = m.solution()
+        assert_solution_close(sb, ref, 1e-8, keys=("x", "u", "lam"))
+        assert_solution_close(sb, s1, 1e-9, keys=("x", "u", "lam"))
+    for m in ms:
+        m.close()

@@ -838,6 +838,8 @@ struct tqgpu_solver {
     PConst pconst{};
     void *sync_slab = nullptr;
     int *d_desc = nullptr;
+    GItem *d_gitems = nullptr, *h_gitems = nullptr; int gitems_cap = 0;   /* batched single-workgroup launches (first mirror of a batch owns the array) */
+    hipEvent_t batch_ev = nullptr;
     size_t sync_words_bytes = 0, lds_persist = 0;
     /* sharded mode */
     int nranks = 1, rank = 0, part_top = -1;      /* part_top: highest partitioned tier */
@@ -1576,7 +1578,7 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
         for (int l = 0; l <= s->Nh; l++) widest = std::max(widest, s->lvl_first[l + 1] - s->lvl_first[l]);
         const size_t per_wave = (std::max(std::max(s->lds_stage, s->lds_hess), std::max(s->lds_factor, s->lds_forward)) + 7) / 8 + 2;
         s->lds_gp_wave = per_wave;
-        s->gpersist_ok = widest <= 6 * GP_WAVES && per_wave * 8 * GP_WAVES <= 64 * 1024;
+        s->gpersist_ok = widest <= 6 * GP_WAVES && per_wave * 8 * GP_WAVES <= 150 * 1024;
         /* LDS mirror of the mutable state (tdunes_gpersist.hpp): 16 node-sized vectors (rounded up to even), 4 block arrays */
         {
             auto ev = [](size_t n) { return (n + 1) & ~(size_t)1; };
@@ -1593,6 +1595,11 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
                      hipFuncSetAttribute(reinterpret_cast<const void *>(g_persist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_gp_total) != hipSuccess) {
                 (void)hipGetLastError();
                 s->gp_in_lds = false; s->lds_gp_total = per_wave * GP_WAVES * 8;
+            }
+            if (s->gpersist_ok && !s->gp_in_lds && s->lds_gp_total > 64 * 1024 &&
+                hipFuncSetAttribute(reinterpret_cast<const void *>(g_persist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_gp_total) != hipSuccess) {
+                (void)hipGetLastError();
+                s->gpersist_ok = false;
             }
         }
         if (s->gpersist_ok) {
@@ -1620,6 +1627,9 @@ extern "C" void tqgpu_destroy(tqgpu_solver *s) {
     if (s->pconst_slab) (void)hipFree(s->pconst_slab);
     if (s->wg_map) (void)hipFree(s->wg_map);
     if (s->d_desc) (void)hipFree(s->d_desc);
+    if (s->d_gitems) (void)hipFree(s->d_gitems);
+    if (s->h_gitems) (void)hipHostFree(s->h_gitems);
+    if (s->batch_ev) (void)hipEventDestroy(s->batch_ev);
     if (s->h_in) (void)hipHostFree(s->h_in);
     if (s->h_lam) (void)hipHostFree(s->h_lam);
     if (s->h_out) (void)hipHostFree(s->h_out);
@@ -1634,8 +1644,10 @@ extern "C" void tqgpu_destroy(tqgpu_solver *s) {
  * trees only), single-workgroup persistent (small trees of any shape), launch per level */
 static bool persist_capable(const tqgpu_solver *s) { return s->fast >= 0 && s->use_fast && s->persist_ok && s->use_persist && s->nranks == 1; }
 static bool tiered_capable(const tqgpu_solver *s) { return s->fast >= 0 && s->use_fast && !s->mstage; }
-static bool uses_gpersist(const tqgpu_solver *s) {
-    return s->gpersist_ok && s->use_gpersist && !s->dense && s->nranks == 1 && !persist_capable(s) && !tiered_capable(s);
+/* `batch`: as a member of a batched launch (one workgroup per tree) the single-workgroup kernel also takes trees whose
+ * state does not fit the LDS mirror; alone, such a tree is faster with one launch per level */
+static bool uses_gpersist(const tqgpu_solver *s, bool batch = false) {
+    return s->gpersist_ok && (s->gp_in_lds || batch) && s->use_gpersist && !s->dense && s->nranks == 1 && !persist_capable(s) && !tiered_capable(s);
 }
 extern "C" int tqgpu_uses_fused_path(const tqgpu_solver *s) {
     if (!s) return 0;
@@ -1850,7 +1862,7 @@ struct SolveCtx {
 #endif
 };
 
-int solve_begin(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx) {
+int solve_begin(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, GItem *defer = nullptr) {
 #ifdef TQ_HOSTPROF
     cx.hp0 = HP_NOW();
 #endif
@@ -1878,7 +1890,7 @@ int solve_begin(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx) {
 
     cx.fast = tiered_capable(s);
     cx.persist = persist_capable(s) && !o->profile && o->maxIter > 0;
-    cx.gpersist = !cx.persist && uses_gpersist(s) && !o->profile && o->maxIter > 0;
+    cx.gpersist = !cx.persist && uses_gpersist(s, defer != nullptr) && !o->profile && o->maxIter > 0;
     if (cx.gpersist) cx.persist = true;                  /* same host flow: one launch, verdict through the result block */
     cx.ring = (int)(s->solve_no % EV_RING);
     cx.ev0 = s->ring_ev0[cx.ring]; cx.ev1 = s->ring_ev1[cx.ring];
@@ -1912,7 +1924,9 @@ int solve_begin(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx) {
             gp.lvl_first = s->d_lvl_first; gp.lam_init = s->d_lam_init; gp.hres = s->h_res; gp.seq = s->psync.seq; gp.lds_wave = (int)s->lds_gp_wave;
             gp.in_lds = s->gp_in_lds ? 1 : 0; gp.sum_nx = s->sum_nx; gp.sum_nu = s->sum_nu; gp.sum_W = s->sum_W; gp.sum_Ut = s->sum_Ut;
             gp.const_in_lds = s->gp_const_in_lds ? 1 : 0; gp.sum_A = s->sum_A; gp.sum_B = s->sum_B;
-            hipLaunchKernelGGL(g_persist, dim3(1), dim3(GP_WAVES * WAVE), s->lds_gp_total, st, T, D, O, gp); cx.launches++;
+            if (defer) { defer->T = T; defer->D = D; defer->G = gp; }           /* launched by the caller, together with the rest of its batch */
+            else hipLaunchKernelGGL(g_persist, dim3(1), dim3(GP_WAVES * WAVE), s->lds_gp_total, st, T, D, O, gp);
+            cx.launches++;
         } else rcx = launch_persist(s, O, cx.launches, 1);
         if (rcx != TQGPU_OK) return rcx;
         cx.first_launch = false; cx.prelaunched = true;
@@ -2049,17 +2063,54 @@ extern "C" int tqgpu_solve_batch(tqgpu_solver **solvers, int n, const tqgpu_opts
         for (; j < n; j++) {
             tqgpu_solver *s = solvers[j];
             const bool persist_like = persist_capable(s) && !o->profile && o->maxIter > 0;
-            const bool gp_like = !persist_like && uses_gpersist(s) && !o->profile && o->maxIter > 0;
-            const int need = persist_like ? s->geom.G : (gp_like ? 1 : s->co_capacity + 1);   /* launch-per-level mirrors go alone */
+            const bool gp_like = !persist_like && uses_gpersist(s, true) && !o->profile && o->maxIter > 0;
+            /* single-workgroup mirrors do not wait for each other: any number per launch; launch-per-level mirrors go alone */
+            const int need = persist_like ? s->geom.G : (gp_like ? 0 : s->co_capacity + 1);
             if (j > i && (s->device != dev || used + need > s->co_capacity)) break;
             used += need;
         }
         const int begun_from = i, begun_to = j;
         int ok_to = begun_from;
+        /* single-workgroup mirrors of this wave go out as ONE launch (one workgroup per tree) on the first one's stream */
+        std::vector<int> gp_members;
         for (int k = begun_from; k < begun_to; k++) {
-            int rc = solve_begin(solvers[k], o, cx[(size_t)k]);
+            tqgpu_solver *s = solvers[k];
+            if (!persist_capable(s) && uses_gpersist(s, true) && !o->profile && o->maxIter > 0) gp_members.push_back(k);
+        }
+        tqgpu_solver *lead = gp_members.size() >= 2 ? solvers[gp_members[0]] : nullptr;
+        if (lead && lead->gitems_cap < (int)gp_members.size()) {
+            if (lead->d_gitems) (void)hipFree(lead->d_gitems);
+            if (lead->h_gitems) (void)hipHostFree(lead->h_gitems);
+            lead->d_gitems = nullptr; lead->h_gitems = nullptr; lead->gitems_cap = 0;
+            const size_t cap = gp_members.size() * 2;
+            if (hipMalloc(&lead->d_gitems, cap * sizeof(GItem)) != hipSuccess || hipHostMalloc((void **)&lead->h_gitems, cap * sizeof(GItem), hipHostMallocDefault) != hipSuccess)
+                return fail(TQGPU_ENOMEM, "allocation of the batch descriptors failed");
+            lead->gitems_cap = (int)cap;
+        }
+        size_t gi = 0, lds_batch = 0;
+        for (int k = begun_from; k < begun_to; k++) {
+            const bool in_group = lead && gi < gp_members.size() && gp_members[gi] == k;
+            int rc = solve_begin(solvers[k], o, cx[(size_t)k], in_group ? &lead->h_gitems[gi] : nullptr);
             if (rc != TQGPU_OK) { if (first_err == TQGPU_OK) { first_err = rc; first_msg = g_err; } break; }
+            if (in_group) { gi++; lds_batch = std::max(lds_batch, solvers[k]->lds_gp_total); }
             ok_to = k + 1;
+        }
+        if (lead && gi > 0) {
+            hipStream_t st0 = lead->stream;
+            /* inputs of the other members were uploaded on their own streams: order the launch behind them, and their
+             * later work (solution export) behind the launch */
+            for (size_t m = 1; m < gi; m++) {
+                tqgpu_solver *sm = solvers[gp_members[m]];
+                if (!sm->batch_ev && hipEventCreateWithFlags(&sm->batch_ev, hipEventDisableTiming) != hipSuccess) return fail(TQGPU_ENODEVICE, "hipEventCreate failed");
+                HIP_TRY(hipEventRecord(sm->batch_ev, sm->stream));
+                HIP_TRY(hipStreamWaitEvent(st0, sm->batch_ev, 0));
+            }
+            HIP_TRY(hipMemcpyAsync(lead->d_gitems, lead->h_gitems, gi * sizeof(GItem), hipMemcpyHostToDevice, st0));
+            if (lds_batch > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(g_persist_batch), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_batch));
+            hipLaunchKernelGGL(g_persist_batch, dim3((unsigned)gi), dim3(GP_WAVES * WAVE), lds_batch, st0, lead->d_gitems, cx[(size_t)gp_members[0]].O);
+            if (!lead->batch_ev && hipEventCreateWithFlags(&lead->batch_ev, hipEventDisableTiming) != hipSuccess) return fail(TQGPU_ENODEVICE, "hipEventCreate failed");
+            HIP_TRY(hipEventRecord(lead->batch_ev, st0));
+            for (size_t m = 1; m < gi; m++) HIP_TRY(hipStreamWaitEvent(solvers[gp_members[m]]->stream, lead->batch_ev, 0));
         }
         for (int k = begun_from; k < ok_to; k++) {
             int rc = solve_end(solvers[k], o, cx[(size_t)k], &results[k]);

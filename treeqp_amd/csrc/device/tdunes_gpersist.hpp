@@ -39,7 +39,7 @@ __device__ __forceinline__ double *gp_take(double *&cursor, int n) { double *p =
 /* The two descriptor structs hold ~60 pointers.  As kernel arguments (or locals) they would have to live in
  * scalar registers for the whole kernel -- 120 SGPRs, more than a wave has -- and every use would be a spill
  * reload.  They live in LDS instead: the bodies fetch the pointer they need when they need it. */
-__global__ void __launch_bounds__(GP_WAVES * WAVE) g_persist(Tree T_in, Data D_in, Opts O, GParams G) {
+__device__ __forceinline__ void g_persist_body(Tree T_in, Data D_in, Opts O, GParams G) {
     __shared__ Data sD;
     __shared__ Tree sT;
     Data D = D_in;
@@ -203,4 +203,15 @@ __global__ void __launch_bounds__(GP_WAVES * WAVE) g_persist(Tree T_in, Data D_i
         __hip_atomic_store(&hr->t_end, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&hr->seq, G.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+
+__global__ void __launch_bounds__(GP_WAVES * WAVE) g_persist(Tree T_in, Data D_in, Opts O, GParams G) { g_persist_body(T_in, D_in, O, G); }
+
+/* a batch of independent small trees (fault_tolerance.c keeps one QP per spring configuration, :486-530): ONE launch, one
+ * workgroup per tree, each working from its own descriptors.  (One launch per tree on its own stream only overlaps as
+ * many trees as the runtime has hardware queues -- four.) */
+struct GItem { Tree T; Data D; GParams G; };
+__global__ void __launch_bounds__(GP_WAVES * WAVE) g_persist_batch(const GItem *items, Opts O) {
+    const GItem *it = items + blockIdx.x;
+    g_persist_body(it->T, it->D, O, it->G);
 }
