@@ -648,3 +648,36 @@ def test_batch_of_pruned_trees_is_one_launch(gpu, orc):
         assert_solution_close(sb, s1, 1e-9, keys=("x", "u", "lam"))
     for m in ms:
         m.close()
+
+
+LS_OPTS = [dict(), dict(lineSearchMaxIter=3), dict(lineSearchMaxIter=5, lineSearchRestartTrigger=2), dict(lineSearchBeta=0.3),
+           dict(lineSearchBeta=0.9, lineSearchMaxIter=40), dict(lineSearchGamma=0.4), dict(lineSearchMaxIter=1), dict(termCondition=1),
+           dict(regType=1, regValue=1e-7)]
+
+
+@pytest.mark.parametrize("make", [lambda: P.linear_chain(2, 6, 6, ubound=0.1), lambda: P.spring_mass(md=3, Nr=2, Nh=7)], ids=["chain_2_6_6", "multistage_3_2_7"])
+def test_persistent_path_line_search_corners(gpu, orc, make):
+    """The in-kernel line search (batches of dry trial sweeps) against the oracle: far starts that need backtracking, trial limit
+    exhausted, restart trigger, other beta / gamma.  Only runs the oracle itself converges on are compared: a start that defeats
+    the method (singular dual Hessian, regularisation-dominated steps of 1e12) has no parity to check."""
+    p = make()
+    flat = oracle_flat_from_lti(orc, p)
+    g = gpu.TqGpu(flat["nk"], flat["nx"], flat["nu"]).upload(flat, p.lambda0)
+    assert g.path == 2
+    compared = backtracked = 0
+    for seed in range(3):
+        for scale in (3.0, 10.0):
+            lam0 = scale * np.random.Generator(np.random.PCG64(seed)).standard_normal(len(p.lambda0))
+            for o in LS_OPTS:
+                ref = orc.solve(flat, orc.default_opts(**o), lam0)
+                if ref["status"] != 0:
+                    continue
+                g.set_lambda(lam0)
+                r = g.solve(**o)
+                assert (r["status"], r["iter"], r["ls_total"]) == (0, ref["iter"], ref["ls_total"]), (seed, scale, o)
+                assert r["n_launches"] <= 3          # one solve kernel (+ the pack / init kernels of a first solve): no host-run trials
+                assert_solution_close(g.solution(), ref, 1e-7, keys=("x", "u", "lam"))
+                compared += 1
+                backtracked += ref["ls_total"] > ref["iter"]
+    assert compared >= 30 and backtracked >= 10
+    g.close()
