@@ -223,6 +223,25 @@ def main():
                          "algorithmic_bytes_per_iteration": bytes_it, "algorithmic_flops_per_iteration": flops_it,
                          "note": "latency-bound: a chain of dependent 25x16 block factorisations per tree level; the solve's state is LDS-resident, so memory traffic is far below the algorithmic bytes"},
         }
+        if world == 1 and args.trees == 1 and g.path == 2:
+            # throughput leg (reported beside the latency metric, never as `value`): independent trees of the same
+            # workload solved by one batched call per step -- what a scenario sweep (fault_tolerance.c:486-530) gets
+            nb = 3
+            more = [capi.TqGpu(nk, nx, nu).upload(flat, p.lambda0) for _ in range(nb - 1)]
+            batch = [g] + more
+            for _ in range(10):
+                capi.solve_batch(batch)
+            tb0 = time.perf_counter()
+            nit = 0
+            ksteps = max(20, min(args.steps, 200))
+            for _ in range(ksteps):
+                nit += sum(rr["iter"] for rr in capi.solve_batch(batch))
+            g.device_times(1)                                            # synchronises
+            tb = time.perf_counter() - tb0
+            out["batched"] = {"trees_per_gpu": nb, "value": nit / tb, "unit": "newton_iter/s", "steps": ksteps, "ms_per_step": 1e3 * tb / ksteps,
+                              "note": "independent trees per GPU, one persistent launch each, concurrently resident; throughput, not the latency metric"}
+            for m in more:
+                m.close()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(p, flat)
         print(json.dumps(out), flush=True)
