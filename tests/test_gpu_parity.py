@@ -359,6 +359,15 @@ FUSED_CASES = [
     ("chain_8_2_2_h5", lambda: P.linear_chain(2, 5, 5, nm=4, nu=2)),
     ("chain_4_1_3_h5", lambda: P.linear_chain(3, 5, 5, nm=2)),
     ("chain_8_3_2_h2", lambda: P.linear_chain(2, 2, 2)),
+    ("chain_4_1_4_h3", lambda: P.linear_chain(4, 3, 3, nm=2)),
+    ("chain_8_1_2_h4", lambda: P.linear_chain(2, 4, 4, nm=4, nu=1)),
+    ("chain_8_4_2_h4", lambda: P.linear_chain(2, 4, 4, nm=4, nu=4)),
+    ("chain_4_2_2_h5", lambda: P.linear_chain(2, 5, 5, nm=2, nu=2)),
+    ("chain_4_2_3_h3", lambda: P.linear_chain(3, 3, 3, nm=2, nu=2)),
+    ("chain_4_2_4_h3", lambda: P.linear_chain(4, 3, 3, nm=2, nu=2)),
+    ("chain_6_1_2_h4", lambda: P.linear_chain(2, 4, 4, nm=3, nu=1)),
+    ("chain_6_3_2_h4", lambda: P.linear_chain(2, 4, 4, nm=3, nu=3)),
+    ("chain_2_1_4_h3", lambda: P.linear_chain(4, 3, 3, nm=1, nu=1)),                              # four children: d = 16 from nx = 4
     ("chain_8_3_2_h3", lambda: P.linear_chain(2, 3, 3)),
     ("chain_8_3_2_h10", lambda: P.linear_chain(2, 10, 10)),
 ]
@@ -372,6 +381,9 @@ MSTAGE_CASES = [
     ("chain_8_3_2_r2_h6", lambda: P.linear_chain(2, 2, 6)),
     ("chain_8_3_2_r4_h5", lambda: P.linear_chain(2, 4, 5)),                           # one chain level only
     ("chain_8_2_2_r3_h8_tight", lambda: P.linear_chain(2, 3, 8, nm=4, nu=2, ubound=0.1)),
+    ("chain_4_1_4_r2_h6", lambda: P.linear_chain(4, 2, 6, nm=2)),
+    ("chain_8_4_2_r2_h6", lambda: P.linear_chain(2, 2, 6, nm=4, nu=4)),
+    ("chain_4_2_3_r2_h5", lambda: P.linear_chain(3, 2, 5, nm=2, nu=2)),
 ]
 
 

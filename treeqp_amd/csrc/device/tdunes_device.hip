@@ -957,7 +957,9 @@ int allow_lds(K kernel, size_t bytes) {
 
 
 /* (NX, NU, MD) instantiations of the fused path */
-#define FAST_TABLE(X) X(0, 8, 3, 2) X(1, 4, 1, 2) X(2, 4, 1, 3) X(3, 2, 1, 2) X(4, 8, 2, 2) X(5, 6, 2, 2)
+/* instantiated (index, nx, nu, md): nx * md <= 16 and a multiple of 4, nx + nu <= 16 */
+#define FAST_TABLE(X) X(0, 8, 3, 2) X(1, 4, 1, 2) X(2, 4, 1, 3) X(3, 2, 1, 2) X(4, 8, 2, 2) X(5, 6, 2, 2) X(6, 4, 1, 4) \
+    X(7, 8, 1, 2) X(8, 8, 4, 2) X(9, 4, 2, 2) X(10, 4, 3, 2) X(11, 4, 2, 3) X(12, 4, 2, 4) X(13, 6, 1, 2) X(14, 6, 3, 2) X(15, 2, 1, 4) X(16, 2, 2, 2)
 
 int fast_index(int NX, int NU, int MD) {
 #define X(idx, nx, nu, md) if (NX == nx && NU == nu && MD == md) return idx;
@@ -974,7 +976,9 @@ void fast_geometry(int idx, int &TH, size_t &tier_lds, size_t &stage_lds) {
 
 /* (NX, NU, MD) instantiations of the multistage persistent kernel: the chain part works on blocks of NX rows,
  * which the MFMA Schur tile wants to be a multiple of 4 */
-#define MSTAGE_TABLE(X) X(0, 8, 3, 2) X(1, 4, 1, 2) X(2, 4, 1, 3) X(4, 8, 2, 2)
+/* multistage trees: the chain part's MFMA tile needs nx % 4 == 0 */
+#define MSTAGE_TABLE(X) X(0, 8, 3, 2) X(1, 4, 1, 2) X(2, 4, 1, 3) X(4, 8, 2, 2) X(6, 4, 1, 4) \
+    X(7, 8, 1, 2) X(8, 8, 4, 2) X(9, 4, 2, 2) X(10, 4, 3, 2) X(11, 4, 2, 3) X(12, 4, 2, 4)
 
 /* multistage tree?  (setup_multistage_tree(md, Nr, Nh) with 1 <= Nr < Nh: every node above stage Nr has md
  * children, every parent from stage Nr on has one; uniform nx, nu) */
