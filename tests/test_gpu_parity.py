@@ -693,3 +693,24 @@ def test_persistent_path_line_search_corners(gpu, orc, make):
                 backtracked += ref["ls_total"] > ref["iter"]
     assert compared >= 30 and backtracked >= 10
     g.close()
+
+
+def test_mixed_batch_of_all_device_paths(gpu, orc):
+    """One batch call over members of every kind -- persistent (uniform, multistage), single-workgroup (small irregular, in LDS or
+    not), launch-per-level with the wide-block kernels -- in an order that interleaves them; default options."""
+    members = [("uniform", oracle_flat_from_lti(orc, P.linear_chain(2, 6, 6)), None),
+               ("pruned_a", P.pruned_chain_qp(seed=11).as_dict(), None),
+               ("irregular", P.irregular_clipping_qp().as_dict(), None),
+               ("multistage", oracle_flat_from_lti(orc, P.spring_mass()), P.spring_mass().lambda0),
+               ("wide", P.random_clipping_qp(nx=10, nu=4, md=3, levels=4).as_dict(), None),
+               ("pruned_b", P.pruned_chain_qp(seed=12).as_dict(), None),
+               ("thesis", P.thesis_example().as_dict(), None)]
+    ms = [gpu.TqGpu(f["nk"], f["nx"], f["nu"]).upload(f, l0) for _, f, l0 in members]
+    assert [m.path for m in ms] == [2, 0, 3, 2, 0, 0, 3]
+    for _ in range(2):
+        res = gpu.solve_batch(ms)
+    for (name, f, l0), m, r in zip(members, ms, res):
+        ref = orc.solve(f, lambda0=l0)
+        assert (r["status"], r["iter"], r["ls_total"]) == (ref["status"], ref["iter"], ref["ls_total"]), name
+        assert_solution_close(m.solution(), ref, 1e-8, keys=("x", "u", "lam"))
+        m.close()
