@@ -1,5 +1,8 @@
+"""Diagnostic: x0-eliminated trees (the form every MPC caller solves) on the persistent path, incl. the heavy-backtracking spring-mass case."""
 import sys, time
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / 'tests'))
 import numpy as np
 from treeqp_amd import capi, problems as P
 from helpers import product_qp_from_lti
