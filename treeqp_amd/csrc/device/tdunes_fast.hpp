@@ -56,12 +56,22 @@ struct Uni {
     static_assert(R <= 64, "tall matrix must fit one wavefront");
     __device__ static __forceinline__ int kid0(int k) { return MD * k + 1; }
     __device__ static __forceinline__ int bo(int p) { return NX * (MD * p + 1); }      /* block vector offset */
-    __device__ static __forceinline__ int first(int level) {                            /* first node of a level */
+    /* first node / number of nodes of a level; closed forms where MD is a power of two (these sit in every level
+     * step of the persistent kernel: as loops they cost hundreds of scalar cycles per call) */
+    __device__ static __forceinline__ int width(int level) {
+        if (MD == 1) return 1;
+        if (MD == 2) return 1 << level;
+        if (MD == 4) return 1 << (2 * level);
+        int w = 1; for (int l = 0; l < level; l++) w *= MD; return w;
+    }
+    __device__ static __forceinline__ int first(int level) {
+        if (MD == 1) return level;
+        if (MD == 2) return (1 << level) - 1;
+        if (MD == 4) return ((1 << (2 * level)) - 1) / 3;
         int n = 0, w = 1;
         for (int l = 0; l < level; l++) { n += w; w *= MD; }
         return n;
     }
-    __device__ static __forceinline__ int width(int level) { int w = 1; for (int l = 0; l < level; l++) w *= MD; return w; }
 };
 
 __device__ __forceinline__ double rdlane(double v, int lane) {

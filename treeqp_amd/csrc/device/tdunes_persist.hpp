@@ -195,6 +195,10 @@ template <int NX, int NU, int MD>
 __device__ __forceinline__ int p_slot_node(int q, int l0, int s, const PConst &C) {
     using U = Uni<NX, NU, MD>;
     if (MD == 1) return C.nB + (l0 - C.Nr + q) * C.S + s;        /* chain part: slot = level offset, s = scenario */
+    if (MD == 2) {                                                /* heap slot q sits on level t = floor(log2(q + 1)) of the subtree */
+        const int t = 31 - __clz(q + 1);
+        return ((1 << (l0 + t)) - 1) + (s << t) + (q + 1 - (1 << t));
+    }
     int t = 0;
     while (q >= U::first(t + 1)) t++;
     return U::first(l0 + t) + s * U::width(t) + (q - U::first(t));
