@@ -714,3 +714,15 @@ def test_mixed_batch_of_all_device_paths(gpu, orc):
         assert (r["status"], r["iter"], r["ls_total"]) == (ref["status"], ref["iter"], ref["ls_total"]), name
         assert_solution_close(m.solution(), ref, 1e-8, keys=("x", "u", "lam"))
         m.close()
+
+
+def test_baseline_configs_take_their_intended_device_path(gpu):
+    """C1 (multistage), C2, C3 (two workgroups per CU must fit: 293 workgroups) -> one persistent launch; guards against a
+    register / LDS regression silently sending C3 back to one launch per tier."""
+    for p in (P.spring_mass(), P.linear_chain(2, 9, 9), P.linear_chain(2, 11, 11)):
+        nk = p.nk()
+        nx = np.full(p.Nn, p.nx, dtype=np.int32)
+        nu = np.where(nk > 0, p.nu, 0).astype(np.int32)
+        g = gpu.TqGpu(nk, nx, nu)
+        assert g.path == 2, p.name
+        g.close()

@@ -1111,7 +1111,7 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
 }
 
 template <int NX, int NU, int MD>
-__global__ void __launch_bounds__(FW * WAVE) f_persist(PConst C, Opts O, PGeom Gm, PSync Sy, int prologue) {
+__global__ void __launch_bounds__(FW * WAVE, 2) f_persist(PConst C, Opts O, PGeom Gm, PSync Sy, int prologue) {
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     const int wg = Gm.wg_of_block[blockIdx.x];
     int tier = 0;
