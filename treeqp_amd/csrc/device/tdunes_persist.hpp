@@ -1125,7 +1125,7 @@ __global__ void __launch_bounds__(FW * WAVE, 2) f_persist(PConst C, Opts O, PGeo
  * chain workgroup spreads G + H and the stage sweep over its four waves; its backward / forward sweeps are one
  * wave walking down the chain, which is what a chain is. */
 template <int NX, int NU, int MD>
-__global__ void __launch_bounds__(FW * WAVE) f_mpersist(PConst C, Opts O, PGeom Gm, PSync Sy, int prologue) {
+__global__ void __launch_bounds__(FW * WAVE, 2) f_mpersist(PConst C, Opts O, PGeom Gm, PSync Sy, int prologue) {
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     const int wg = Gm.wg_of_block[blockIdx.x];
     int tier = 0;
