@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batched", action="store_true", help="skip the batched-throughput leg (profiling runs: only the timed launches in the kernel statistics)")
     ap.add_argument("--mode", choices=["batch", "shard"], default="batch", help="N > 1: independent trees (weak) or one sharded tree (strong)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--trees", type=int, default=1, help="independent trees per GPU solved by one batched call per step (throughput mode; default 1 = the latency metric)")
@@ -223,7 +224,7 @@ def main():
                          "algorithmic_bytes_per_iteration": bytes_it, "algorithmic_flops_per_iteration": flops_it,
                          "note": "latency-bound: a chain of dependent 25x16 block factorisations per tree level; the solve's state is LDS-resident, so memory traffic is far below the algorithmic bytes"},
         }
-        if world == 1 and args.trees == 1 and g.path == 2:
+        if world == 1 and args.trees == 1 and g.path == 2 and not args.no_batched:
             # throughput leg (reported beside the latency metric, never as `value`): independent trees of the same
             # workload solved by one batched call per step -- what a scenario sweep (fault_tolerance.c:486-530) gets
             nb = 3
