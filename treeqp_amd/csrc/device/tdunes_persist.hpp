@@ -374,6 +374,23 @@ __device__ __forceinline__ void p_factor_rows(Ctrl *ctrl, const Opts &O, int lan
     }
 }
 
+/* the same without the saved copy of the block (32 registers across the factorisation): the first pass only; when it
+ * reports a small pivot under ON_THE_FLY regularisation the caller reloads the rows (rare) and calls p_refactor_rows */
+template <int NX, int NU, int MD>
+__device__ __forceinline__ bool p_factor_rows_first(const Opts &O, int lane, double (&T)[Uni<NX, NU, MD>::D]) {
+    constexpr int D = Uni<NX, NU, MD>::D;
+    if (O.regType == 1) ShiftDiag<0, D>::run(T, T, O.regValue);                    /* ddiare (ALWAYS) */
+    const double pmin = p_potrf_rows<D>(T, lane);
+    return O.regType == 2 && pmin <= O.regTol * O.regTol;                          /* sqrt(pivot) <= regTol, incl. non-positive pivots */
+}
+template <int NX, int NU, int MD>
+__device__ __forceinline__ void p_refactor_rows(Ctrl *ctrl, const Opts &O, int lane, double (&T)[Uni<NX, NU, MD>::D]) {
+    constexpr int D = Uni<NX, NU, MD>::D;
+    ShiftDiag<0, D>::run(T, T, O.regValue);
+    (void)p_potrf_rows<D>(T, lane);
+    if (lane == 0) atomicAdd(&ctrl->n_reg, 1);
+}
+
 template <int NX, int NU, int MD>
 __device__ __forceinline__ void p_load_rows(PLds<NX, NU, MD> &L, int loc, int lane, bool is_root, double (&T)[Uni<NX, NU, MD>::D]) {
     using U = Uni<NX, NU, MD>;
@@ -919,14 +936,20 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
                     const int loc = U::first(t) + wave, ii = p_slot_node<NX, NU, MD>(loc, l0, s, C);
                     const bool is_root = is_top && t == 0;
                     bool ok = true;
-                    p_load_rows<NX, NU, MD>(L, loc, lane, is_root, Tc);
-                    if (t < th - 1) sub_children<NX, NU, MD>((lds_cptr)(L.sch + (U::first(t + 1) + MD * wave) * U::SCH), lane, Tc);
-                    else if (!is_bottom) {
-                        ok = p_sub_children_tagged<NX, NU, MD>(Sy, Sy.sch + (size_t)kid0g<MD>(ii, C) * U::SCH * 2, tag_e, lane, Tc);
-                        ok = __all(ok);
-                        if (!ok && lane == 0) *L.abort = p_abort_code(Sy);
+                    auto assemble = [&]() {                           /* the block's rows minus the children's Schur records */
+                        p_load_rows<NX, NU, MD>(L, loc, lane, is_root, Tc);
+                        if (t < th - 1) sub_children<NX, NU, MD>((lds_cptr)(L.sch + (U::first(t + 1) + MD * wave) * U::SCH), lane, Tc);
+                        else if (!is_bottom) {
+                            ok = p_sub_children_tagged<NX, NU, MD>(Sy, Sy.sch + (size_t)kid0g<MD>(ii, C) * U::SCH * 2, tag_e, lane, Tc);
+                            ok = __all(ok);
+                            if (!ok && lane == 0) *L.abort = p_abort_code(Sy);
+                        }
+                    };
+                    assemble();
+                    if (p_factor_rows_first<NX, NU, MD>(O, lane, Tc)) {
+                        assemble();                                   /* rare: shift and refactorise (the rows are still in LDS) */
+                        p_refactor_rows<NX, NU, MD>(c, O, lane, Tc);
                     }
-                    p_factor_rows<NX, NU, MD>(c, O, lane, Tc);
                     if (!is_root) {
                         p_store_factor<NX, NU, MD>(L, loc, lane, Tc);
                         if (t == 0) { if (ok) p_schur<NX, NU, MD, true>(L, loc, lane, L.sch, Sy.sch + (size_t)ii * U::SCH * 2, tag_e); }
