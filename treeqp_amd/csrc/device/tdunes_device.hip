@@ -792,6 +792,7 @@ struct tqgpu_solver {
     void *pconst_slab = nullptr;    /* packed constants of the persistent path + its PDump */
     int *wg_map = nullptr;          /* blockIdx.x -> workgroup id (XCD-aware placement) */
     int co_capacity = 1;            /* workgroups of persistent launches that can be resident on the device together */
+    int n_cu = 0;
     bool gpersist_ok = false;       /* small tree of any shape: whole solve in one launch of one workgroup (tdunes_gpersist.hpp) */
     int use_gpersist = 1;
     int *d_lvl_first = nullptr;
@@ -1285,6 +1286,7 @@ int setup_persist(tqgpu_solver *s, int device) {
     const int capacity = per_cu <= 1 ? prop.multiProcessorCount * per_cu : prop.multiProcessorCount * per_cu - prop.multiProcessorCount / 2;
     if (getenv("TREEQP_AMD_VERBOSE")) fprintf(stderr, "[treeqp_amd] persistent path: %d workgroups, %d per CU possible, capacity %d\n", G.G, per_cu, capacity);
     s->co_capacity = std::max(1, capacity);
+    s->n_cu = prop.multiProcessorCount;
     if (per_cu < 1 || G.G > capacity) return TQGPU_OK;
     /* hand-over buffers (tagged 64-bit words, see tdunes_persist.hpp); zeroed once, never reset */
     const int nx0 = s->nx[0];
@@ -2070,7 +2072,9 @@ extern "C" int tqgpu_solve_batch(tqgpu_solver **solvers, int n, const tqgpu_opts
             const bool gp_like = !persist_like && uses_gpersist(s, true) && !o->profile && o->maxIter > 0;
             /* single-workgroup mirrors do not wait for each other: any number per launch; launch-per-level mirrors go alone */
             const int need = persist_like ? s->geom.G : (gp_like ? 0 : s->co_capacity + 1);
-            if (j > i && (s->device != dev || used + need > s->co_capacity)) break;
+            /* two workgroups on one CU run at half speed each: a batch fills the CUs once, not twice, unless a member needs more */
+            const int cap = (s->n_cu > 0 && need <= s->n_cu) ? std::min(s->co_capacity, s->n_cu) : s->co_capacity;
+            if (j > i && (s->device != dev || used + need > cap)) break;
             used += need;
         }
         const int begun_from = i, begun_to = j;
