@@ -171,13 +171,17 @@ struct PLds {
     static constexpr int D = U::D, NBT = U::NBT, NZ = U::NZ;
     static constexpr int SLOTS = NBT + (MD == 2 ? 8 : MD * MD);      /* nodes a workgroup can own: its blocks' owners + (bottom tier) the leaves */
     static constexpr int NODE = 4 * NZ;                              /* per owned node: [x | u], clipped inverse Hessian, unclipped [x | u], modified gradient */
-    static constexpr int DOUBLES = NBT * (D * D + NX * D + 4 * D) + NBT * U::SCH + NBT * D + SLOTS * NODE + 2 * NBT * D + 3 * NX + 4 * FW + FW * U::WAVE_LDS + 32 + 64;
+    /* leading dimensions of a block's W / L (D columns) and Ut / CholUt (D columns of NX entries) in LDS: odd, so that lanes
+     * walking a row (the forward sweep reads COLUMN `lane` of L and of CholUt) hit different banks -- with D = 16 (NX = 8)
+     * as the stride those were 16-way (4-way) conflicts on every one of the 24 loads of a forward step */
+    static constexpr int LDWB = D + 1, LDU = NX + 1;
+    static constexpr int DOUBLES = NBT * (D * LDWB + LDU * D + 4 * D) + NBT * U::SCH + NBT * D + SLOTS * NODE + 2 * NBT * D + 3 * NX + 4 * FW + FW * U::WAVE_LDS + 32 + 64;
     /* scratch of the top workgroup's reductions: the Schur record storage, free before the backward sweep */
     static constexpr int RED_CAP = NBT * U::SCH / 2;
     lds_ptr W, Ut, res, y, inv, dl, sch, node, lamb, lamroot, droot, part, wave0, wave, bat;     /* bat: 64 doubles, reductions of a batch of trials */
     lds_iptr flag, abort;                                            /* abort: a poll gave up (launch over), leave at the next uniform point */
     __device__ PLds(double *base, int wave_id) {
-        W = to_lds(base); Ut = W + NBT * D * D; res = Ut + NBT * NX * D; y = res + NBT * D; inv = y + NBT * D;
+        W = to_lds(base); Ut = W + NBT * D * LDWB; res = Ut + NBT * LDU * D; y = res + NBT * D; inv = y + NBT * D;
         dl = inv + NBT * D; sch = dl + NBT * D; node = sch + NBT * U::SCH; lamb = node + SLOTS * NODE;
         lamroot = lamb + 2 * NBT * D; droot = lamroot + 2 * NX; part = droot + NX; wave0 = part + 4 * FW; wave = wave0 + wave_id * U::WAVE_LDS;
         flag = (lds_iptr)(wave0 + FW * U::WAVE_LDS); abort = flag + 1; bat = wave0 + FW * U::WAVE_LDS + 32;
@@ -263,14 +267,15 @@ __device__ __forceinline__ double p_gh_compute(PLds<NX, NU, MD> &L, int loc, int
     const bool live = row < D;
     f64x4 acc = {0.0, 0.0, 0.0, 0.0};
     double part = 0.0;
-    lds_ptr Ut = L.Ut + loc * NX * D;
+    constexpr int LDWB = PLds<NX, NU, MD>::LDWB, LDU = PLds<NX, NU, MD>::LDU;
+    lds_ptr Ut = L.Ut + loc * LDU * D;
 #pragma unroll
     for (int s = 0; s < U::KS; s++) {
         const int cc = g + 4 * s;
         const double ap = G.a[s] * G.pc[s];
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(G.a[s], ap, acc, 0, 0, 0);
         part = fma(G.a[s], G.z[s], part);
-        if (live && cc < NX) Ut[cc + row * NX] = -1.0 * ap;
+        if (live && cc < NX) Ut[cc + row * LDU] = -1.0 * ap;
     }
     part = rows_fold<false>(part);
     double e = 0.0;
@@ -279,14 +284,14 @@ __device__ __forceinline__ double p_gh_compute(PLds<NX, NU, MD> &L, int loc, int
         L.res[loc * D + row] = rv;
         e = (termCondition == 2) ? fabs(rv) : rv * rv;
     }
-    lds_ptr W = L.W + loc * D * D;
+    lds_ptr W = L.W + loc * D * LDWB;
 #pragma unroll
     for (int rr = 0; rr < 4; rr++) {
         const int i = g + 4 * rr;
         if (live && i < D) {
             double w = acc[rr];
             if (i == row) w += G.qk;
-            W[i + row * D] = w;
+            W[i + row * LDWB] = w;
         }
     }
     return (termCondition == 2) ? wmax(e) : wsum(e);
@@ -396,10 +401,11 @@ __device__ __forceinline__ void p_load_rows(PLds<NX, NU, MD> &L, int loc, int la
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D, R = U::R;
     lds_cptr src; int stride;
-    if (lane < D) { src = L.W + loc * D * D + lane; stride = D; }
+    constexpr int LDWB = PLds<NX, NU, MD>::LDWB, LDU = PLds<NX, NU, MD>::LDU;
+    if (lane < D) { src = L.W + loc * D * LDWB + lane; stride = LDWB; }
     else if (lane == D) { src = L.res + loc * D; stride = 1; }
-    else if (lane < R && !is_root) { src = L.Ut + loc * NX * D + (lane - D - 1); stride = NX; }
-    else { src = L.W + loc * D * D; stride = D; }
+    else if (lane < R && !is_root) { src = L.Ut + loc * LDU * D + (lane - D - 1); stride = LDU; }
+    else { src = L.W + loc * D * LDWB; stride = LDWB; }
 #pragma unroll
     for (int j = 0; j < D; j++) T[j] = src[j * stride];
 }
@@ -411,9 +417,10 @@ __device__ __forceinline__ void p_store_factor(PLds<NX, NU, MD> &L, int loc, int
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D, R = U::R;
     lds_ptr dst; int stride;
-    if (lane < D) { dst = L.W + loc * D * D + lane; stride = D; }
+    constexpr int LDWB = PLds<NX, NU, MD>::LDWB, LDU = PLds<NX, NU, MD>::LDU;
+    if (lane < D) { dst = L.W + loc * D * LDWB + lane; stride = LDWB; }
     else if (lane == D) { dst = L.y + loc * D; stride = 1; }
-    else { dst = L.Ut + loc * NX * D + (lane - D - 1); stride = NX; }
+    else { dst = L.Ut + loc * LDU * D + (lane - D - 1); stride = LDU; }
     if (lane < R) {
 #pragma unroll
         for (int j = 0; j < D; j++) dst[j * stride] = T[j];
@@ -430,8 +437,9 @@ __device__ __forceinline__ void p_schur(PLds<NX, NU, MD> &L, int loc, int lane, 
     lds_fence();
     const int i = lane & 15, g = lane >> 4;
     /* per-lane base + stride, all loads issued before the first MFMA */
-    lds_cptr src = (i < NX) ? L.Ut + loc * NX * D + i + g * NX : L.y + loc * D + g;
-    const int stp = (i < NX) ? 4 * NX : 4;
+    constexpr int LDU = PLds<NX, NU, MD>::LDU;
+    lds_cptr src = (i < NX) ? L.Ut + loc * LDU * D + i + g * LDU : L.y + loc * D + g;
+    const int stp = (i < NX) ? 4 * LDU : 4;
     double m[D / 4];
 #pragma unroll
     for (int st = 0; st < D / 4; st++) m[st] = src[st * stp];
@@ -461,8 +469,9 @@ __device__ __forceinline__ double p_forward(const PSync &Sy, PLds<NX, NU, MD> &L
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D;
     const int li = lane < D ? lane : 0;
-    lds_cptr Lc = L.W + loc * D * D + li * D;
-    lds_cptr Cc = L.Ut + loc * NX * D + li * NX;
+    constexpr int LDWB = PLds<NX, NU, MD>::LDWB, LDU = PLds<NX, NU, MD>::LDU;
+    lds_cptr Lc = L.W + loc * D * LDWB + li * LDWB;
+    lds_cptr Cc = L.Ut + loc * LDU * D + li * LDU;
     double dv[NX];
     bool ok = true;
     if (from_parent) {
