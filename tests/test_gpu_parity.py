@@ -726,3 +726,36 @@ def test_baseline_configs_take_their_intended_device_path(gpu):
         g = gpu.TqGpu(nk, nx, nu)
         assert g.path == 2, p.name
         g.close()
+
+
+RANDOM_SHAPES = [  # (seed, depth, max_kids, nx range, nu range)
+    (1, 3, 3, (1, 4), (1, 3)), (2, 4, 2, (2, 6), (1, 2)), (3, 3, 5, (1, 3), (1, 2)),          # small blocks; parents with five children
+    (4, 3, 3, (4, 12), (1, 4)), (5, 2, 6, (3, 9), (2, 5)), (6, 3, 4, (6, 14), (1, 6)),        # blocks of 17..56 rows: the wide kernels, mixed sizes
+    (7, 4, 3, (2, 9), (1, 3)), (8, 5, 2, (5, 11), (2, 4)),
+]
+
+
+@pytest.mark.parametrize("seed,depth,kids,nxr,nur", RANDOM_SHAPES, ids=[f"seed{c[0]}_d{c[1]}_k{c[2]}_nx{c[3][1]}" for c in RANDOM_SHAPES])
+def test_random_tree_shapes_with_per_node_dimensions(gpu, orc, seed, depth, kids, nxr, nur):
+    """Trees of random shape with per-node nx / nu (the class of the irregular probe, scaled up): wave-per-block or workgroup-per-
+    block kernels by block size, single-workgroup kernel when small; iteration counts and solution against the oracle."""
+    f = P.random_shape_qp(seed, depth, kids, nxr, nur)
+    ref = orc.solve(f.as_dict())
+    assert ref["status"] == 0
+    for path in ("auto", "generic"):
+        r, sol, _ = _solve_flat_tq(gpu, f.as_dict(), None, path)
+        assert (r["status"], r["iter"], r["ls_total"]) == (0, ref["iter"], ref["ls_total"]), path
+        assert_solution_close(sol, ref, 1e-8, keys=("x", "u", "lam"))
+        assert orc.max_kkt(f.as_dict(), sol) < 1e-8
+
+
+def test_batch_of_random_tree_shapes(gpu, orc):
+    """All the random shapes above as ONE batched call (single-workgroup members share a launch, the others follow)."""
+    fs = [P.random_shape_qp(*c) for c in RANDOM_SHAPES]
+    ms = [gpu.TqGpu(f.nk, f.nx, f.nu).upload(f.as_dict(), None) for f in fs]
+    res = gpu.solve_batch(ms)
+    for f, m, r in zip(fs, ms, res):
+        ref = orc.solve(f.as_dict())
+        assert (r["status"], r["iter"], r["ls_total"]) == (0, ref["iter"], ref["ls_total"]), f.name
+        assert_solution_close(m.solution(), ref, 1e-8, keys=("x", "u", "lam"))
+        m.close()

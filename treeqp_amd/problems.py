@@ -321,6 +321,37 @@ def irregular_clipping_qp(seed: int = 3) -> FlatProblem:
         xmin=xmin, xmax=xmax, umin=-0.3 * np.ones(su), umax=0.3 * np.ones(su))
 
 
+def random_shape_qp(seed: int, depth: int = 3, max_kids: int = 3, nx_range=(1, 4), nu_range=(1, 3), ubound: float = 0.3) -> FlatProblem:
+    """Random tree SHAPE (every non-leaf has 1..max_kids children, all leaves at `depth`) with per-node nx / nu drawn from the
+    given ranges (inclusive) and seeded random data: the shape class of the irregular probe of SURVEY section 8c, scaled up so
+    that blocks of any dimension (and parents with more than four children) occur."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    nk, width = [], 1
+    for _ in range(depth):
+        counts = [int(rng.integers(1, max_kids + 1)) for _ in range(width)]
+        nk += counts
+        width = sum(counts)
+    nk += [0] * width
+    nk = np.asarray(nk, dtype=np.int32)
+    Nn = len(nk)
+    dad = parents_of(nk)
+    nx = rng.integers(nx_range[0], nx_range[1] + 1, size=Nn).astype(np.int32)
+    nu = np.where(nk > 0, rng.integers(nu_range[0], nu_range[1] + 1, size=Nn), 0).astype(np.int32)
+    A = np.concatenate([(1.2 / max(1, nx[dad[k]])) * rng.random(nx[k] * nx[dad[k]]) for k in range(1, Nn)])
+    B = np.concatenate([rng.random(nx[k] * nu[dad[k]]) for k in range(1, Nn)])
+    b = 0.1 * rng.random(int(nx[1:].sum()))
+    sx, su = int(nx.sum()), int(nu.sum())
+    xmin = -INF * np.ones(sx)
+    xmax = INF * np.ones(sx)
+    x0 = rng.random(nx[0])
+    xmin[:nx[0]] = x0
+    xmax[:nx[0]] = x0
+    return FlatProblem(
+        name=f"random_shape_qp(seed={seed},depth={depth},max_kids={max_kids},nx={nx_range},nu={nu_range})", nk=nk, nx=nx, nu=nu, A=A, B=B, b=b,
+        Qd=1.0 + 9.0 * rng.random(sx), Rd=0.5 + rng.random(su), q=rng.random(sx) - 0.5, r=rng.random(su) - 0.5,
+        xmin=xmin, xmax=xmax, umin=-ubound * np.ones(su), umax=ubound * np.ones(su))
+
+
 def thesis_example() -> FlatProblem:
     """The 6-node tree of examples/thesis_example.c:52-92 (values typed from the example's setters)."""
     nk = np.asarray([2, 2, 1, 0, 0, 0], dtype=np.int32)
