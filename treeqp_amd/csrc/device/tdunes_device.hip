@@ -837,7 +837,7 @@ struct tqgpu_solver {
     PGeom geom{};
     PSync psync{};
     PConst pconst{};
-    void *sync_slab = nullptr;
+    void *sync_slab = nullptr; size_t sync_bytes = 0;
     int *d_desc = nullptr;
     GItem *d_gitems = nullptr, *h_gitems = nullptr; int gitems_cap = 0;   /* batched single-workgroup launches (first mirror of a batch owns the array) */
     hipEvent_t batch_ev = nullptr;
@@ -1296,6 +1296,7 @@ int setup_persist(tqgpu_solver *s, int device) {
     const size_t bytes = (n_sch + n_dlt + n_ndt + n_parts + n_errs + 32 + n_bparts) * sizeof(unsigned long long);
     HIP_TRY(hipMalloc(&s->sync_slab, bytes));
     HIP_TRY(hipMemset(s->sync_slab, 0, bytes));
+    s->sync_bytes = bytes;
     unsigned long long *w = static_cast<unsigned long long *>(s->sync_slab);
     s->psync.sch = w; s->psync.dlt = w + n_sch; s->psync.ndt = s->psync.dlt + n_dlt; s->psync.parts = s->psync.ndt + n_ndt;
     s->psync.errs = s->psync.parts + n_parts;
@@ -1356,7 +1357,12 @@ int setup_persist(tqgpu_solver *s, int device) {
 int launch_persist(tqgpu_solver *s, const Opts &O, int &launches, int prologue) {
     const Data &D = s->D; hipStream_t st = s->stream;
     s->launch_no = (s->launch_no + 1) & 0xFFFFu;
-    if (s->launch_no == 0) s->launch_no = 1;
+    if (s->launch_no == 0) {
+        /* the 16-bit launch number wraps: words that are not rewritten by every launch (the line-search command / verdict /
+         * batch partials) could still carry a tag of 65535 launches ago -- wipe the hand-over buffers (stream-ordered) */
+        s->launch_no = 1;
+        HIP_TRY(hipMemsetAsync(s->sync_slab, 0, s->sync_bytes, st));
+    }
     s->psync.seq = s->launch_no << 16;
     if (s->need_pack) {
         const int n = std::max(s->Nn * 16, (s->Nn - 1) * s->nx[0] * (s->nx[0] + s->nu[0]));
