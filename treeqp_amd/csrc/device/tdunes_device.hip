@@ -1328,6 +1328,10 @@ int setup_persist(tqgpu_solver *s, int device) {
         for (int x = 0; x < NXCD; x++) for (size_t k = next[x]; k < want[x].size(); k++) rest.push_back(want[x][k]);
         size_t r = 0;
         for (int b = 0; b < Gn; b++) if (map[b] < 0) map[b] = rest[r++];
+        /* more workgroups than CUs (two per CU): the workgroups dispatched last share a CU with an earlier one.  Let those be
+         * the UPPER tiers -- they work while the bottom tier waits and vice versa -- instead of two bottom-tier subtrees
+         * halving each other on the critical path: plain tier order (bottom tier first). */
+        if (Gn > prop.multiProcessorCount) for (int b = 0; b < Gn; b++) map[b] = b;
         HIP_TRY(hipMalloc(&s->wg_map, sizeof(int) * (size_t)Gn));
         HIP_TRY(hipMemcpy(s->wg_map, map.data(), sizeof(int) * (size_t)Gn, hipMemcpyHostToDevice));
         G.wg_of_block = s->wg_map;
