@@ -1,5 +1,6 @@
 """Diagnostic: in-kernel phase stamps of the fused kernels (workgroup 0) on the GPU box.
-Usage: TREEQP_AMD_STAMPS=1 python tools/stamps.py [Nr]"""
+Needs a library built with the stamps compiled in: TQ_DEFS=-DTQ_STAMPS python treeqp_amd/build.py --force
+Usage: TREEQP_AMD_STAMPS=2 python tools/stamps.py [Nr]"""
 import ctypes as C
 import os
 import sys

@@ -625,6 +625,9 @@ struct PGeom {
 
 /* diagnostic stamps of the persistent kernel: first workgroup of every tier, thread 0, iteration O.stamps of the launch */
 __device__ __forceinline__ void pstamp(const PConst &C, const Opts &O, unsigned e, int tier, int s, int slot) {
+#ifndef TQ_STAMPS      /* diagnostic builds only (TQ_DEFS=-DTQ_STAMPS python treeqp_amd/build.py): even the never-taken stamp branches cost ~0.2 us each, 6 us per C2 solve */
+    return;
+#endif
     if (O.stamps == (int)e && threadIdx.x == 0 && s == 0 && slot < 32 && tier < 8) {
         unsigned long long *st = C.dump->stamps;
         st[(tier * 32 + slot) * 2 + 0] = clock64();
