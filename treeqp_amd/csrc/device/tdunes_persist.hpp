@@ -130,12 +130,9 @@ struct PollGuard {
         h = __hip_atomic_load(Sy.halt, RLX, AGENT); tmo = __hip_atomic_load(Sy.timeout, RLX, AGENT);
         cm = (unsigned)(__hip_atomic_load(Sy.cmd + 1, RLX, AGENT) >> 32);
     }
-    /* t0: wall clock of the first failed attempt (0 = none yet): a poll that finds its data at once never reads the clock */
-    __device__ __forceinline__ bool go_on(const PSync &Sy, u64 &t0) const {
+    __device__ __forceinline__ bool go_on(const PSync &Sy, u64 t0) const {
         if (h == Sy.seq || tmo || cm == Sy.trip) return false;
-        const u64 now = wall_clock64();
-        if (t0 == 0) t0 = now;
-        if (now - t0 > 50000000ull) { __hip_atomic_store(Sy.timeout, 1u, RLX, AGENT); return false; }   /* 0.5 s at 100 MHz */
+        if (wall_clock64() - t0 > 50000000ull) { __hip_atomic_store(Sy.timeout, 1u, RLX, AGENT); return false; }   /* 0.5 s at 100 MHz */
         return true;
     }
 };
@@ -246,7 +243,7 @@ __device__ __forceinline__ void p_gh_load(const PConst &C, const PSync &Sy, cons
         /* staged by the child workgroup in this launch: poll its tagged copy */
         const u64 *src = Sy.ndt + ((size_t)k * 2 * NX + r) * 2;
         const unsigned tag = Sy.seq | ns;
-        u64 t0 = 0;
+        const u64 t0 = wall_clock64();
         bool ok;
         for (;;) {
             PollGuard pg;
@@ -479,7 +476,7 @@ __device__ __forceinline__ double p_forward(const PSync &Sy, PLds<NX, NU, MD> &L
     bool ok = true;
     if (from_parent) {
         const u64 *src = Sy.dlt + (size_t)NX * ii * 2;
-        u64 t0 = 0;
+        const u64 t0 = wall_clock64();
         for (;;) {
             PollGuard pg;
             ok = true;
@@ -649,7 +646,7 @@ __device__ __forceinline__ bool p_sub_children_tagged(const PSync &Sy, const u64
     const int r = lane < D ? lane - lc * NX : 0;
     const int off = vrow ? NX * NX : r, stride = vrow ? 1 : NX;
     double v[MD][NX];
-    u64 t0 = 0;
+    const u64 t0 = wall_clock64();
     bool ok;
     for (;;) {
         PollGuard pg;
@@ -707,7 +704,7 @@ __device__ __forceinline__ bool p_gather3(const PSync &Sy, PLds<NX, NU, MD> &L, 
         double f = 0.0, d = 0.0, er = 0.0;
         if (w < count) {
             const u64 *pp = Sy.parts + (size_t)w * 4, *pe = Sy.errs + (size_t)w * 2;
-            u64 t0 = 0;
+            const u64 t0 = wall_clock64();
             bool ok;
             for (;;) {
                 PollGuard pg;
