@@ -759,3 +759,25 @@ def test_batch_of_random_tree_shapes(gpu, orc):
         assert (r["status"], r["iter"], r["ls_total"]) == (0, ref["iter"], ref["ls_total"]), f.name
         assert_solution_close(m.solution(), ref, 1e-8, keys=("x", "u", "lam"))
         m.close()
+
+
+RANDOM_UNIFORM = [(1, 8, 3, 2, 5, 5), (2, 8, 3, 2, 3, 7), (3, 4, 1, 3, 3, 3), (4, 4, 1, 3, 2, 6), (5, 4, 2, 4, 2, 4), (6, 6, 2, 2, 4, 4),
+                  (7, 2, 1, 2, 6, 6), (8, 8, 4, 2, 4, 4), (9, 4, 3, 2, 3, 9), (10, 8, 1, 2, 6, 6), (11, 2, 2, 2, 5, 5), (12, 2, 1, 4, 3, 3)]
+
+
+@pytest.mark.parametrize("seed,nx,nu,md,Nr,Nh", RANDOM_UNIFORM, ids=[f"seed{c[0]}_{c[1]}_{c[2]}_{c[3]}_r{c[4]}_h{c[5]}" for c in RANDOM_UNIFORM])
+def test_persistent_path_on_random_time_varying_data(gpu, orc, seed, nx, nu, md, Nr, Nh):
+    """Uniform / multistage shapes with per-edge / per-node random data (no LTI structure): every one needs 4 .. 14 Newton
+    iterations with backtracking in most of them -- the whole solve, batched line search included, in one launch."""
+    f = P.random_uniform_tree_qp(seed, nx, nu, md, Nr, Nh)
+    ref = orc.solve(f.as_dict())
+    assert ref["status"] == 0 and ref["ls_total"] > ref["iter"]
+    g = gpu.TqGpu(f.nk, f.nx, f.nu).upload(f.as_dict(), None)
+    assert g.path == 2
+    for _ in range(2):                                                   # the second solve relaunches on warm hand-over buffers
+        r = g.solve()
+        assert (r["status"], r["iter"], r["ls_total"]) == (0, ref["iter"], ref["ls_total"])
+    sol = g.solution()
+    assert_solution_close(sol, ref, 1e-8, keys=("x", "u", "lam"))
+    assert orc.max_kkt(f.as_dict(), sol) < 1e-8
+    g.close()

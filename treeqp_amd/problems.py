@@ -352,6 +352,31 @@ def random_shape_qp(seed: int, depth: int = 3, max_kids: int = 3, nx_range=(1, 4
         xmin=xmin, xmax=xmax, umin=-ubound * np.ones(su), umax=ubound * np.ones(su))
 
 
+def random_uniform_tree_qp(seed: int, nx: int, nu: int, md: int, Nr: int, Nh: int, ubound: float = 0.4, xbound: float = 3.0) -> FlatProblem:
+    """Uniform / multistage tree shape (setup_multistage_tree(md, Nr, Nh)) with every edge and node carrying its OWN random
+    data (time- and scenario-varying A, B, b, diagonal weights, linear terms, bounds): the shapes the persistent path takes,
+    without the structure of the LTI models (same matrices per realization) the other fixtures have."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    nk = multistage_nk(md, Nr, Nh)
+    Nn = len(nk)
+    Np = int((nk > 0).sum())
+    nxv = np.full(Nn, nx, dtype=np.int32)
+    nuv = np.where(nk > 0, nu, 0).astype(np.int32)
+    A = (1.1 / nx) * rng.random((Nn - 1, nx * nx)) + np.tile((0.4 * np.eye(nx)).reshape(-1, order="F"), (Nn - 1, 1))
+    B = rng.random((Nn - 1, nx * nu)) - 0.3
+    b = 0.05 * (rng.random((Nn - 1, nx)) - 0.5)
+    x0 = rng.random(nx) - 0.5
+    xmin = -xbound * (0.5 + rng.random(Nn * nx))
+    xmax = xbound * (0.5 + rng.random(Nn * nx))
+    xmin[:nx] = x0
+    xmax[:nx] = x0
+    return FlatProblem(
+        name=f"random_uniform_tree_qp(seed={seed},nx={nx},nu={nu},md={md},Nr={Nr},Nh={Nh})", nk=nk, nx=nxv, nu=nuv,
+        A=A.ravel(), B=B.ravel(), b=b.ravel(), Qd=0.5 + 9.5 * rng.random(Nn * nx), Rd=0.2 + 2.0 * rng.random(Np * nu),
+        q=rng.random(Nn * nx) - 0.5, r=rng.random(Np * nu) - 0.5, xmin=xmin, xmax=xmax,
+        umin=-ubound * (0.5 + rng.random(Np * nu)), umax=ubound * (0.5 + rng.random(Np * nu)))
+
+
 def thesis_example() -> FlatProblem:
     """The 6-node tree of examples/thesis_example.c:52-92 (values typed from the example's setters)."""
     nk = np.asarray([2, 2, 1, 0, 0, 0], dtype=np.int32)
