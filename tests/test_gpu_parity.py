@@ -781,3 +781,21 @@ def test_persistent_path_on_random_time_varying_data(gpu, orc, seed, nx, nu, md,
     assert_solution_close(sol, ref, 1e-8, keys=("x", "u", "lam"))
     assert orc.max_kkt(f.as_dict(), sol) < 1e-8
     g.close()
+
+
+EDGE_SHAPES = [("one_block_2", lambda: P.linear_chain(2, 1, 1)), ("one_level_then_chain", lambda: P.linear_chain(2, 1, 2)), ("chains_only_9", lambda: P.linear_chain(2, 1, 9)),
+               ("two_levels", lambda: P.linear_chain(2, 2, 2)), ("one_block_3", lambda: P.spring_mass(md=3, Nr=1, Nh=1)), ("md3_then_chain", lambda: P.spring_mass(md=3, Nr=1, Nh=2)),
+               ("one_block_4", lambda: P.linear_chain(4, 1, 1, nm=2)), ("chains_of_17", lambda: P.linear_chain(2, 3, 20)), ("chains_of_28", lambda: P.spring_mass(md=3, Nr=2, Nh=30))]
+
+
+@pytest.mark.parametrize("name,make", EDGE_SHAPES, ids=[c[0] for c in EDGE_SHAPES])
+def test_smallest_and_longest_shapes(gpu, orc, name, make):
+    """One block, one level, chains only, chains of several stacked chain tiers: whatever path the shape takes."""
+    p = make()
+    flat = oracle_flat_from_lti(orc, p)
+    ref = orc.solve(flat, lambda0=p.lambda0)
+    g = gpu.TqGpu(flat["nk"], flat["nx"], flat["nu"]).upload(flat, p.lambda0)
+    r = g.solve()
+    assert (r["status"], r["iter"], r["ls_total"]) == (ref["status"], ref["iter"], ref["ls_total"])
+    assert_solution_close(g.solution(), ref, 1e-9, keys=("x", "u", "lam"))
+    g.close()
