@@ -112,3 +112,27 @@ def test_openmp_threads_do_not_change_results(orc):
     b = orc.solve(qp, orc.default_opts(num_threads=4), p.lambda0)
     for k in ("x", "u", "lam"):
         assert np.array_equal(a[k], b[k])
+
+
+def test_random_fixture_families_are_well_posed(orc):
+    """The seeded random families the GPU parity tests draw from (random tree shapes with per-node dimensions, uniform /
+    multistage shapes with time-varying data, pruned scenario trees): the oracle converges on every member to a KKT point,
+    most of them with Armijo backtracking -- so a GPU mismatch on one of them is a device bug, not a fixture problem."""
+    from treeqp_amd import problems as P
+    import test_gpu_parity as G
+    backtracking = 0
+    for c in G.RANDOM_SHAPES:
+        f = P.random_shape_qp(*c)
+        ref = orc.solve(f.as_dict())
+        assert ref["status"] == 0 and orc.max_kkt(f.as_dict(), ref) < 1e-9, f.name
+        backtracking += ref["ls_total"] > ref["iter"]
+    for c in G.RANDOM_UNIFORM:
+        f = P.random_uniform_tree_qp(*c)
+        ref = orc.solve(f.as_dict())
+        assert ref["status"] == 0 and orc.max_kkt(f.as_dict(), ref) < 1e-9, f.name
+        backtracking += ref["ls_total"] > ref["iter"]
+    for seed in range(7, 13):
+        f = P.pruned_chain_qp(seed=seed)
+        ref = orc.solve(f.as_dict(), orc.default_opts(**f.opts), lambda0=f.lambda0)
+        assert ref["status"] == 0 and orc.max_kkt(f.as_dict(), ref) < 1e-8, f.name
+    assert backtracking >= 15
