@@ -1349,7 +1349,7 @@ int setup_persist(tqgpu_solver *s, int device) {
     hd.hres = s->h_res;
     PDump *dd = reinterpret_cast<PDump *>(pc + n_ab + n_cst);
     HIP_TRY(hipMemcpy(dd, &hd, sizeof(PDump), hipMemcpyHostToDevice));
-    s->pconst.AB = s->pab; s->pconst.b = D.b; s->pconst.cst = s->pcst; s->pconst.ctrl = D.ctrl; s->pconst.dump = dd; s->pconst.Np = s->Np;
+    s->pconst.AB = s->pab; s->pconst.b = D.b; s->pconst.cst = s->pcst; s->pconst.ctrl = D.ctrl; s->pconst.dump = dd; s->pconst.lam0_src = s->d_lam_init; s->pconst.Np = s->Np;
     s->pconst.S = s->mstage ? s->ms_S : 0; s->pconst.nB = s->mstage ? s->ms_nB : s->Np; s->pconst.Nr = s->mstage ? s->ms_Nr : s->Nh;
     s->need_pack = true;
     s->persist_ok = true;

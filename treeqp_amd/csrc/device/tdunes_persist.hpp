@@ -84,6 +84,7 @@ struct PConst {
     const double *cst;      /* [nodes][16][5]  {linear term, 1/weight, weight, lower, upper} of entry t of node k  */
     Ctrl *ctrl;
     const PDump *dump;
+    const double *lam0_src; /* starting duals of a fresh solve (= dump->lam_init): here so that the state load of the prologue needs no trip through `dump` first */
     int Np;                 /* number of parent nodes                                                              */
     /* multistage trees (setup_multistage_tree(md, Nr, Nh), Nr < Nh: branching for Nr stages, then one child per
      * node): the first nB nodes (levels < Nr) are numbered like a complete md-ary tree, below them every level
@@ -812,7 +813,7 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
     {
         const PDump *dp = C.dump;
         if (threadIdx.x == 0) *L.abort = 0;
-        const double *lsrc = prologue ? dp->lam_init : (cur ? dp->lam1 : dp->lam0);
+        const double *lsrc = prologue ? C.lam0_src : (cur ? dp->lam1 : dp->lam0);
         for (int i = threadIdx.x; i < nbt * D; i += FW * WAVE) {
             const int loc = i / D, t = i - loc * D;
             L.lamb_(cur, loc)[t] = lsrc[NX * kid0g<MD>(p_slot_node<NX, NU, MD>(loc, l0, s, C), C) + t];
