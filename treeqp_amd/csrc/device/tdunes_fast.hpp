@@ -93,6 +93,9 @@ __device__ __forceinline__ double pivot_rsqrt(double p) {
 /* diagnostic stamp: slot of kernel `kern`, workgroup 0 / thread 0 only; the buffer is never read
  * by any kernel */
 __device__ __forceinline__ void stamp(const Data &Dt, const Opts &O, int kern, int slot) {
+#ifndef TQ_STAMPS      /* diagnostic builds only, as in the persistent kernel: the never-taken branches are not free */
+    return;
+#endif
     if (O.stamps && threadIdx.x == 0 && blockIdx.x == 0 && slot < 32 && kern < 8) {
         Dt.stamps[(kern * 32 + slot) * 2 + 0] = clock64();
         Dt.stamps[(kern * 32 + slot) * 2 + 1] = wall_clock64();
