@@ -36,9 +36,33 @@ for kern in range(8):
     if kern == 7:
         print('fine stamps (cycles) load_rows / sub_children / factor / store_factor / schur:', [int(v) for v in np.diff(s[:6, 0])])
         continue
+    if s[20, 0] > 0 and s[24, 0] > 0:
+        print("   fine stamps of level t = 1, wave 0 (cycles, each includes one stamp): assemble / factor / store_factor / schur:", [int(v) for v in np.diff(s[20:25, 0])])
+        s = s.copy(); s[20:25] = 0
+        n = int((s[:20, 1] > 0).sum())
+    if s[31, 0] > 0:
+        print(f"   (cost of one stamp: {int(s[31, 0]) - int(s[0, 0])} cycles)")
+        s = s.copy(); s[31] = 0
+        n = int((s[:31, 1] > 0).sum())
     cyc = np.diff(s[:n, 0])
     wall = np.diff(s[:n, 1]) * 10.0          # 100 MHz -> ns
     print(name, "phases:", n - 1, f" starts at +{(int(s[0, 1]) - t_first) * 0.01:.2f} us")
     for i in range(n - 1):
         print(f"   {i:2d}: {wall[i] / 1e3:8.2f} us  {cyc[i]:8d} cycles  ({cyc[i] / max(wall[i], 1):.2f} GHz)")
     print(f"   total {wall.sum() / 1e3:.2f} us")
+# placement census of the persistent launch (TQ_STAMPS builds): workgroup -> (XCC, SE, CU)
+big = np.zeros(8 * 32 * 2 + 1024, dtype=np.uint64)
+capi.lib().tqgpu_get_stamps(g.h, big.ctypes.data_as(C.POINTER(C.c_ulonglong)), len(big))
+cen = big[8 * 32 * 2:]
+place = {}
+for wg_id, v in enumerate(cen):
+    v = int(v)
+    if v == 0:
+        continue
+    hw, xcc = v & 0xFFFFFFFF, (v >> 32) & 0xF
+    cu, sh, se = (hw >> 8) & 0xF, (hw >> 12) & 1, (hw >> 13) & 0x7
+    place.setdefault((xcc, se, sh, cu), []).append(wg_id)
+shared = {k: v for k, v in place.items() if len(v) > 1}
+print(f"placement: {sum(len(v) for v in place.values())} workgroups on {len(place)} distinct (xcc, se, sh, cu); shared CUs: {len(shared)}")
+for k, v in sorted(shared.items())[:40]:
+    print("   CU", k, "holds workgroups", v)

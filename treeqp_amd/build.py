@@ -55,6 +55,23 @@ def product_library() -> Path:
     return LIBDIR / "libtreeqp_amd.so"
 
 
+def build_variant(name: str, defs) -> Path:
+    """Experiment build: the device code with extra -D flags, linked with the current host objects into
+    treeqp_amd/lib_var/<name>/libtreeqp_amd.so (loaded when TREEQP_AMD_LIB points at it; never the default)."""
+    build_product()
+    out = ROOT / "treeqp_amd" / "lib_var" / name
+    out.mkdir(parents=True, exist_ok=True)
+    hipcc = hipcc_path()
+    objs = [OBJDIR / (n + ".o") for n in HOST_SOURCES]
+    for n in DEVICE_SOURCES:
+        obj = out / (n + ".o")
+        _run([hipcc, *HIP_FLAGS, *defs, f"-I{INCLUDE}", f"-I{CSRC / 'device'}", "-c", CSRC / "device" / n, "-o", obj])
+        objs.append(obj)
+    lib = out / "libtreeqp_amd.so"
+    _run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", *objs, "-o", lib, "-lm"])
+    return lib
+
+
 def build_product(force: bool = False) -> Path:
     LIBDIR.mkdir(parents=True, exist_ok=True)
     OBJDIR.mkdir(parents=True, exist_ok=True)
@@ -142,5 +159,9 @@ def build_all(force: bool = False):
 
 
 if __name__ == "__main__":
+    if "--variant" in sys.argv:          # python treeqp_amd/build.py --variant NAME -DFOO -DBAR=1
+        i = sys.argv.index("--variant")
+        print("[build] variant:", build_variant(sys.argv[i + 1], sys.argv[i + 2:]))
+        sys.exit(0)
     out = build_all(force="--force" in sys.argv)
     print("[build] done:", *out[:2], *out[2])

@@ -13,6 +13,7 @@ raises ``RuntimeError`` (the C function would print the HIP error and ``exit(1)`
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 import numpy as np
@@ -111,7 +112,9 @@ _SIZEOF_CHECK = [(0, Dmat), (1, Dvec), (2, Node), (3, QpIn), (4, QpOut), (5, Tdu
 
 
 def library_path() -> Path:
-    return _ROOT / "lib" / "libtreeqp_amd.so"
+    # TREEQP_AMD_LIB: an experiment build of the same library (treeqp_amd/build.py --variant), for A/B timing runs
+    override = os.environ.get("TREEQP_AMD_LIB")
+    return Path(override) if override else _ROOT / "lib" / "libtreeqp_amd.so"
 
 
 def lib():

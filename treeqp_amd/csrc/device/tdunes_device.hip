@@ -959,8 +959,12 @@ int allow_lds(K kernel, size_t bytes) {
 
 /* (NX, NU, MD) instantiations of the fused path */
 /* instantiated (index, nx, nu, md): nx * md <= 16 and a multiple of 4, nx + nu <= 16 */
+#ifdef TQ_SMALL_TABLE   /* experiment builds (tools/variants.sh): only the BASELINE shapes, a fifth of the compile time */
+#define FAST_TABLE(X) X(0, 8, 3, 2) X(2, 4, 1, 3)
+#else
 #define FAST_TABLE(X) X(0, 8, 3, 2) X(1, 4, 1, 2) X(2, 4, 1, 3) X(3, 2, 1, 2) X(4, 8, 2, 2) X(5, 6, 2, 2) X(6, 4, 1, 4) \
     X(7, 8, 1, 2) X(8, 8, 4, 2) X(9, 4, 2, 2) X(10, 4, 3, 2) X(11, 4, 2, 3) X(12, 4, 2, 4) X(13, 6, 1, 2) X(14, 6, 3, 2) X(15, 2, 1, 4) X(16, 2, 2, 2)
+#endif
 
 int fast_index(int NX, int NU, int MD) {
 #define X(idx, nx, nu, md) if (NX == nx && NU == nu && MD == md) return idx;
@@ -978,8 +982,12 @@ void fast_geometry(int idx, int &TH, size_t &tier_lds, size_t &stage_lds) {
 /* (NX, NU, MD) instantiations of the multistage persistent kernel: the chain part works on blocks of NX rows,
  * which the MFMA Schur tile wants to be a multiple of 4 */
 /* multistage trees: the chain part's MFMA tile needs nx % 4 == 0 */
+#ifdef TQ_SMALL_TABLE
+#define MSTAGE_TABLE(X) X(0, 8, 3, 2) X(2, 4, 1, 3)
+#else
 #define MSTAGE_TABLE(X) X(0, 8, 3, 2) X(1, 4, 1, 2) X(2, 4, 1, 3) X(4, 8, 2, 2) X(6, 4, 1, 4) \
     X(7, 8, 1, 2) X(8, 8, 4, 2) X(9, 4, 2, 2) X(10, 4, 3, 2) X(11, 4, 2, 3) X(12, 4, 2, 4)
+#endif
 
 /* multistage tree?  (setup_multistage_tree(md, Nr, Nh) with 1 <= Nr < Nh: every node above stage Nr has md
  * children, every parent from stage Nr on has one; uniform nx, nu) */
@@ -1279,6 +1287,15 @@ int setup_persist(tqgpu_solver *s, int device) {
             default: break;
         }
     }
+    if (const char *e = getenv("TREEQP_AMD_LDS_PAD")) {      /* experiment: force fewer workgroups per CU */
+        s->lds_persist += (size_t)atoi(e) * 1024;
+        switch (s->fast) {
+#define X(idx, nx, nu, md) case idx: if (!s->mstage) { allow_lds(f_persist<nx, nu, md>, s->lds_persist); HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f_persist<nx, nu, md>, FW * WAVE, s->lds_persist)); } break;
+            FAST_TABLE(X)
+#undef X
+            default: break;
+        }
+    }
     /* every workgroup must be resident at once (they wait for each other); keep one block per CU of
      * margin against the occupancy query over-reporting (MI355X guide, "Residency and cooperative launch") */
     /* one workgroup per CU needs no margin (the figure is exact when registers allow a single 4-wave workgroup);
@@ -1501,7 +1518,7 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
     for (int k = 0; k < Nn; k++) s->poff[k + 1] = s->poff[k] + (s->nx[k] + s->nu[k]) * (s->nx[k] + s->nu[k]);
     const size_t o_poff = cv.take((Nn + 1) * I), o_Hd = cv.take((size_t)std::max(s->poff[Nn], 1) * Dbl), o_Pd = cv.take((size_t)std::max(s->poff[Nn], 1) * Dbl);
     const size_t o_ctrl = cv.take(sizeof(Ctrl));
-    const size_t o_stamps = cv.take(8 * 32 * 2 * sizeof(unsigned long long));
+    const size_t o_stamps = cv.take((8 * 32 * 2 + 1024) * sizeof(unsigned long long));   /* + 1024: placement census of the persistent launch (diagnostic builds) */
     s->ls_log_cap = 4096;
     const size_t o_log = cv.take(s->ls_log_cap * I);
     s->slab_bytes = cv.off + 256;
@@ -1676,7 +1693,7 @@ extern "C" int tqgpu_uses_fused_path(const tqgpu_solver *s) {
  * {shader clock, 100 MHz wall clock}); only filled when TREEQP_AMD_STAMPS is set */
 extern "C" int tqgpu_get_stamps(tqgpu_solver *s, unsigned long long *out, int cap) {
     if (!s || !out) return fail(TQGPU_EINVAL, "bad arguments");
-    const int n = std::min(cap, 8 * 32 * 2);
+    const int n = std::min(cap, 8 * 32 * 2 + 1024);
     HIP_TRY(hipMemcpy(out, s->D.stamps, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToHost));
     return TQGPU_OK;
 }

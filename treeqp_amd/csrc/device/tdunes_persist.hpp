@@ -176,16 +176,23 @@ struct PLds {
      * walking a row (the forward sweep reads COLUMN `lane` of L and of CholUt) hit different banks -- with D = 16 (NX = 8)
      * as the stride those were 16-way (4-way) conflicts on every one of the 24 loads of a forward step */
     static constexpr int LDWB = D + 1, LDU = NX + 1;
-    static constexpr int DOUBLES = NBT * (D * LDWB + LDU * D + 4 * D) + NBT * U::SCH + NBT * D + SLOTS * NODE + 2 * NBT * D + 3 * NX + 4 * FW + FW * U::WAVE_LDS + 32 + 64;
+    /* rows of the tall matrix a wave factorises: [W ; res' ; Ut ; I] -- the identity rows come out as the columns of L^-1 */
+    static constexpr int RI = U::R + D;
+    static_assert(RI <= 64, "tall matrix with the identity rows must fit one wavefront");
+    static constexpr int LDI = D + 1;                                 /* L^-1 of a block: entry (k, i) at k * LDI + i */
+    static constexpr int DOUBLES = NBT * (D * LDWB + LDU * D + 4 * D) + NBT * U::SCH + NBT * D + SLOTS * NODE + 2 * NBT * D + 3 * NX + 4 * FW + FW * U::WAVE_LDS + 32 + 64
+                                   + NBT * D * LDI + 2 * D;
     /* scratch of the top workgroup's reductions: the Schur record storage, free before the backward sweep */
     static constexpr int RED_CAP = NBT * U::SCH / 2;
     lds_ptr W, Ut, res, y, inv, dl, sch, node, lamb, lamroot, droot, part, wave0, wave, bat;     /* bat: 64 doubles, reductions of a batch of trials */
+    lds_ptr Li, iden;                                                /* L^-1 per block; iden[j] = (j == D - 1): rows of the identity as shifted views */
     lds_iptr flag, abort;                                            /* abort: a poll gave up (launch over), leave at the next uniform point */
     __device__ PLds(double *base, int wave_id) {
         W = to_lds(base); Ut = W + NBT * D * LDWB; res = Ut + NBT * LDU * D; y = res + NBT * D; inv = y + NBT * D;
         dl = inv + NBT * D; sch = dl + NBT * D; node = sch + NBT * U::SCH; lamb = node + SLOTS * NODE;
         lamroot = lamb + 2 * NBT * D; droot = lamroot + 2 * NX; part = droot + NX; wave0 = part + 4 * FW; wave = wave0 + wave_id * U::WAVE_LDS;
         flag = (lds_iptr)(wave0 + FW * U::WAVE_LDS); abort = flag + 1; bat = wave0 + FW * U::WAVE_LDS + 32;
+        Li = bat + 64; iden = Li + NBT * D * LDI;
     }
     /* part[4 w + i]: wave w's partials -- 0 termination norm, 1 res' * dlam, 2 dual function value */
     /* owned node `q` (heap order inside the tier subtree): entry t < NZ of [x | u] at +t, of the clipped
@@ -406,6 +413,7 @@ __device__ __forceinline__ void p_load_rows(PLds<NX, NU, MD> &L, int loc, int la
     if (lane < D) { src = L.W + loc * D * LDWB + lane; stride = LDWB; }
     else if (lane == D) { src = L.res + loc * D; stride = 1; }
     else if (lane < R && !is_root) { src = L.Ut + loc * LDU * D + (lane - D - 1); stride = LDU; }
+    else if (lane >= R && lane < R + D) { src = L.iden + (D - 1) - (lane - R); stride = 1; }      /* row lane - R of the identity */
     else { src = L.W + loc * D * LDWB; stride = LDWB; }
 #pragma unroll
     for (int j = 0; j < D; j++) T[j] = src[j * stride];
@@ -419,10 +427,12 @@ __device__ __forceinline__ void p_store_factor(PLds<NX, NU, MD> &L, int loc, int
     constexpr int D = U::D, R = U::R;
     lds_ptr dst; int stride;
     constexpr int LDWB = PLds<NX, NU, MD>::LDWB, LDU = PLds<NX, NU, MD>::LDU;
+    constexpr int LDI = PLds<NX, NU, MD>::LDI;
     if (lane < D) { dst = L.W + loc * D * LDWB + lane; stride = LDWB; }
     else if (lane == D) { dst = L.y + loc * D; stride = 1; }
-    else { dst = L.Ut + loc * LDU * D + (lane - D - 1); stride = LDU; }
-    if (lane < R) {
+    else if (lane < R) { dst = L.Ut + loc * LDU * D + (lane - D - 1); stride = LDU; }
+    else { dst = L.Li + loc * D * LDI + (lane - R); stride = LDI; }      /* lane R + i holds column i of L^-1: entry (k, i) at k * LDI + i */
+    if (lane < R + D) {
 #pragma unroll
         for (int j = 0; j < D; j++) dst[j * stride] = T[j];
     }
@@ -460,7 +470,44 @@ __device__ __forceinline__ void p_schur(PLds<NX, NU, MD> &L, int loc, int lane, 
     }
 }
 
-/* forward step of block `loc` from LDS; the solution stays in LDS (dl).
+/* Forward preparation of block `loc` (calculate_delta_lambda :756-775 restated): the forward step of a block is
+ *     dlam = L^-T (y - CholUt' delta),      delta = the NX entries of the parent block's solution that belong to the owner node,
+ * a D-step substitution chain that can only start once delta is known.  Split it: z0 = L^-T y and M = L^-T CholUt' do not
+ * depend on delta, so they are computed here, OFF the critical path (by waves that are idle during the upper levels of the
+ * backward sweep, or while the workgroup waits for its parent), and the forward step shrinks to dlam = z0 - M delta: NX
+ * fused multiply-adds.  L^-1 costs nothing: the factorisation carries D identity rows below the tall matrix (lanes that
+ * were idle), which come out as the columns of L^-1.  [M | z0] = (L^-1)' [CholUt' | y] is one f64 MFMA tile (K = D), operands
+ * straight from LDS; z0 replaces y and M replaces CholUt (same places, same layout). */
+template <int NX, int NU, int MD>
+__device__ __forceinline__ void p_prep_forward(const PLds<NX, NU, MD> &L, int loc, int lane) {
+    using U = Uni<NX, NU, MD>;
+    constexpr int D = U::D;
+    constexpr int LDU = PLds<NX, NU, MD>::LDU, LDI = PLds<NX, NU, MD>::LDI;
+    const int i = lane & 15, g = lane >> 4;
+    /* A[i][k] = Linv[k][i] (lane (i, g): k = g + 4 st);  B[k][j] = CholUt[j][k] (j < NX) or y[k] (j == NX) */
+    lds_cptr asrc = L.Li + loc * D * LDI + (i < D ? i : 0) + g * LDI;
+    lds_cptr bsrc = (i < NX) ? L.Ut + loc * LDU * D + i + g * LDU : L.y + loc * D + g;
+    const int bstp = (i < NX) ? 4 * LDU : 4;
+    double a[D / 4], b[D / 4];
+#pragma unroll
+    for (int st = 0; st < D / 4; st++) { a[st] = asrc[st * 4 * LDI]; b[st] = bsrc[st * bstp]; }
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int st = 0; st < D / 4; st++)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(i < D ? a[st] : 0.0, i <= NX ? b[st] : 0.0, acc, 0, 0, 0);
+    lds_fence();                                  /* every operand is in registers before the results overwrite CholUt / y */
+    lds_ptr Mdst = L.Ut + loc * LDU * D;
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+        const int row = g + 4 * rr;               /* acc[rr] = [M | z0][row][i] */
+        if (row < D) {
+            if (i < NX) Mdst[row * LDU + i] = acc[rr];
+            else if (i == NX) L.y[loc * D + row] = acc[rr];
+        }
+    }
+}
+
+/* forward step of block `loc` from LDS (prepared by p_prep_forward): dlam = z0 - M delta; the solution stays in LDS (dl).
  * from_parent: the block is my subtree root, the step of its owner node's duals comes from the parent
  * workgroup (tagged words, polled).  to_children: the block's children are tier subtree roots of the
  * tier below: they get a tagged copy of the solution.  ii: global block (= owner node), bo: offset of its duals. */
@@ -470,9 +517,12 @@ __device__ __forceinline__ double p_forward(const PSync &Sy, PLds<NX, NU, MD> &L
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D;
     const int li = lane < D ? lane : 0;
-    constexpr int LDWB = PLds<NX, NU, MD>::LDWB, LDU = PLds<NX, NU, MD>::LDU;
-    lds_cptr Lc = L.W + loc * D * LDWB + li * LDWB;
-    lds_cptr Cc = L.Ut + loc * LDU * D + li * LDU;
+    constexpr int LDU = PLds<NX, NU, MD>::LDU;
+    lds_cptr Mr = L.Ut + loc * LDU * D + li * LDU;       /* row li of M */
+    double mv[NX];
+#pragma unroll
+    for (int r = 0; r < NX; r++) mv[r] = Mr[r];
+    const double z0 = L.y[loc * D + li], rv = L.res[loc * D + li];
     double dv[NX];
     bool ok = true;
     if (from_parent) {
@@ -498,25 +548,13 @@ __device__ __forceinline__ double p_forward(const PSync &Sy, PLds<NX, NU, MD> &L
     }
     double acc0 = 0.0, acc1 = 0.0;                       /* two chains: half the dependent latency */
 #pragma unroll
-    for (int r = 0; r < NX; r += 2) { acc0 = fma(Cc[r], dv[r], acc0); if (r + 1 < NX) acc1 = fma(Cc[r + 1], dv[r + 1], acc1); }
-    double s = fma(-1.0, acc0 + acc1, L.y[loc * D + li]);
-    const double inv = diag_inv(Lc[li]);
-    /* column li of L below the diagonal, zero on and above it: the substitution loop then needs no lane
-     * masks at all -- a lane whose entry is zero simply keeps its value, and lane k's value is final after step k */
-    double Lcol[D];
-#pragma unroll
-    for (int k = 0; k < D; k++) { const double v = Lc[k]; Lcol[k] = (k > li) ? v : 0.0; }
-#pragma unroll
-    for (int k = D - 1; k >= 1; k--) {
-        const double zk = rdlane(s * inv, k);
-        s = fma(-Lcol[k], zk, s);
-    }
-    const double mine = s * inv;
+    for (int r = 0; r < NX; r += 2) { acc0 = fma(mv[r], dv[r], acc0); if (r + 1 < NX) acc1 = fma(mv[r + 1], dv[r + 1], acc1); }
+    const double mine = fma(-1.0, acc0 + acc1, z0);
     double pd = 0.0;
     if (lane < D) {
         if (to_children && ok) st_tag(Sy.dlt + (size_t)(bo + lane) * 2, mine, tag);
         if (ok) L.dl[loc * D + lane] = mine;              /* a step computed from a failed poll must not replace the last good one (it is written back on leaving) */
-        pd = L.res[loc * D + lane] * mine;
+        pd = rv * mine;
     }
     return pd;                                            /* per-lane term of res' * dlam: summed once per sweep */
 }
@@ -631,8 +669,9 @@ __device__ __forceinline__ void pstamp(const PConst &C, const Opts &O, unsigned 
 #endif
     if (O.stamps == (int)e && threadIdx.x == 0 && s == 0 && slot < 32 && tier < 8) {
         unsigned long long *st = C.dump->stamps;
-        st[(tier * 32 + slot) * 2 + 0] = clock64();
-        st[(tier * 32 + slot) * 2 + 1] = wall_clock64();
+        const unsigned long long ck = clock64();     /* the shader clock only: reading the 100 MHz wall clock takes ~1 us and would sit inside every phase */
+        st[(tier * 32 + slot) * 2 + 0] = ck;
+        st[(tier * 32 + slot) * 2 + 1] = ck / 24;    /* nominal 2.4 GHz in 100 MHz ticks */
     }
 }
 
@@ -793,6 +832,11 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
     const int nown = nbt + (is_bottom ? U::width(th) : 0);             /* nodes I own */
     const int root_blk = p_slot_node<NX, NU, MD>(0, l0, s, C);         /* subtree root block (= node) */
     const unsigned long long t_start = wall_clock64();
+#ifdef TQ_STAMPS
+    /* placement census: which XCD / SE / CU this workgroup landed on (HW_REG_HW_ID = 4, HW_REG_XCC_ID = 20) */
+    if (threadIdx.x == 0 && wg < 1024)
+        C.dump->stamps[8 * 32 * 2 + wg] = ((unsigned long long)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 4);
+#endif
     int cur = 0;
     unsigned nd = 0u;          /* stage sweeps (= {fval, dot} reductions) of this launch so far */
     bool have_dl = false;      /* a forward sweep of this launch has filled the step of my blocks */
@@ -813,6 +857,7 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
     {
         const PDump *dp = C.dump;
         if (threadIdx.x == 0) *L.abort = 0;
+        if (threadIdx.x < 2 * D) L.iden[threadIdx.x] = (threadIdx.x == D - 1) ? 1.0 : 0.0;
         const double *lsrc = prologue ? C.lam0_src : (cur ? dp->lam1 : dp->lam0);
         for (int i = threadIdx.x; i < nbt * D; i += FW * WAVE) {
             const int loc = i / D, t = i - loc * D;
@@ -859,6 +904,9 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
 
         int sl = 0;
         pstamp(C, O, e, tier, s, sl++);                                   /* 0: iteration start */
+#ifdef TQ_STAMPS
+        pstamp(C, O, e, tier, s, 31);                                     /* slot 31 - slot 0 = cost of one stamp */
+#endif
         /* ---- G + H for my blocks (heap order inside the subtree), two blocks per wave in flight; the
          * children of my bottom-level blocks were staged by the child workgroups (polled) ---- */
         {
@@ -941,10 +989,20 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
         /* ---- backward sweep ---- */
         bool gone = false;
         double dotp = 0.0;                                /* per-lane terms of res' * dlam over my blocks */
+        int prep_next = nbt - 1;                          /* blocks >= prep_next + 1 have their forward step prepared (descending order) */
         if (verdict != 2) {
             double Tc[D];
             for (int t = th - 1; t >= 0; t--) {
                 const int nb = U::width(t);
+                /* waves without a block on this level prepare the forward steps of the levels below (at most two each) */
+                const int idle = FW - nb, lo = U::first(t + 1);
+                if (wave >= nb) {
+                    for (int r = 0; r < 2; r++) {
+                        const int loc = prep_next - (r * idle + (wave - nb));
+                        if (loc >= lo) p_prep_forward<NX, NU, MD>(L, loc, lane);
+                    }
+                }
+                { const int avail = prep_next - lo + 1, take = avail < 2 * idle ? avail : 2 * idle; prep_next -= take > 0 ? take : 0; }
                 if (wave < nb) {
                     const int loc = U::first(t) + wave, ii = p_slot_node<NX, NU, MD>(loc, l0, s, C);
                     const bool is_root = is_top && t == 0;
@@ -958,38 +1016,41 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
                             if (!ok && lane == 0) *L.abort = p_abort_code(Sy);
                         }
                     };
+#ifdef TQ_FINE_STAMPS      /* one interior level (t == 1) of the stamped workgroup: slots 20.. = start, rows assembled, factorised, stored, Schur record posted */
+#define FSTAMP(i) do { if (t == 1 && wave == 0) pstamp(C, O, e, tier, s, 20 + (i)); } while (0)
+#else
+#define FSTAMP(i) do { } while (0)
+#endif
+                    FSTAMP(0);
                     assemble();
+                    FSTAMP(1);
                     if (p_factor_rows_first<NX, NU, MD>(O, lane, Tc)) {
                         assemble();                                   /* rare: shift and refactorise (the rows are still in LDS) */
                         p_refactor_rows<NX, NU, MD>(c, O, lane, Tc);
                     }
+                    FSTAMP(2);
                     if (!is_root) {
                         p_store_factor<NX, NU, MD>(L, loc, lane, Tc);
+                        FSTAMP(3);
                         if (t == 0) { if (ok) p_schur<NX, NU, MD, true>(L, loc, lane, L.sch, Sy.sch + (size_t)ii * U::SCH * 2, tag_e); }
                         else p_schur<NX, NU, MD, false>(L, loc, lane, L.sch + loc * U::SCH, nullptr, 0u);
+                        FSTAMP(4);
                     } else {
-                        /* root: keep L and 1/diag, then dlam_0 = L^-T (L^-1 res) */
-                        if (lane <= D) {
+                        /* root: dlam_0 = L^-T (L^-1 res) = (L^-1)' y -- lane R + i holds column i of L^-1 (the identity rows of the
+                         * factorisation), lane D holds y: D independent multiply-adds per lane, no substitution chain */
+                        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
-                            for (int j = 0; j < D; j++) L.wave[lane * U::LDW + j] = Tc[j];
+                        for (int k = 0; k < D; k += 4) {
+                            a0 = fma(Tc[k], rdlane(Tc[k], D), a0);
+                            a1 = fma(Tc[k + 1], rdlane(Tc[k + 1], D), a1);
+                            a2 = fma(Tc[k + 2], rdlane(Tc[k + 2], D), a2);
+                            a3 = fma(Tc[k + 3], rdlane(Tc[k + 3], D), a3);
                         }
-                        lds_fence();
-                        const int lc = lane < D ? lane : 0;
-                        const double myinv = diag_inv(L.wave[lc * U::LDW + lc]);
-                        double sv = L.wave[D * U::LDW + lc], Lcol[D];
-#pragma unroll
-                        for (int k = 0; k < D; k++) Lcol[k] = L.wave[k * U::LDW + lc];
-#pragma unroll
-                        for (int k = 0; k < D; k++) Lcol[k] = (k > lc) ? Lcol[k] : 0.0;      /* strictly below the diagonal: no lane masks in the loop */
-#pragma unroll
-                        for (int k = D - 1; k >= 1; k--) {
-                            const double zk = rdlane(sv * myinv, k);
-                            sv = fma(-Lcol[k], zk, sv);
-                        }
-                        const double mine = sv * myinv;
-                        if (lane < D) {
-                            if (th == 1 && !is_bottom && ok) st_tag(Sy.dlt + (size_t)(NX * kid0g<MD>(0, C) + lane) * 2, mine, tag_e);
-                            L.dl[lane] = mine; dotp = L.res[lane] * mine;
+                        const double mine = (a0 + a1) + (a2 + a3);
+                        const int ri = lane - U::R;
+                        if (ri >= 0 && ri < D) {
+                            if (th == 1 && !is_bottom && ok) st_tag(Sy.dlt + (size_t)(NX * kid0g<MD>(0, C) + ri) * 2, mine, tag_e);
+                            L.dl[ri] = mine; dotp = L.res[ri] * mine;
                         }
                         lds_fence();
                     }
@@ -1001,6 +1062,11 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
         }
         if (gone) { if (*L.abort == 2) { verdict = 2; gone = false; } else break; }
         pstamp(C, O, e, tier, s, sl++);                                   /* backward done */
+        if (verdict != 2) {
+            /* what is left to prepare (the subtree root, which was factorised last; the root block of the tree needs none) */
+            for (int loc = prep_next - wave; loc >= (is_top ? 1 : 0); loc -= FW) p_prep_forward<NX, NU, MD>(L, loc, lane);
+            lds_barrier();
+        }
 
         /* ---- forward sweep (my subtree root first waits for the parent workgroup's step) ---- */
         for (int t = (is_top ? 1 : 0); t < th && verdict != 2; t++) {
@@ -1146,8 +1212,11 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
     }
 }
 
+#ifndef TQ_WPS
+#define TQ_WPS 2
+#endif
 template <int NX, int NU, int MD>
-__global__ void __launch_bounds__(FW * WAVE, 2) f_persist(PConst C, Opts O, PGeom Gm, PSync Sy, int prologue) {
+__global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_persist(PConst C, Opts O, PGeom Gm, PSync Sy, int prologue) {
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     const int wg = Gm.wg_of_block[blockIdx.x];
     int tier = 0;
@@ -1161,7 +1230,7 @@ __global__ void __launch_bounds__(FW * WAVE, 2) f_persist(PConst C, Opts O, PGeo
  * chain workgroup spreads G + H and the stage sweep over its four waves; its backward / forward sweeps are one
  * wave walking down the chain, which is what a chain is. */
 template <int NX, int NU, int MD>
-__global__ void __launch_bounds__(FW * WAVE, 2) f_mpersist(PConst C, Opts O, PGeom Gm, PSync Sy, int prologue) {
+__global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_mpersist(PConst C, Opts O, PGeom Gm, PSync Sy, int prologue) {
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     const int wg = Gm.wg_of_block[blockIdx.x];
     int tier = 0;
