@@ -131,6 +131,11 @@ struct PollGuard {
         h = __hip_atomic_load(Sy.halt, RLX, AGENT); tmo = __hip_atomic_load(Sy.timeout, RLX, AGENT);
         cm = (unsigned)(__hip_atomic_load(Sy.cmd + 1, RLX, AGENT) >> 32);
     }
+    /* call right after the poll loop: the three guard words are only looked at when the payload is not there yet, so on the
+     * usual exit their loads are still in flight as far as the compiler knows; it then waits for them -- with a vmcnt(0)
+     * that also waits for every STORE issued since (tagged hand-over stores take ~1 us to complete) -- at some later point
+     * where it wants their registers back.  Naming them here puts that wait where nothing else is pending. */
+    __device__ __forceinline__ void settle() const { asm volatile("" :: "v"(h), "v"(tmo), "v"(cm)); }
     __device__ __forceinline__ bool go_on(const PSync &Sy, u64 t0) const {
         if (h == Sy.seq || tmo || cm == Sy.trip) return false;
         if (wall_clock64() - t0 > 50000000ull) { __hip_atomic_store(Sy.timeout, 1u, RLX, AGENT); return false; }   /* 0.5 s at 100 MHz */
@@ -154,6 +159,7 @@ __device__ __forceinline__ bool p_read_top(const PSync &Sy, const u64 *src, unsi
 #pragma unroll
         for (int i = 0; i < N; i++) v[i] = ld_tag(src + 2 * i, tag, ok);
         const unsigned h = __hip_atomic_load(Sy.halt, RLX, AGENT), tmo = __hip_atomic_load(Sy.timeout, RLX, AGENT);
+        asm volatile("" :: "v"(h), "v"(tmo));            /* as PollGuard::settle */
         if (ok || h == Sy.seq || tmo) break;
         if (wall_clock64() - t0 > 50000000ull) { __hip_atomic_store(Sy.timeout, 1u, RLX, AGENT); break; }
     }
@@ -172,28 +178,30 @@ struct PLds {
     static constexpr int D = U::D, NBT = U::NBT, NZ = U::NZ;
     static constexpr int SLOTS = NBT + (MD == 2 ? 8 : MD * MD);      /* nodes a workgroup can own: its blocks' owners + (bottom tier) the leaves */
     static constexpr int NODE = 4 * NZ;                              /* per owned node: [x | u], clipped inverse Hessian, unclipped [x | u], modified gradient */
-    /* leading dimensions of a block's W / L (D columns) and Ut / CholUt (D columns of NX entries) in LDS: odd, so that lanes
-     * walking a row (the forward sweep reads COLUMN `lane` of L and of CholUt) hit different banks -- with D = 16 (NX = 8)
-     * as the stride those were 16-way (4-way) conflicts on every one of the 24 loads of a forward step */
-    static constexpr int LDWB = D + 1, LDU = NX + 1;
-    /* rows of the tall matrix a wave factorises: [W ; res' ; Ut ; I] -- the identity rows come out as the columns of L^-1 */
-    static constexpr int RI = U::R + D;
+    /* A block's tall matrix T = [W ; rhs' ; Ut] (R = D + 1 + NX rows, D columns) lives TRANSPOSED in one region: entry (q, j) at
+     * j * S + q.  The wave that factorises it holds row q in lane q, so its D loads (and later its D stores) differ only by
+     * an immediate offset j * S -- one address register, no per-lane stride; consecutive lanes touch consecutive doubles (no
+     * bank conflict) and S is odd, so that walking a row is conflict-free too.  The factorisation carries D identity rows
+     * below T (lanes R .. R + D - 1, read from the shared table `idt`): they come out as the columns of L^-1.  What the
+     * factorisation leaves -- y (lane D), CholUt (lanes D + 1 .. R - 1), L^-1 (lanes R ..) -- goes back IN PLACE, shifted by D
+     * lanes: entry (q', j) at j * S + q' with q' = lane - D (the rows of W are dead by then; L itself is never needed again). */
+    static constexpr int S = U::R;
+    static constexpr int RI = U::R + D;                              /* rows a wave factorises, identity rows included */
     static_assert(RI <= 64, "tall matrix with the identity rows must fit one wavefront");
-    static constexpr int LDI = D + 1;                                 /* L^-1 of a block: entry (k, i) at k * LDI + i */
-    static constexpr int DOUBLES = NBT * (D * LDWB + LDU * D + 4 * D) + NBT * U::SCH + NBT * D + SLOTS * NODE + 2 * NBT * D + 3 * NX + 4 * FW + FW * U::WAVE_LDS + 32 + 64
-                                   + NBT * D * LDI + 2 * D;
-    /* scratch of the top workgroup's reductions: the Schur record storage, free before the backward sweep */
-    static constexpr int RED_CAP = NBT * U::SCH / 2;
-    lds_ptr W, Ut, res, y, inv, dl, sch, node, lamb, lamroot, droot, part, wave0, wave, bat;     /* bat: 64 doubles, reductions of a batch of trials */
-    lds_ptr Li, iden;                                                /* L^-1 per block; iden[j] = (j == D - 1): rows of the identity as shifted views */
+    static_assert(1 + NX + D <= S, "the factor's output rows must fit the region they replace");
+    static constexpr int LDM = NX + 1;                               /* forward data of a block: row i = [z0_i | M_i0 .. M_i,NX-1] */
+    static constexpr int DOUBLES = NBT * D * S + D * S + NBT * D * LDM + 2 * NBT * D + 16 + SLOTS * NODE + 2 * NBT * D + 3 * NX + 4 * FW
+                                   + FW * U::WAVE_LDS + 32 + 64;
+    lds_ptr tt, idt, mz, res, dl, red, node, lamb, lamroot, droot, part, wave0, wave, bat;     /* red: reductions of the top workgroup; bat: 64 doubles, reductions of a batch of trials */
     lds_iptr flag, abort;                                            /* abort: a poll gave up (launch over), leave at the next uniform point */
     __device__ PLds(double *base, int wave_id) {
-        W = to_lds(base); Ut = W + NBT * D * LDWB; res = Ut + NBT * LDU * D; y = res + NBT * D; inv = y + NBT * D;
-        dl = inv + NBT * D; sch = dl + NBT * D; node = sch + NBT * U::SCH; lamb = node + SLOTS * NODE;
+        tt = to_lds(base); idt = tt + NBT * D * S; mz = idt + D * S; res = mz + NBT * D * LDM; dl = res + NBT * D; red = dl + NBT * D;
+        node = red + 16; lamb = node + SLOTS * NODE;
         lamroot = lamb + 2 * NBT * D; droot = lamroot + 2 * NX; part = droot + NX; wave0 = part + 4 * FW; wave = wave0 + wave_id * U::WAVE_LDS;
         flag = (lds_iptr)(wave0 + FW * U::WAVE_LDS); abort = flag + 1; bat = wave0 + FW * U::WAVE_LDS + 32;
-        Li = bat + 64; iden = Li + NBT * D * LDI;
     }
+    __device__ __forceinline__ lds_ptr tt_(int loc) const { return tt + loc * D * S; }
+    __device__ __forceinline__ lds_ptr mz_(int loc) const { return mz + loc * D * LDM; }
     /* part[4 w + i]: wave w's partials -- 0 termination norm, 1 res' * dlam, 2 dual function value */
     /* owned node `q` (heap order inside the tier subtree): entry t < NZ of [x | u] at +t, of the clipped
      * inverse Hessian at NZ + t, of the unclipped value at 2 NZ + t, of the modified gradient at 3 NZ + t */
@@ -258,7 +266,7 @@ __device__ __forceinline__ void p_gh_load(const PConst &C, const PSync &Sy, cons
             ok = true;
             xv = ld_tag(src, tag, ok); qv = ld_tag(src + 2 * NX, tag, ok);
             pg.load(Sy);
-            if (ok || !pg.go_on(Sy, t0)) break;
+            if (ok || !pg.go_on(Sy, t0)) { pg.settle(); break; }
         }
         if (!ok) *L.abort = p_abort_code(Sy);
     } else if (foreign) { const PDump *dp = C.dump; xv = dp->x[bo + rowc]; qv = dp->QinvCal[bo + rowc]; }   /* relaunch: staged by earlier kernels */
@@ -271,35 +279,35 @@ template <int NX, int NU, int MD>
 __device__ __forceinline__ double p_gh_compute(PLds<NX, NU, MD> &L, int loc, int lane, const GhRegs<NX, NU, MD> &G, int termCondition) {
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D;
+    constexpr int S = PLds<NX, NU, MD>::S;
     const int row = lane & 15, g = lane >> 4;
     const bool live = row < D;
     f64x4 acc = {0.0, 0.0, 0.0, 0.0};
     double part = 0.0;
-    constexpr int LDWB = PLds<NX, NU, MD>::LDWB, LDU = PLds<NX, NU, MD>::LDU;
-    lds_ptr Ut = L.Ut + loc * LDU * D;
+    lds_ptr Tt = L.tt_(loc) + row * S;                    /* column `row` of the tall matrix: W (symmetric) entries, rhs, Ut */
 #pragma unroll
     for (int s = 0; s < U::KS; s++) {
         const int cc = g + 4 * s;
         const double ap = G.a[s] * G.pc[s];
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(G.a[s], ap, acc, 0, 0, 0);
         part = fma(G.a[s], G.z[s], part);
-        if (live && cc < NX) Ut[cc + row * LDU] = -1.0 * ap;
+        if (live && cc < NX) Tt[D + 1 + cc] = -1.0 * ap;
     }
     part = rows_fold<false>(part);
     double e = 0.0;
     if (live && g == 0) {
         const double rv = fma(-1.0, G.xk, G.bk) + part;
-        L.res[loc * D + row] = rv;
+        L.res[loc * D + row] = rv;                        /* the gradient itself (res' * dlam); the copy in the tall matrix takes the children's updates */
+        Tt[D] = rv;
         e = (termCondition == 2) ? fabs(rv) : rv * rv;
     }
-    lds_ptr W = L.W + loc * D * LDWB;
 #pragma unroll
     for (int rr = 0; rr < 4; rr++) {
         const int i = g + 4 * rr;
         if (live && i < D) {
             double w = acc[rr];
             if (i == row) w += G.qk;
-            W[i + row * LDWB] = w;
+            Tt[i] = w;
         }
     }
     return (termCondition == 2) ? wmax(e) : wsum(e);
@@ -404,56 +412,54 @@ __device__ __forceinline__ void p_refactor_rows(Ctrl *ctrl, const Opts &O, int l
     if (lane == 0) atomicAdd(&ctrl->n_reg, 1);
 }
 
+/* rows of the tall matrix of block `loc`, identity rows below: ONE address per lane, D loads with immediate offsets */
 template <int NX, int NU, int MD>
-__device__ __forceinline__ void p_load_rows(PLds<NX, NU, MD> &L, int loc, int lane, bool is_root, double (&T)[Uni<NX, NU, MD>::D]) {
+__device__ __forceinline__ void p_load_rows(const PLds<NX, NU, MD> &L, int loc, int lane, double (&T)[Uni<NX, NU, MD>::D]) {
     using U = Uni<NX, NU, MD>;
-    constexpr int D = U::D, R = U::R;
-    lds_cptr src; int stride;
-    constexpr int LDWB = PLds<NX, NU, MD>::LDWB, LDU = PLds<NX, NU, MD>::LDU;
-    if (lane < D) { src = L.W + loc * D * LDWB + lane; stride = LDWB; }
-    else if (lane == D) { src = L.res + loc * D; stride = 1; }
-    else if (lane < R && !is_root) { src = L.Ut + loc * LDU * D + (lane - D - 1); stride = LDU; }
-    else if (lane >= R && lane < R + D) { src = L.iden + (D - 1) - (lane - R); stride = 1; }      /* row lane - R of the identity */
-    else { src = L.W + loc * D * LDWB; stride = LDWB; }
+    constexpr int D = U::D, R = U::R, S = PLds<NX, NU, MD>::S;
+    const int m = lane - R;
+    lds_cptr src = (lane < R) ? L.tt_(loc) + lane : L.idt + (m < D ? m : D);      /* lanes beyond the identity rows read a zero column */
 #pragma unroll
-    for (int j = 0; j < D; j++) T[j] = src[j * stride];
+    for (int j = 0; j < D; j++) T[j] = src[j * S];
 }
 
-/* factor data of block `loc` back into LDS with ONE store per column (per-lane base + stride):
- * L over W (lanes < D), y (lane D), CholUt over Ut (lanes D+1 .. R-1); 1/diag was stored by the factorisation */
+/* what the factorisation leaves, back into the block's region shifted by D lanes: y (lane D), CholUt (lanes D+1 .. R-1),
+ * the columns of L^-1 (lanes R .. R+D-1); the rows of L are not needed again */
 template <int NX, int NU, int MD>
-__device__ __forceinline__ void p_store_factor(PLds<NX, NU, MD> &L, int loc, int lane, const double (&T)[Uni<NX, NU, MD>::D]) {
+__device__ __forceinline__ void p_store_factor(const PLds<NX, NU, MD> &L, int loc, int lane, const double (&T)[Uni<NX, NU, MD>::D]) {
     using U = Uni<NX, NU, MD>;
-    constexpr int D = U::D, R = U::R;
-    lds_ptr dst; int stride;
-    constexpr int LDWB = PLds<NX, NU, MD>::LDWB, LDU = PLds<NX, NU, MD>::LDU;
-    constexpr int LDI = PLds<NX, NU, MD>::LDI;
-    if (lane < D) { dst = L.W + loc * D * LDWB + lane; stride = LDWB; }
-    else if (lane == D) { dst = L.y + loc * D; stride = 1; }
-    else if (lane < R) { dst = L.Ut + loc * LDU * D + (lane - D - 1); stride = LDU; }
-    else { dst = L.Li + loc * D * LDI + (lane - R); stride = LDI; }      /* lane R + i holds column i of L^-1: entry (k, i) at k * LDI + i */
-    if (lane < R + D) {
+    constexpr int D = U::D, R = U::R, S = PLds<NX, NU, MD>::S;
+    if (lane >= D && lane < R + D) {
+        lds_ptr dst = L.tt_(loc) + (lane - D);
 #pragma unroll
-        for (int j = 0; j < D; j++) dst[j * stride] = T[j];
+        for (int j = 0; j < D; j++) dst[j * S] = T[j];
     }
 }
 
-/* Schur record [S | v] = CUt * [CUt' | y] (one f64 MFMA tile, K = D) straight from the CholUt / y just
- * stored in LDS: lane (i, g) feeds CUt[i][g + 4 st] as A and the same (i < NX) or y (i == NX) as B.
- * GLOBAL: destination is the parent workgroup (tagged words), else an LDS record. */
+/* Schur record [S | v] = CUt * [CUt' | y] (one f64 MFMA tile, K = D) straight from the CholUt / y just stored:
+ * lane (i, g) feeds CUt[i][g + 4 st] as A and the same (i < NX) or y (i == NX) as B.
+ * GLOBAL: the parent is another workgroup: the record travels as tagged words.  Otherwise the parent block `ploc` is
+ * mine and the record is subtracted from its tall matrix in place (child number `cidx`: rows / columns cidx NX ..): the
+ * parent's wave then loads rows that already carry its children -- nothing to subtract on its critical path. */
 template <int NX, int NU, int MD, bool GLOBAL>
-__device__ __forceinline__ void p_schur(PLds<NX, NU, MD> &L, int loc, int lane, lds_ptr sdst_lds, u64 *sdst_glb, unsigned tag) {
+__device__ __forceinline__ void p_schur(const PLds<NX, NU, MD> &L, int loc, int lane, int ploc, int cidx, u64 *sdst_glb, unsigned tag) {
     using U = Uni<NX, NU, MD>;
-    constexpr int D = U::D;
+    constexpr int D = U::D, S = PLds<NX, NU, MD>::S;
     lds_fence();
     const int i = lane & 15, g = lane >> 4;
-    /* per-lane base + stride, all loads issued before the first MFMA */
-    constexpr int LDU = PLds<NX, NU, MD>::LDU;
-    lds_cptr src = (i < NX) ? L.Ut + loc * LDU * D + i + g * LDU : L.y + loc * D + g;
-    const int stp = (i < NX) ? 4 * LDU : 4;
+    lds_cptr src = L.tt_(loc) + g * S + ((i < NX) ? 1 + i : 0);
     double m[D / 4];
 #pragma unroll
-    for (int st = 0; st < D / 4; st++) m[st] = src[st * stp];
+    for (int st = 0; st < D / 4; st++) m[st] = src[st * 4 * S];
+    /* targets in the parent's tall matrix: S[ip][i] -> entry (row pos + ip, column pos + i); v[ip] -> rhs entry pos + ip */
+    const int pos = cidx * NX;
+    lds_ptr dst = L.tt_(GLOBAL ? 0 : ploc) + ((i < NX) ? (pos + i) * S + pos + g : (pos + g) * S + D);
+    const int dstp = (i < NX) ? 4 : 4 * S;
+    double old[4];
+    if (!GLOBAL) {
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) old[rr] = (g + 4 * rr < NX && i <= NX) ? dst[rr * dstp] : 0.0;
+    }
     f64x4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int st = 0; st < D / 4; st++) {
@@ -464,8 +470,8 @@ __device__ __forceinline__ void p_schur(PLds<NX, NU, MD> &L, int loc, int lane, 
     for (int rr = 0; rr < 4; rr++) {
         const int ip = g + 4 * rr;
         if (ip < NX && i <= NX) {
-            const int off = (i < NX) ? ip + i * NX : NX * NX + ip;
-            if (GLOBAL) st_tag(sdst_glb + 2 * off, acc[rr], tag); else sdst_lds[off] = acc[rr];
+            if (GLOBAL) { const int off = (i < NX) ? ip + i * NX : NX * NX + ip; st_tag(sdst_glb + 2 * off, acc[rr], tag); }
+            else dst[rr * dstp] = old[rr] - acc[rr];
         }
     }
 }
@@ -477,86 +483,99 @@ __device__ __forceinline__ void p_schur(PLds<NX, NU, MD> &L, int loc, int lane, 
  * backward sweep, or while the workgroup waits for its parent), and the forward step shrinks to dlam = z0 - M delta: NX
  * fused multiply-adds.  L^-1 costs nothing: the factorisation carries D identity rows below the tall matrix (lanes that
  * were idle), which come out as the columns of L^-1.  [M | z0] = (L^-1)' [CholUt' | y] is one f64 MFMA tile (K = D), operands
- * straight from LDS; z0 replaces y and M replaces CholUt (same places, same layout). */
+ * straight from LDS; the result goes to the block's forward record mz: row i = [z0_i | M_i0 .. ]. */
 template <int NX, int NU, int MD>
 __device__ __forceinline__ void p_prep_forward(const PLds<NX, NU, MD> &L, int loc, int lane) {
     using U = Uni<NX, NU, MD>;
-    constexpr int D = U::D;
-    constexpr int LDU = PLds<NX, NU, MD>::LDU, LDI = PLds<NX, NU, MD>::LDI;
+    constexpr int D = U::D, S = PLds<NX, NU, MD>::S, LDM = PLds<NX, NU, MD>::LDM;
     const int i = lane & 15, g = lane >> 4;
     /* A[i][k] = Linv[k][i] (lane (i, g): k = g + 4 st);  B[k][j] = CholUt[j][k] (j < NX) or y[k] (j == NX) */
-    lds_cptr asrc = L.Li + loc * D * LDI + (i < D ? i : 0) + g * LDI;
-    lds_cptr bsrc = (i < NX) ? L.Ut + loc * LDU * D + i + g * LDU : L.y + loc * D + g;
-    const int bstp = (i < NX) ? 4 * LDU : 4;
+    lds_cptr asrc = L.tt_(loc) + g * S + 1 + NX + (i < D ? i : 0);
+    lds_cptr bsrc = L.tt_(loc) + g * S + ((i < NX) ? 1 + i : 0);
     double a[D / 4], b[D / 4];
 #pragma unroll
-    for (int st = 0; st < D / 4; st++) { a[st] = asrc[st * 4 * LDI]; b[st] = bsrc[st * bstp]; }
+    for (int st = 0; st < D / 4; st++) { a[st] = asrc[st * 4 * S]; b[st] = bsrc[st * 4 * S]; }
     f64x4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int st = 0; st < D / 4; st++)
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(i < D ? a[st] : 0.0, i <= NX ? b[st] : 0.0, acc, 0, 0, 0);
-    lds_fence();                                  /* every operand is in registers before the results overwrite CholUt / y */
-    lds_ptr Mdst = L.Ut + loc * LDU * D;
+    lds_ptr dst = L.mz_(loc) + g * LDM + ((i < NX) ? 1 + i : 0);
 #pragma unroll
-    for (int rr = 0; rr < 4; rr++) {
-        const int row = g + 4 * rr;               /* acc[rr] = [M | z0][row][i] */
-        if (row < D) {
-            if (i < NX) Mdst[row * LDU + i] = acc[rr];
-            else if (i == NX) L.y[loc * D + row] = acc[rr];
-        }
-    }
+    for (int rr = 0; rr < 4; rr++)
+        if (g + 4 * rr < D && i <= NX) dst[rr * 4 * LDM] = acc[rr];          /* acc[rr] = [M | z0][row g + 4 rr][i] */
 }
 
-/* forward step of block `loc` from LDS (prepared by p_prep_forward): dlam = z0 - M delta; the solution stays in LDS (dl).
- * from_parent: the block is my subtree root, the step of its owner node's duals comes from the parent
- * workgroup (tagged words, polled).  to_children: the block's children are tier subtree roots of the
- * tier below: they get a tagged copy of the solution.  ii: global block (= owner node), bo: offset of its duals. */
+/* Forward sweep of a whole tier subtree without a barrier between its levels: wave w walks the path from the subtree root
+ * (level t0) to ITS block of the last level (number w there); the solution of a block stays in the wave's registers
+ * (entry i in lane i) and the NX entries the next block needs are read from it by v_readlane.  Blocks on several paths
+ * are computed by every wave that passes through them (a handful of multiply-adds) and stored / counted by one of them.
+ * from_parent: the step of the subtree root's owner node comes from the parent workgroup (tagged words, polled); otherwise
+ * (top workgroup, t0 = 1) the root block's solution is in L.dl already.  to_children: the last level's blocks hand their
+ * solution to the tier below as tagged words.  Returns the per-lane terms of res' * dlam of the blocks this wave owns. */
 template <int NX, int NU, int MD>
-__device__ __forceinline__ double p_forward(const PSync &Sy, PLds<NX, NU, MD> &L, int ii, int bo, int loc, int lane, lds_cptr delta_lds,
-                                            bool from_parent, bool to_children, unsigned tag) {
+__device__ __forceinline__ double p_forward_tier(const PConst &C, const PSync &Sy, const PLds<NX, NU, MD> &L, int l0, int s, int th, int t0, int wave, int lane,
+                                                 bool from_parent, bool to_children, unsigned tag) {
     using U = Uni<NX, NU, MD>;
-    constexpr int D = U::D;
+    constexpr int D = U::D, LDM = PLds<NX, NU, MD>::LDM;
     const int li = lane < D ? lane : 0;
-    constexpr int LDU = PLds<NX, NU, MD>::LDU;
-    lds_cptr Mr = L.Ut + loc * LDU * D + li * LDU;       /* row li of M */
-    double mv[NX];
-#pragma unroll
-    for (int r = 0; r < NX; r++) mv[r] = Mr[r];
-    const double z0 = L.y[loc * D + li], rv = L.res[loc * D + li];
+    const int wl = U::width(th - 1);                     /* blocks of the last level */
+    const bool active = wave < wl;
+    const int w = active ? wave : 0;
     double dv[NX];
     bool ok = true;
     if (from_parent) {
+        const int ii = p_slot_node<NX, NU, MD>(0, l0, s, C);
         const u64 *src = Sy.dlt + (size_t)NX * ii * 2;
-        const u64 t0 = wall_clock64();
+        const u64 t0c = wall_clock64();
         for (;;) {
             PollGuard pg;
             ok = true;
 #pragma unroll
             for (int r = 0; r < NX; r++) dv[r] = ld_tag(src + 2 * r, tag, ok);
             pg.load(Sy);
-            if (ok || !pg.go_on(Sy, t0)) break;
+            if (ok || !pg.go_on(Sy, t0c)) { pg.settle(); break; }
         }
         ok = __all(ok);
-        if (!ok) *L.abort = p_abort_code(Sy);             /* the launch is over or the pass is dropped: nothing below may leave the workgroup */
-        if (lane == 0 && ok) {                            /* the subtree root's own step: the stage sweep reads it from LDS */
+        if (!ok) { if (lane == 0) *L.abort = p_abort_code(Sy); }      /* the launch is over or the pass is dropped: nothing below may leave the workgroup */
+        else if (wave == 0 && lane == 0) {                           /* the subtree root's own step: the stage sweep reads it from LDS */
 #pragma unroll
             for (int r = 0; r < NX; r++) L.droot[r] = dv[r];
         }
+    } else if (t0 < th) {
+        /* top workgroup: parent of my level-t0 block is the block above it (level t0 - 1), solved already */
+        const int bpar = w / U::width(th - t0), cpar = (w / U::width(th - 1 - t0)) % MD;     /* parent's number on its level, my ordinal among its children */
+        lds_cptr dsrc = L.dl + (U::first(t0 - 1) + bpar) * D + cpar * NX;
+#pragma unroll
+        for (int r = 0; r < NX; r++) dv[r] = dsrc[r];
     } else {
 #pragma unroll
-        for (int r = 0; r < NX; r++) dv[r] = delta_lds[r];
+        for (int r = 0; r < NX; r++) dv[r] = 0.0;
     }
-    double acc0 = 0.0, acc1 = 0.0;                       /* two chains: half the dependent latency */
-#pragma unroll
-    for (int r = 0; r < NX; r += 2) { acc0 = fma(mv[r], dv[r], acc0); if (r + 1 < NX) acc1 = fma(mv[r + 1], dv[r + 1], acc1); }
-    const double mine = fma(-1.0, acc0 + acc1, z0);
     double pd = 0.0;
-    if (lane < D) {
-        if (to_children && ok) st_tag(Sy.dlt + (size_t)(bo + lane) * 2, mine, tag);
-        if (ok) L.dl[loc * D + lane] = mine;              /* a step computed from a failed poll must not replace the last good one (it is written back on leaving) */
-        pd = rv * mine;
+    for (int t = t0; t < th; t++) {
+        const int span = U::width(th - 1 - t);           /* last-level blocks below one block of level t */
+        const int bt = w / span, loc = U::first(t) + bt;
+        const bool owner = active && (w - bt * span) == 0;
+        lds_cptr mr = L.mz_(loc) + li * LDM;
+        double acc0 = 0.0, acc1 = 0.0;                   /* two chains: half the dependent latency */
+#pragma unroll
+        for (int r = 0; r < NX; r += 2) { acc0 = fma(mr[1 + r], dv[r], acc0); if (r + 1 < NX) acc1 = fma(mr[2 + r], dv[r + 1], acc1); }
+        const double mine = fma(-1.0, acc0 + acc1, mr[0]);
+        if (owner && ok && lane < D) {
+            L.dl[loc * D + lane] = mine;                 /* a step computed from a failed poll must not replace the last good one (it is written back on leaving) */
+            pd = fma(L.res[loc * D + lane], mine, pd);
+            if (to_children && t == th - 1) {
+                const int ii = p_slot_node<NX, NU, MD>(loc, l0, s, C);
+                st_tag(Sy.dlt + (size_t)(NX * kid0g<MD>(ii, C) + lane) * 2, mine, tag);
+            }
+        }
+        if (t + 1 < th) {
+            const int cn = (w / U::width(th - 2 - t)) % MD;          /* which child of this block lies on my path */
+#pragma unroll
+            for (int r = 0; r < NX; r++) dv[r] = rdlane(mine, cn * NX + r);
+        }
     }
-    return pd;                                            /* per-lane term of res' * dlam: summed once per sweep */
+    return pd;
 }
 
 /* stage QP of owned node slot q (= node k) at the trial point lam_cur + step*dlam, by ONE 16-lane
@@ -699,7 +718,7 @@ __device__ __forceinline__ bool p_sub_children_tagged(const PSync &Sy, const u64
         }
         pg.load(Sy);
         ok = ok || !need;
-        if (ok || !pg.go_on(Sy, t0)) break;
+        if (ok || !pg.go_on(Sy, t0)) { pg.settle(); break; }
     }
 #pragma unroll
     for (int c = 0; c < MD; c++) {
@@ -752,16 +771,16 @@ __device__ __forceinline__ bool p_gather3(const PSync &Sy, PLds<NX, NU, MD> &L, 
                 if (want_parts) { f = ld_tag(pp, tag_p, ok); d = ld_tag(pp + 2, tag_p, ok); }
                 er = ld_tag(pe, tag_e, ok);
                 pg.load(Sy);
-                if (ok || !pg.go_on(Sy, t0)) break;
+                if (ok || !pg.go_on(Sy, t0)) { pg.settle(); break; }
             }
             if (!ok) { *L.abort = 1; f = 0.0; d = 0.0; er = 0.0; }
         }
         f = wsum(f); d = wsum(d); er = err_max ? wmax(er) : wsum(er);
-        if (lane == 0) { L.sch[3 * wave] = f; L.sch[3 * wave + 1] = d; L.sch[3 * wave + 2] = er; }
+        if (lane == 0) { L.red[3 * wave] = f; L.red[3 * wave + 1] = d; L.red[3 * wave + 2] = er; }
         __syncthreads();
         if (*L.abort) return false;
         if (threadIdx.x == 0) {
-            for (int v = 0; v < FW; v++) { fa += L.sch[3 * v]; da += L.sch[3 * v + 1]; ea = err_max ? fmax(ea, L.sch[3 * v + 2]) : ea + L.sch[3 * v + 2]; }
+            for (int v = 0; v < FW; v++) { fa += L.red[3 * v]; da += L.red[3 * v + 1]; ea = err_max ? fmax(ea, L.red[3 * v + 2]) : ea + L.red[3 * v + 2]; }
         }
         __syncthreads();
     }
@@ -789,6 +808,7 @@ __device__ __forceinline__ bool p_gather_batch(const PSync &Sy, PLds<NX, NU, MD>
 #pragma unroll
                 for (int k = 0; k < 8; k++) if (k < K) f[k] = ld_tag(pp + 2 * k, tag, ok);
                 const unsigned h = __hip_atomic_load(Sy.halt, RLX, AGENT), tmo = __hip_atomic_load(Sy.timeout, RLX, AGENT);
+                asm volatile("" :: "v"(h), "v"(tmo));    /* as PollGuard::settle */
                 if (ok || h == Sy.seq || tmo) break;
                 if (wall_clock64() - t0 > 50000000ull) { __hip_atomic_store(Sy.timeout, 1u, RLX, AGENT); break; }
             }
@@ -857,7 +877,10 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
     {
         const PDump *dp = C.dump;
         if (threadIdx.x == 0) *L.abort = 0;
-        if (threadIdx.x < 2 * D) L.iden[threadIdx.x] = (threadIdx.x == D - 1) ? 1.0 : 0.0;
+        for (int i = threadIdx.x; i < D * PLds<NX, NU, MD>::S; i += FW * WAVE) {      /* identity rows of the tall matrices: entry (m, j) at j * S + m */
+            const int j = i / PLds<NX, NU, MD>::S, m = i - j * PLds<NX, NU, MD>::S;
+            L.idt[i] = (m == j) ? 1.0 : 0.0;
+        }
         const double *lsrc = prologue ? C.lam0_src : (cur ? dp->lam1 : dp->lam0);
         for (int i = threadIdx.x; i < nbt * D; i += FW * WAVE) {
             const int loc = i / D, t = i - loc * D;
@@ -1007,10 +1030,9 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
                     const int loc = U::first(t) + wave, ii = p_slot_node<NX, NU, MD>(loc, l0, s, C);
                     const bool is_root = is_top && t == 0;
                     bool ok = true;
-                    auto assemble = [&]() {                           /* the block's rows minus the children's Schur records */
-                        p_load_rows<NX, NU, MD>(L, loc, lane, is_root, Tc);
-                        if (t < th - 1) sub_children<NX, NU, MD>((lds_cptr)(L.sch + (U::first(t + 1) + MD * wave) * U::SCH), lane, Tc);
-                        else if (!is_bottom) {
+                    auto assemble = [&]() {                           /* the block's rows (my own children have subtracted their Schur records in place) minus the records of the tier below */
+                        p_load_rows<NX, NU, MD>(L, loc, lane, Tc);
+                        if (t == th - 1 && !is_bottom) {
                             ok = p_sub_children_tagged<NX, NU, MD>(Sy, Sy.sch + (size_t)kid0g<MD>(ii, C) * U::SCH * 2, tag_e, lane, Tc);
                             ok = __all(ok);
                             if (!ok && lane == 0) *L.abort = p_abort_code(Sy);
@@ -1032,8 +1054,8 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
                     if (!is_root) {
                         p_store_factor<NX, NU, MD>(L, loc, lane, Tc);
                         FSTAMP(3);
-                        if (t == 0) { if (ok) p_schur<NX, NU, MD, true>(L, loc, lane, L.sch, Sy.sch + (size_t)ii * U::SCH * 2, tag_e); }
-                        else p_schur<NX, NU, MD, false>(L, loc, lane, L.sch + loc * U::SCH, nullptr, 0u);
+                        if (t == 0) { if (ok) p_schur<NX, NU, MD, true>(L, loc, lane, 0, 0, Sy.sch + (size_t)ii * U::SCH * 2, tag_e); }
+                        else p_schur<NX, NU, MD, false>(L, loc, lane, U::first(t - 1) + wave / MD, wave % MD, nullptr, 0u);
                         FSTAMP(4);
                     } else {
                         /* root: dlam_0 = L^-T (L^-1 res) = (L^-1)' y -- lane R + i holds column i of L^-1 (the identity rows of the
@@ -1068,18 +1090,12 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
             lds_barrier();
         }
 
-        /* ---- forward sweep (my subtree root first waits for the parent workgroup's step) ---- */
-        for (int t = (is_top ? 1 : 0); t < th && verdict != 2; t++) {
-            const int nb = U::width(t);
-            if (wave < nb) {
-                const int loc = U::first(t) + wave, ii = p_slot_node<NX, NU, MD>(loc, l0, s, C), bo = NX * kid0g<MD>(ii, C);
-                const bool to_children = !is_bottom && t == th - 1;
-                if (t == 0) dotp += p_forward<NX, NU, MD>(Sy, L, ii, bo, loc, lane, (lds_cptr)L.dl, true, to_children, tag_e);
-                else dotp += p_forward<NX, NU, MD>(Sy, L, ii, bo, loc, lane, (lds_cptr)(L.dl + (U::first(t - 1) + wave / MD) * D + (wave % MD) * NX), false, to_children, tag_e);
-            }
+        /* ---- forward sweep of my subtree, one barrier at its end (the subtree root first waits for the parent workgroup's step) ---- */
+        if (verdict != 2) {
+            dotp += p_forward_tier<NX, NU, MD>(C, Sy, L, l0, s, th, is_top ? 1 : 0, wave, lane, !is_top, !is_bottom, tag_e);
             lds_barrier();
-            if (t == 0 && *L.abort) { gone = true; break; }            /* the parent never delivered: the launch is over, or the pass is dropped */
-            if (t == 0) pstamp(C, O, e, tier, s, sl++);                   /* parent's step arrived + first level */
+            if (!is_top && *L.abort) gone = true;                          /* the parent never delivered: the launch is over, or the pass is dropped */
+            pstamp(C, O, e, tier, s, sl++);
         }
         if (gone) { if (*L.abort == 2) { verdict = 2; gone = false; } else break; }
         double step = 1.0;
