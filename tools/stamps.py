@@ -20,13 +20,17 @@ nx = np.full(p.Nn, p.nx, dtype=np.int32)
 nu = np.where(nk > 0, p.nu, 0).astype(np.int32)
 qp = capi.TreeQp(nx, nu, nk).fill_lti(p)
 g = capi.TqGpu(nk, nx, nu).upload(qp.flat(), p.lambda0)
+kw = {}
+if os.environ.get("STAMPS_TOL"):
+    kw["stationarityTolerance"] = float(os.environ["STAMPS_TOL"])
 for _ in range(5):
-    r = g.solve(maxIter=1) if g.path != 2 else g.solve()   # tiered: one real iteration; persistent: full solve, iteration $TREEQP_AMD_STAMPS
+    r = g.solve(maxIter=1) if g.path != 2 else g.solve(**kw)   # tiered: one real iteration; persistent: full solve, iteration $TREEQP_AMD_STAMPS
 print(r)
 buf = np.zeros(8 * 32 * 2, dtype=np.uint64)
 capi.lib().tqgpu_get_stamps(g.h, buf.ctypes.data_as(C.POINTER(C.c_ulonglong)), len(buf))
 st = buf.reshape(8, 32, 2).astype(np.int64)
 t_first = min(int(st[k][0, 1]) for k in range(8) if st[k][0, 1] > 0)
+LAUNCH0 = min([int(st[k][25, 1]) for k in range(8) if st[k][25, 1] > 0] or [0])
 for kern in range(8):
     name = f"kernel#{kern} (back tiers, top, fwd tiers, stage in launch order)"
     s = st[kern]
@@ -36,6 +40,11 @@ for kern in range(8):
     if kern == 7:
         print('fine stamps (cycles) load_rows / sub_children / factor / store_factor / schur:', [int(v) for v in np.diff(s[:6, 0])])
         continue
+    if s[25, 1] > 0:
+        names = ["start", "state loaded", "first sweep done", "left the loop", "verdict sent to host", "state written back"]
+        w = s[25:31, 1].astype(np.int64)
+        print(f"   launch-level stamps of workgroup {kern} (100 MHz clock, us after the earliest start):", ", ".join(f"{names[i]} {(w[i] - LAUNCH0) * 0.01:.2f}" for i in range(6) if w[i] > 0))
+        s = s.copy(); s[25:31] = 0
     if s[20, 0] > 0 and s[24, 0] > 0:
         print("   fine stamps of level t = 1, wave 0 (cycles, each includes one stamp): assemble / factor / store_factor / schur:", [int(v) for v in np.diff(s[20:25, 0])])
         s = s.copy(); s[20:25] = 0

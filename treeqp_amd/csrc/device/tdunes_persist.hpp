@@ -190,16 +190,28 @@ struct PLds {
     static_assert(RI <= 64, "tall matrix with the identity rows must fit one wavefront");
     static_assert(1 + NX + D <= S, "the factor's output rows must fit the region they replace");
     static constexpr int LDM = NX + 1;                               /* forward data of a block: row i = [z0_i | M_i0 .. M_i,NX-1] */
+    /* the CONSTANTS of the nodes a workgroup owns live in LDS for the launch as well (loaded once, with the state): [A | B] of
+     * the edges to an owned parent's children (column stride LDA = NX + 2 doubles: 16-byte aligned columns whose b128 reads
+     * by 16 consecutive lanes hit 16 disjoint bank quads), their b, and {linear term, 1/weight, weight, lower, upper} per
+     * entry of an owned node.  An iteration then touches global memory only through the tagged hand-over words: no load
+     * ever queues behind a hand-over store (vmcnt is one in-order counter for loads AND stores on gfx9). */
+    static constexpr int LDA = NX + 2;
+    static constexpr int EDGE = NZ * LDA, CST = NZ * 5;
     static constexpr int DOUBLES = NBT * D * S + D * S + NBT * D * LDM + 2 * NBT * D + 16 + SLOTS * NODE + 2 * NBT * D + 3 * NX + 4 * FW
-                                   + FW * U::WAVE_LDS + 32 + 64;
+                                   + FW * U::WAVE_LDS + 32 + 64 + NBT * MD * EDGE + NBT * D + SLOTS * CST + 16;
     lds_ptr tt, idt, mz, res, dl, red, node, lamb, lamroot, droot, part, wave0, wave, bat;     /* red: reductions of the top workgroup; bat: 64 doubles, reductions of a batch of trials */
+    lds_ptr cab, cb, ccst, ctl;                                      /* ctl: the control block, kept by the top workgroup for the launch */
     lds_iptr flag, abort;                                            /* abort: a poll gave up (launch over), leave at the next uniform point */
     __device__ PLds(double *base, int wave_id) {
         tt = to_lds(base); idt = tt + NBT * D * S; mz = idt + D * S; res = mz + NBT * D * LDM; dl = res + NBT * D; red = dl + NBT * D;
         node = red + 16; lamb = node + SLOTS * NODE;
         lamroot = lamb + 2 * NBT * D; droot = lamroot + 2 * NX; part = droot + NX; wave0 = part + 4 * FW; wave = wave0 + wave_id * U::WAVE_LDS;
         flag = (lds_iptr)(wave0 + FW * U::WAVE_LDS); abort = flag + 1; bat = wave0 + FW * U::WAVE_LDS + 32;
+        cab = bat + 64; cb = cab + NBT * MD * EDGE; ccst = cb + NBT * D; ctl = ccst + SLOTS * CST;
     }
+    __device__ __forceinline__ lds_ptr cab_(int loc, int child) const { return cab + (loc * MD + child) * EDGE; }      /* entry (r, column c) at c * LDA + r */
+    __device__ __forceinline__ lds_ptr cb_(int loc) const { return cb + loc * D; }
+    __device__ __forceinline__ lds_ptr ccst_(int q) const { return ccst + q * CST; }                                    /* entry t: 5 doubles at 5 t */
     __device__ __forceinline__ lds_ptr tt_(int loc) const { return tt + loc * D * S; }
     __device__ __forceinline__ lds_ptr mz_(int loc) const { return mz + loc * D * LDM; }
     /* part[4 w + i]: wave w's partials -- 0 termination norm, 1 res' * dlam, 2 dual function value */
@@ -243,7 +255,7 @@ __device__ __forceinline__ void p_gh_load(const PConst &C, const PSync &Sy, cons
     const int rowc = live ? row : 0;                         /* dead rows load row 0 and are masked */
     const int cidx = rowc / NX, r = rowc - cidx * NX;
     const int k = kid0g<MD>(p, C) + cidx;
-    const double *AB = C.AB + (size_t)(k - 1) * NX * NZ + r;
+    lds_cptr AB = L.cab_(loc, cidx) + r;
     const int bo = NX * kid0g<MD>(p, C);
     lds_cptr own = L.node_(loc);                             /* [x | u] then the clipped inverse Hessian, NZ apart */
 #pragma unroll
@@ -251,7 +263,7 @@ __device__ __forceinline__ void p_gh_load(const PConst &C, const PSync &Sy, cons
         const int cc = g + 4 * s;
         const bool ok = live && cc < NZ;
         const int cz = (cc < NZ) ? cc : 0;
-        const double av = AB[(size_t)cz * NX], zv = own[cz], pv = own[NZ + cz];
+        const double av = AB[cz * PLds<NX, NU, MD>::LDA], zv = own[cz], pv = own[NZ + cz];
         G.a[s] = ok ? av : 0.0; G.pc[s] = ok ? pv : 0.0; G.z[s] = ok ? zv : 0.0;
     }
     double xv, qv;
@@ -271,7 +283,7 @@ __device__ __forceinline__ void p_gh_load(const PConst &C, const PSync &Sy, cons
         if (!ok) *L.abort = p_abort_code(Sy);
     } else if (foreign) { const PDump *dp = C.dump; xv = dp->x[bo + rowc]; qv = dp->QinvCal[bo + rowc]; }   /* relaunch: staged by earlier kernels */
     else { lds_cptr kid = L.node_(MD * loc + 1 + cidx); xv = kid[r]; qv = kid[NZ + r]; }
-    const double bv = C.b[bo + rowc];
+    const double bv = L.cb_(loc)[rowc];
     G.xk = (live && g == 0) ? xv : 0.0; G.bk = (live && g == 0) ? bv : 0.0; G.qk = live ? qv : 0.0;
 }
 
@@ -395,21 +407,52 @@ __device__ __forceinline__ void p_factor_rows(Ctrl *ctrl, const Opts &O, int lan
     }
 }
 
-/* the same without the saved copy of the block (32 registers across the factorisation): the first pass only; when it
- * reports a small pivot under ON_THE_FLY regularisation the caller reloads the rows (rare) and calls p_refactor_rows */
+/* The factorisation on the critical path: as p_potrf_rows with the rare cases taken out of the pivot chain.  A pivot that is
+ * not above `thr` (NaN included) only raises a flag -- one compare into a scalar mask per column, no select on the reciprocal
+ * square root, no running minimum -- and the result is then garbage: the caller reloads the rows and takes the careful
+ * path.  thr = regTol^2 under ON_THE_FLY regularisation (then the careful path shifts the diagonal first), 0 otherwise
+ * (then it is p_potrf_rows itself, for its zero column of a non-positive pivot). */
+template <int D>
+__device__ __forceinline__ bool p_potrf_fast(double (&T)[D], int lane, double thr) {
+    unsigned long long flagged = 0ull;
+#pragma unroll
+    for (int j = 0; j < D; j++) {
+        double s = T[j];
+#pragma unroll
+        for (int k = 0; k < j; k++) s = fma(-T[k], rdlane(T[k], j), s);
+        const double pj = rdlane(s, j);
+        flagged |= __builtin_amdgcn_ballot_w64(!(pj > thr));
+        const double y0 = __builtin_amdgcn_rsq(pj);
+        const double e = fma(-(pj * y0), y0, 1.0);
+        const double h = fma(0.375, e, 0.5);
+        T[j] = s * fma(y0 * e, h, y0);
+    }
+    return flagged != 0ull;
+}
+
+/* first pass without a saved copy of the block (32 registers across the factorisation); true: the caller reloads the rows
+ * (rare) and calls p_refactor_rows */
 template <int NX, int NU, int MD>
 __device__ __forceinline__ bool p_factor_rows_first(const Opts &O, int lane, double (&T)[Uni<NX, NU, MD>::D]) {
     constexpr int D = Uni<NX, NU, MD>::D;
     if (O.regType == 1) ShiftDiag<0, D>::run(T, T, O.regValue);                    /* ddiare (ALWAYS) */
+#ifndef TQ_FAST_PIVOT      /* default: the running minimum costs nothing measurable on C2 (the pivot chain, not the issue rate, bounds the factorisation); the flag-only variant measured +1.5 % on C1, -1 % on C2 */
     const double pmin = p_potrf_rows<D>(T, lane);
-    return O.regType == 2 && pmin <= O.regTol * O.regTol;                          /* sqrt(pivot) <= regTol, incl. non-positive pivots */
+    return O.regType == 2 && pmin <= O.regTol * O.regTol;
+#else
+    return p_potrf_fast<D>(T, lane, O.regType == 2 ? O.regTol * O.regTol : 0.0);   /* sqrt(pivot) <= regTol, incl. non-positive pivots */
+#endif
 }
+/* the careful pass on freshly reloaded rows.  ON_THE_FLY (dual_Newton_common.c:60-68): a diagonal entry of the first factor
+ * was <= regTol -- the flag of the fast pass says exactly that, its first flagged pivot being computed from unflagged ones --
+ * so shift the diagonal and factorise again.  Otherwise a pivot was not positive: factorise again (ALWAYS: on the shifted
+ * diagonal) with the zero-column convention of p_potrf_rows. */
 template <int NX, int NU, int MD>
 __device__ __forceinline__ void p_refactor_rows(Ctrl *ctrl, const Opts &O, int lane, double (&T)[Uni<NX, NU, MD>::D]) {
     constexpr int D = Uni<NX, NU, MD>::D;
-    ShiftDiag<0, D>::run(T, T, O.regValue);
+    if (O.regType != 0) ShiftDiag<0, D>::run(T, T, O.regValue);
     (void)p_potrf_rows<D>(T, lane);
-    if (lane == 0) atomicAdd(&ctrl->n_reg, 1);
+    if (O.regType == 2 && lane == 0) atomicAdd(&ctrl->n_reg, 1);
 }
 
 /* rows of the tall matrix of block `loc`, identity rows below: ONE address per lane, D loads with immediate offsets */
@@ -593,12 +636,11 @@ __device__ __forceinline__ double p_stage16(const PConst &C, const PSync &Sy, PL
     static_assert(NX + NU <= 16 && D <= 16, "16-lane stage needs nx+nu <= 16 and d <= 16");
     const bool parent = active && k < C.Np;
     const int nuk = parent ? NU : 0;
-    const int ko = NX * kid0g<MD>(k, C);
     const bool isx = t < NX, live = active && t < NX + nuk;
     /* branch-free loads: every lane reads from a valid (clamped) address and masks afterwards */
     const bool pk = parent && t < D, ox = active && isx && k > 0;
     const int qb = pk ? q : 0, tb = pk ? t : 0;                       /* my block's duals / step */
-    const double lca = L.lamb_(cb, qb)[tb], dla = L.dl[qb * D + tb], ba = C.b[pk ? ko + t : 0];
+    const double lca = L.lamb_(cb, qb)[tb], dla = L.dl[qb * D + tb], ba = L.cb_(qb)[tb];
     const int qp = (ox && q > 0) ? (q - 1) / MD : 0, tp = (ox && q > 0) ? ((q - 1) % MD) * NX + t : 0;   /* my own slice in the parent's block */
     const int tr = ox ? t : 0;
     const double lcb = (q > 0) ? L.lamb_(cb, qp)[tp] : L.lamroot[cb * NX + tr];
@@ -607,12 +649,11 @@ __device__ __forceinline__ double p_stage16(const PConst &C, const PSync &Sy, PL
     double col[MD][NX];
 #pragma unroll
     for (int cc = 0; cc < MD; cc++) {
-        const int kid = pl ? kid0g<MD>(k, C) + cc : 1;
-        const double *cp = C.AB + (size_t)(kid - 1) * NX * NZ + (size_t)(pl ? t : 0) * NX;      /* column t of [A | B] */
+        lds_cptr cp = L.cab_(pl ? q : 0, cc) + (pl ? t : 0) * PLds<NX, NU, MD>::LDA;            /* column t of [A | B] of the edge to child cc */
 #pragma unroll
         for (int i = 0; i < NX; i++) col[cc][i] = cp[i];
     }
-    const double *cs = C.cst + ((size_t)(active ? k : 0) * 16 + t) * 5;
+    lds_cptr cs = L.ccst_(active ? q : 0) + (t < NZ ? t : 0) * 5;
     const double lin = cs[0], winv = cs[1], wd = cs[2], lob = cs[3], hib = cs[4];
     double p_c = 0.0;
     {
@@ -690,7 +731,7 @@ __device__ __forceinline__ void pstamp(const PConst &C, const Opts &O, unsigned 
         unsigned long long *st = C.dump->stamps;
         const unsigned long long ck = clock64();     /* the shader clock only: reading the 100 MHz wall clock takes ~1 us and would sit inside every phase */
         st[(tier * 32 + slot) * 2 + 0] = ck;
-        st[(tier * 32 + slot) * 2 + 1] = ck / 24;    /* nominal 2.4 GHz in 100 MHz ticks */
+        st[(tier * 32 + slot) * 2 + 1] = slot >= 25 ? wall_clock64() : ck / 24;    /* launch-level stamps: the chip-wide 100 MHz clock (comparable across workgroups); phases: nominal 2.4 GHz in 100 MHz ticks */
     }
 }
 
@@ -843,9 +884,14 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
     PSync Sy = Sy_in;
     Sy.trip = 0u;
     constexpr int D = U::D, NZ = U::NZ;
-    Ctrl *c = C.ctrl;
+    /* the control block lives in the top workgroup's LDS during the launch (its thread 0 is the only one that takes decisions):
+     * a verdict is a dozen dependent reads and writes of it, each a trip to L2 when it sits in global memory.  Global memory
+     * holds it between launches (cg): read at the start of a relaunch, written back with the verdict. */
+    Ctrl *cg = C.ctrl;
+    static_assert(sizeof(Ctrl) <= 16 * sizeof(double), "control block copy");
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     PLds<NX, NU, MD> L(lds_all, wave);
+    Ctrl *c = reinterpret_cast<Ctrl *>((double *)L.ctl);
     const int l0 = Gm.l0[tier], th = Gm.l1[tier] - l0;
     const bool is_top = tier == Gm.n_tiers - 1, is_bottom = tier == 0;
     const int nbt = U::first(th);                                      /* my blocks */
@@ -857,6 +903,7 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
     if (threadIdx.x == 0 && wg < 1024)
         C.dump->stamps[8 * 32 * 2 + wg] = ((unsigned long long)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 4);
 #endif
+    pstamp(C, O, (unsigned)O.stamps, tier, s, 25);                     /* 25: workgroup started */
     int cur = 0;
     unsigned nd = 0u;          /* stage sweeps (= {fval, dot} reductions) of this launch so far */
     bool have_dl = false;      /* a forward sweep of this launch has filled the step of my blocks */
@@ -867,10 +914,12 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
         if (is_top && threadIdx.x == 0) {
             c->done = 0; c->status = 0; c->iter = 0; c->cur = 0; c->ls_pending = 0; c->ls_iter = 0; c->ls_total = 0; c->ls_last = 0;
             c->restart_counter = 0; c->n_reg = 0; c->tau = 0.0; c->tauPrev = 0.0; c->fval0 = 0.0; c->fval = 0.0; c->dot = 0.0; c->err = 0.0;
+            cg->n_reg = 0;                                                    /* counted in global memory by whoever regularises a block */
         }
     } else {
-        if (__hip_atomic_load(&c->done, RLX, AGENT) || __hip_atomic_load(&c->ls_pending, RLX, AGENT)) return;
-        cur = __hip_atomic_load(&c->cur, RLX, AGENT);
+        if (__hip_atomic_load(&cg->done, RLX, AGENT) || __hip_atomic_load(&cg->ls_pending, RLX, AGENT)) return;
+        cur = __hip_atomic_load(&cg->cur, RLX, AGENT);
+        if (is_top && threadIdx.x == 0) *c = *cg;
     }
 
     /* ---- load the state this workgroup owns: duals of my blocks and of my root, node store ---- */
@@ -880,6 +929,20 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
         for (int i = threadIdx.x; i < D * PLds<NX, NU, MD>::S; i += FW * WAVE) {      /* identity rows of the tall matrices: entry (m, j) at j * S + m */
             const int j = i / PLds<NX, NU, MD>::S, m = i - j * PLds<NX, NU, MD>::S;
             L.idt[i] = (m == j) ? 1.0 : 0.0;
+        }
+        /* constants of my nodes: [A | B] and b of the edges below my blocks' owner nodes, stage constants of every node I own */
+        for (int i = threadIdx.x; i < nbt * MD * NX * NZ; i += FW * WAVE) {
+            const int e = i / (NX * NZ), w = i - e * (NX * NZ), loc = e / MD, cc = e - loc * MD, col = w / NX, r = w - col * NX;
+            const int kid = kid0g<MD>(p_slot_node<NX, NU, MD>(loc, l0, s, C), C) + cc;
+            L.cab_(loc, cc)[col * PLds<NX, NU, MD>::LDA + r] = C.AB[(size_t)(kid - 1) * NX * NZ + w];
+        }
+        for (int i = threadIdx.x; i < nbt * D; i += FW * WAVE) {
+            const int loc = i / D, t = i - loc * D;
+            L.cb_(loc)[t] = C.b[NX * kid0g<MD>(p_slot_node<NX, NU, MD>(loc, l0, s, C), C) + t];
+        }
+        for (int i = threadIdx.x; i < nown * NZ * 5; i += FW * WAVE) {
+            const int q = i / (NZ * 5), w = i - q * (NZ * 5);
+            L.ccst_(q)[w] = C.cst[(size_t)p_slot_node<NX, NU, MD>(q, l0, s, C) * 16 * 5 + w];
         }
         const double *lsrc = prologue ? C.lam0_src : (cur ? dp->lam1 : dp->lam0);
         for (int i = threadIdx.x; i < nbt * D; i += FW * WAVE) {
@@ -907,6 +970,7 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
         st_tag(Sy.parts + (size_t)wg * 4 + 2, d, Sy.seq | nd);
     };
 
+    pstamp(C, O, (unsigned)O.stamps, tier, s, 26);                     /* 26: state and constants loaded */
     if (prologue) {
         /* ---- first sweep of the solve: stage QPs at lambda0, fval0 ---- */
         const double fsum = p_stage_owned<NX, NU, MD>(C, Sy, L, l0, nown, s, wave, lane, 0.0, cur, true, !is_top, Sy.seq | 1u, PChain{1, 0.0, 0.0}, false);
@@ -916,6 +980,7 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
         if (threadIdx.x == 0) post_parts();
     }
 
+    pstamp(C, O, (unsigned)O.stamps, tier, s, 27);                     /* 27: first sweep done */
     /* one trip = one PASS: G + H at the point of the latest stage sweep, then -- if the top workgroup accepts
      * that point -- backward sweep, forward sweep and the first trial of the next line search; if it rejects
      * it (Armijo test failed, more trials to go) the pass is dropped after G + H and the trip ends with the
@@ -1048,7 +1113,7 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
                     FSTAMP(1);
                     if (p_factor_rows_first<NX, NU, MD>(O, lane, Tc)) {
                         assemble();                                   /* rare: shift and refactorise (the rows are still in LDS) */
-                        p_refactor_rows<NX, NU, MD>(c, O, lane, Tc);
+                        p_refactor_rows<NX, NU, MD>(cg, O, lane, Tc);
                     }
                     FSTAMP(2);
                     if (!is_root) {
@@ -1188,18 +1253,25 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
      * workgroup has finished the same number of stage sweeps and none has started the next forward
      * sweep, so what LDS holds is the point the control block describes. ---- */
     __syncthreads();
+    pstamp(C, O, (unsigned)O.stamps, tier, s, 28);                     /* 28: left the loop */
     {
         const PDump *dp = C.dump;
         if (is_top && threadIdx.x == 0) {
             /* the verdict goes straight to the host (system-scope stores to pinned memory, then the sequence word) */
             HostRes *hr = dp->hres;
+            c->n_reg = __hip_atomic_load(&cg->n_reg, RLX, AGENT);
+            *cg = *c;                                                         /* for the next launch and for the stream-ordered readers */
             const unsigned long long *src = reinterpret_cast<const unsigned long long *>(c);
             unsigned long long *dst = reinterpret_cast<unsigned long long *>(&hr->c);
             for (int i = 0; i < (int)(sizeof(Ctrl) / 8); i++) __hip_atomic_store(dst + i, src[i], RLX, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(&hr->t_start, t_start, RLX, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(&hr->t_end, (unsigned long long)wall_clock64(), RLX, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&hr->seq, Sy.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            /* the block is complete once every store above has left the chip: wait for their acknowledgements, then the sequence word.
+             * (NOT a system-scope release: that writes back the whole L2 of this XCD first -- 6 us measured, on the host's critical path) */
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&hr->seq, Sy.seq, RLX, __HIP_MEMORY_SCOPE_SYSTEM);
         }
+        pstamp(C, O, (unsigned)O.stamps, tier, s, 29);                 /* 29: verdict on the host's way */
         if (nd > 0u) {
             for (int i = threadIdx.x; i < nown * 16; i += FW * WAVE) {
                 const int q = i >> 4, t = i & 15;
@@ -1226,6 +1298,7 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
             }
         }
     }
+    pstamp(C, O, (unsigned)O.stamps, tier, s, 30);                     /* 30: state written back */
 }
 
 #ifndef TQ_WPS
