@@ -39,6 +39,8 @@ extern "C" {
 #define TQGPU_ENOMEM (-3)
 #define TQGPU_EUNSUPPORTED (-4)  /* e.g. dual block too large for the LDS-resident kernels */
 #define TQGPU_ECOMM (-5)         /* RCCL failure */
+#define TQGPU_ETIMEOUT (-6)      /* a bounded wait inside the persistent launch gave up (its workgroups were not all resident: the device is
+                                    shared); tqgpu_solve does not return this -- it redoes the solve on the launch-per-tier / per-level path */
 
 typedef struct tqgpu_solver tqgpu_solver;
 
@@ -98,6 +100,8 @@ int tqgpu_get_solution(tqgpu_solver *s, double *x, double *u, double *lam, doubl
  * 0: generic per-level kernels.  TREEQP_AMD_PATH=generic|tiered in the environment at create time
  * forces the lower paths. */
 int tqgpu_uses_fused_path(const tqgpu_solver *s);
+/* diagnostic: persistent launches of this mirror that timed out (device shared with other work) and were redone on another path */
+int tqgpu_timeouts(const tqgpu_solver *s);
 
 /* sizes of the flat arrays, for callers that did not keep them */
 int tqgpu_dims(const tqgpu_solver *s, int *sum_nx, int *sum_nu, int *sum_lam, int *sum_A, int *sum_B);
@@ -137,6 +141,10 @@ int tqgpu_get_device_times(tqgpu_solver *s, double *out, int n);
 
 /* diagnostic in-kernel time stamps of the last fused iteration (TREEQP_AMD_STAMPS=1) */
 int tqgpu_get_stamps(tqgpu_solver *s, unsigned long long *out, int cap);
+/* test support: a foreign kernel holding compute units (blocks x 256 threads, lds_kb KiB of LDS each, spinning for ms milliseconds
+ * on its own stream; returns at once), and the wait for it */
+int tqgpu_debug_occupy(int device, int blocks, int lds_kb, int ms);
+int tqgpu_debug_occupy_wait(void);
 
 /* sizeof() of the public structs (0 dmat, 1 dvec, 2 node, 3 tree_qp_in, 4 tree_qp_out,
  * 5 tdunes opts, 6 tdunes workspace, 7 profiling record, 8 qp_internal_t) for FFI self-checks */

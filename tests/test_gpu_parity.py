@@ -73,10 +73,9 @@ def test_x0_eliminated_spring_mass(gpu, orc):
     assert status == ref["status"] == 0
     assert ref["iter"] == 58
     assert qp.max_kkt_res() < 1e-10                     # examples/spring_mass.c:331
-    # a long, line-search heavy run: late Armijo tests are decided by rounding noise, so the
-    # iteration counts may differ slightly while the solution may not
-    assert abs(qp.info["iter"] - ref["iter"]) <= 2
-    assert_solution_close(qp.solution(), ref, 1e-9)
+    # a long, line-search heavy run (1329 trials): every Armijo decision of the device falls as the reference's
+    assert qp.info["iter"] == ref["iter"] and s.ls_total == ref["ls_total"]
+    assert_solution_close(qp.solution(), ref, TOL)
     s.destroy()
 
 
@@ -107,7 +106,7 @@ def test_x0_eliminated_trees_take_the_persistent_path(gpu, orc, make):
     assert r["status"] == rg["status"] == ref["status"] == 0
     assert abs(r["iter"] - ref["iter"]) <= 2 and abs(rg["iter"] - ref["iter"]) <= 2
     for sl in (sol, sg):
-        assert_solution_close(sl, ref, 1e-9)
+        assert_solution_close(sl, ref, TOL)
         assert orc.max_kkt(flat, sl) < 1e-8
 
 
@@ -172,7 +171,7 @@ def test_options_termination_and_regularisation(gpu, orc):
         qp, s, status, ref, flat = solve_lti_both(gpu, orc, p, **opts)
         assert status == ref["status"], opts
         assert qp.info["iter"] == ref["iter"], opts
-        assert_solution_close(qp.solution(), ref, 1e-9, keys=("x", "u", "lam"))
+        assert_solution_close(qp.solution(), ref, TOL)
         s.destroy()
 
 
@@ -207,7 +206,7 @@ def test_mpc_loop_updates_x0_after_elimination(gpu, orc):
         ref = orc.solve(flat, lambda0=None if scale == 1.0 else prev)      # noqa: F821
         assert ref["status"] == 0
         assert qp.max_kkt_res() < 1e-9
-        assert_solution_close(qp.solution(), ref, 1e-8, keys=("x", "u"))
+        assert_solution_close(qp.solution(), ref, TOL)
         prev = qp.solution()["lam"]
     s.destroy()
 
@@ -252,7 +251,7 @@ def test_wide_block_kernels_match_oracle(gpu, orc, nx, nu, md, levels):
     assert g.path == 0
     r = g.solve(**f.opts)
     assert r["status"] == ref["status"] == 0 and r["iter"] == ref["iter"] == 1
-    assert_solution_close(g.solution(), ref, 1e-9, keys=("x", "u", "lam"))
+    assert_solution_close(g.solution(), ref, TOL)
     g.close()
 
 
@@ -265,7 +264,7 @@ def test_wide_block_kernels_regularisation(gpu, orc, reg):
     g = gpu.TqGpu(f.nk, f.nx, f.nu).upload(f.as_dict(), f.lambda0)
     r = g.solve(**opts)
     assert r["status"] == ref["status"] == 0 and r["iter"] == ref["iter"] and r["ls_total"] == ref["ls_total"]
-    assert_solution_close(g.solution(), ref, 1e-8, keys=("x", "u", "lam"))
+    assert_solution_close(g.solution(), ref, TOL)
     g.close()
 
 
@@ -296,7 +295,7 @@ def test_full_size_random_c4(gpu, orc):
     assert status == ref["status"] == 0
     assert qp.info["iter"] == ref["iter"] == 1          # unconstrained: one Newton step (random_qp.c:251-253)
     assert qp.max_kkt_res() < 1e-8
-    assert_solution_close(qp.solution(), ref, 1e-8, keys=("x", "u"))
+    assert_solution_close(qp.solution(), ref, TOL)
     s.destroy()
 
 
@@ -416,12 +415,12 @@ def test_multistage_tree_backtracking_and_options(gpu, orc):
     assert ref["status"] == 0 and ref["ls_total"] > ref["iter"], "fixture should need backtracking"
     rf, sf, _ = _solve_flat_tq(gpu, flat, lam0, "auto")
     assert rf["status"] == 0 and rf["iter"] == ref["iter"] and rf["ls_total"] == ref["ls_total"]
-    assert_solution_close(sf, ref, 1e-9)
+    assert_solution_close(sf, ref, TOL)
     for opts in (dict(regType=1, regValue=1e-8), dict(termCondition=1), dict(maxIter=2)):
         ref = orc.solve(flat, orc.default_opts(**opts), p.lambda0)
         rf, sf, _ = _solve_flat_tq(gpu, flat, p.lambda0, "auto", **opts)
         assert rf["status"] == ref["status"] and rf["iter"] == ref["iter"]
-        assert_solution_close(sf, ref, 1e-9, keys=("x", "u", "lam"))
+        assert_solution_close(sf, ref, TOL)
 
 
 def _solve_flat_tq(gpu, flat, lambda0, path, **opts):
@@ -466,7 +465,7 @@ def test_fused_path_options(gpu, orc, opts):
     rf, sf, fused = _solve_flat_tq(gpu, flat, p.lambda0, "auto", **opts)
     assert fused
     assert rf["status"] == ref["status"] and rf["iter"] == ref["iter"]
-    assert_solution_close(sf, ref, 1e-9, keys=("x", "u", "lam"))
+    assert_solution_close(sf, ref, TOL)
 
 
 def test_fused_path_multi_trial_line_search(gpu, orc):
@@ -481,7 +480,7 @@ def test_fused_path_multi_trial_line_search(gpu, orc):
     rf, sf, fused = _solve_flat_tq(gpu, flat, lam0, "auto")
     assert fused and rf["status"] == 0
     assert rf["iter"] == ref["iter"] and rf["ls_total"] == ref["ls_total"]
-    assert_solution_close(sf, ref, 1e-9)
+    assert_solution_close(sf, ref, TOL)
 
 
 # --- one tree sharded over several (virtual) ranks -----------------------------------------------
@@ -528,7 +527,7 @@ def test_sharded_virtual_ranks_backtracking(gpu, orc):
     mirrors = [gpu.TqGpu(flat["nk"], flat["nx"], flat["nu"]).upload(flat, lam0).shard_init(r, 4) for r in range(4)]
     res = gpu.solve_virtual_ranks(mirrors)
     assert res["status"] == 0 and res["iter"] == ref["iter"] and res["ls_total"] == ref["ls_total"]
-    assert_solution_close(mirrors[3].solution(), ref, 1e-9)
+    assert_solution_close(mirrors[3].solution(), ref, TOL)
     for m in mirrors:
         m.close()
 
@@ -656,8 +655,8 @@ def test_batch_of_pruned_trees_is_one_launch(gpu, orc):
         assert rb["status"] == ref["status"] == 0 and rb["iter"] == ref["iter"] == r1["iter"] and rb["ls_total"] == ref["ls_total"]
         assert rb["n_launches"] == 1
         sb = m.solution()
-        assert_solution_close(sb, ref, 1e-8, keys=("x", "u", "lam"))
-        assert_solution_close(sb, s1, 1e-9, keys=("x", "u", "lam"))
+        assert_solution_close(sb, ref, TOL)
+        assert_solution_close(sb, s1, TOL)
     for m in ms:
         m.close()
 
@@ -688,7 +687,7 @@ def test_persistent_path_line_search_corners(gpu, orc, make):
                 r = g.solve(**o)
                 assert (r["status"], r["iter"], r["ls_total"]) == (0, ref["iter"], ref["ls_total"]), (seed, scale, o)
                 assert r["n_launches"] <= 3          # one solve kernel (+ the pack / init kernels of a first solve): no host-run trials
-                assert_solution_close(g.solution(), ref, 1e-7, keys=("x", "u", "lam"))
+                assert_solution_close(g.solution(), ref, TOL)
                 compared += 1
                 backtracked += ref["ls_total"] > ref["iter"]
     assert compared >= 30 and backtracked >= 10
@@ -712,7 +711,7 @@ def test_mixed_batch_of_all_device_paths(gpu, orc):
     for (name, f, l0), m, r in zip(members, ms, res):
         ref = orc.solve(f, lambda0=l0)
         assert (r["status"], r["iter"], r["ls_total"]) == (ref["status"], ref["iter"], ref["ls_total"]), name
-        assert_solution_close(m.solution(), ref, 1e-8, keys=("x", "u", "lam"))
+        assert_solution_close(m.solution(), ref, TOL)
         m.close()
 
 
@@ -745,7 +744,7 @@ def test_random_tree_shapes_with_per_node_dimensions(gpu, orc, seed, depth, kids
     for path in ("auto", "generic"):
         r, sol, _ = _solve_flat_tq(gpu, f.as_dict(), None, path)
         assert (r["status"], r["iter"], r["ls_total"]) == (0, ref["iter"], ref["ls_total"]), path
-        assert_solution_close(sol, ref, 1e-8, keys=("x", "u", "lam"))
+        assert_solution_close(sol, ref, TOL)
         assert orc.max_kkt(f.as_dict(), sol) < 1e-8
 
 
@@ -757,7 +756,7 @@ def test_batch_of_random_tree_shapes(gpu, orc):
     for f, m, r in zip(fs, ms, res):
         ref = orc.solve(f.as_dict())
         assert (r["status"], r["iter"], r["ls_total"]) == (0, ref["iter"], ref["ls_total"]), f.name
-        assert_solution_close(m.solution(), ref, 1e-8, keys=("x", "u", "lam"))
+        assert_solution_close(m.solution(), ref, TOL)
         m.close()
 
 
@@ -778,7 +777,7 @@ def test_persistent_path_on_random_time_varying_data(gpu, orc, seed, nx, nu, md,
         r = g.solve()
         assert (r["status"], r["iter"], r["ls_total"]) == (0, ref["iter"], ref["ls_total"])
     sol = g.solution()
-    assert_solution_close(sol, ref, 1e-8, keys=("x", "u", "lam"))
+    assert_solution_close(sol, ref, TOL)
     assert orc.max_kkt(f.as_dict(), sol) < 1e-8
     g.close()
 
@@ -797,5 +796,5 @@ def test_smallest_and_longest_shapes(gpu, orc, name, make):
     g = gpu.TqGpu(flat["nk"], flat["nx"], flat["nu"]).upload(flat, p.lambda0)
     r = g.solve()
     assert (r["status"], r["iter"], r["ls_total"]) == (ref["status"], ref["iter"], ref["ls_total"])
-    assert_solution_close(g.solution(), ref, 1e-9, keys=("x", "u", "lam"))
+    assert_solution_close(g.solution(), ref, TOL)
     g.close()

@@ -1,0 +1,144 @@
+"""Behaviour at the edges of a solve, on the MI355X: exits the reference takes without a solution (NaN data, iteration limit),
+and a device that is shared with other work.  Every expectation is the reference's (via the oracle), cited per test."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from helpers import assert_solution_close, oracle_flat_from_lti, product_qp_from_flat, product_qp_from_lti
+from treeqp_amd import problems as P
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def gpu(capi):
+    if capi.device_count() < 1:
+        pytest.fail("no HIP device visible: the -m gpu tests must run on the MI355X box")
+    return capi
+
+
+def flat_case(gpu, orc, name):
+    if name == "uniform":            # persistent path, three tiers of workgroups
+        p = P.linear_chain(2, 7, 7)
+    elif name == "multistage":       # persistent path, chain tiers (the reference's example)
+        p = P.spring_mass()
+    elif name == "irregular":        # single-workgroup kernel
+        return P.irregular_clipping_qp().as_dict(), None
+    elif name == "pruned":           # launch per level
+        f = P.pruned_chain_qp(seed=11)
+        return f.as_dict(), f.lambda0
+    return product_qp_from_lti(gpu, p).flat(), p.lambda0
+
+
+PATH_CASES = ["uniform", "multistage", "irregular", "pruned"]
+
+
+@pytest.mark.parametrize("name", PATH_CASES)
+@pytest.mark.parametrize("k", [1, 2])
+def test_iteration_limit_exit_pairs_last_trial_with_phase_s(gpu, orc, name, k):
+    """MAXIMUM_ITERATIONS_REACHED: x, u are those of the last line-search trial, but export_mu (clipping.c:386-399) uses the
+    unclipped solution of the last phase S (the trial sweeps, clipping.c:231-260, do not write xUnc) -- so mu is NOT the
+    multiplier of the returned point.  Every device path keeps phase S's unclipped values for this (Data::xUncS)."""
+    flat, lam0 = flat_case(gpu, orc, name)
+    ref = orc.solve(flat, orc.default_opts(maxIter=k), lam0)
+    g = gpu.TqGpu(flat["nk"], flat["nx"], flat["nu"]).upload(flat, lam0)
+    r = g.solve(maxIter=k)
+    sol = g.solution()
+    g.close()
+    assert r["status"] == ref["status"] and r["iter"] == ref["iter"]
+    assert_solution_close(sol, ref, TOL)
+    if ref["status"] == 1:
+        # the test would be blind if mu happened to be the multiplier of the returned point: it is not
+        inside = (ref["x"] > np.asarray(flat["xmin"]) + 1e-9) & (ref["x"] < np.asarray(flat["xmax"]) - 1e-9)
+        inside_u = (ref["u"] > np.asarray(flat["umin"]) + 1e-9) & (ref["u"] < np.asarray(flat["umax"]) - 1e-9)
+        assert np.any(np.abs(ref["mu_x"][inside]) > 1e-8) or np.any(np.abs(ref["mu_u"][inside_u]) > 1e-8) or name in ("irregular",)
+
+
+@pytest.mark.parametrize("name", PATH_CASES)
+@pytest.mark.parametrize("where", ["q", "lambda0"])
+def test_nan_data_ends_with_not_descent_direction(gpu, orc, name, where):
+    """A NaN in the data or in the starting duals: the reference's residual norm is NaN (MAX(error, NaN), dual_Newton_tree.c:412-442),
+    `error < tol` is false, and the line search returns TREEQP_DN_NOT_DESCENT_DIRECTION (:949) -- never "optimal" with a NaN solution.
+    The device reductions propagate NaN (v_max_f64 alone would drop it and report convergence at iteration 0)."""
+    flat, lam0 = flat_case(gpu, orc, name)
+    flat = {k: np.array(v, copy=True) for k, v in flat.items()}
+    nlam = int(np.sum(flat["nx"][1:]))
+    lam0 = np.zeros(nlam) if lam0 is None else np.array(lam0[:nlam], dtype=float, copy=True)
+    if where == "q":
+        flat["q"][len(flat["q"]) // 2] = np.nan
+    else:
+        lam0[nlam // 3] = np.nan
+    ref = orc.solve(flat, lambda0=lam0)
+    assert ref["status"] == 2
+    g = gpu.TqGpu(flat["nk"], flat["nx"], flat["nu"]).upload(flat, lam0)
+    r = g.solve()
+    g.close()
+    assert r["status"] == 2, r
+
+
+def test_nan_leaves_qp_out_untouched_through_the_dropin_api(gpu, orc):
+    """early error return: qp_out is not written (dual_Newton_tree.c:1177, 1215)"""
+    p = P.spring_mass()
+    qp = product_qp_from_lti(gpu, p)
+    s = gpu.TdunesSolver(qp)
+    lam = np.array(p.lambda0, copy=True)
+    lam[5] = np.nan
+    s.set_dual_initialization(lam)
+    before = {k: v.copy() for k, v in qp.solution().items()}
+    assert s.solve() == 2
+    after = qp.solution()
+    for k in before:
+        assert np.array_equal(before[k], after[k], equal_nan=True), k
+    s.destroy()
+
+
+def test_options_rejected_without_side_effects(gpu):
+    """maxIter cannot grow after create: the Python mirror refuses BEFORE assigning, the C entry point returns
+    TREEQP_INVALID_OPTION instead of aborting the process (the reference asserts)."""
+    p = P.spring_mass(Nh=4)
+    qp = product_qp_from_lti(gpu, p)
+    s = gpu.TdunesSolver(qp, maxIter=5)
+    s.create()
+    with pytest.raises(ValueError):
+        s.set_option("maxIter", 50)
+    assert s.opts.maxIter == 5
+    s.opts.maxIter = 50                      # behind the mirror's back
+    assert s.solve() == 9                    # TREEQP_INVALID_OPTION
+    s.opts.maxIter = 5
+    s.set_dual_initialization(p.lambda0)
+    assert s.solve() in (0, 1)
+    s.destroy()
+
+
+def test_shared_device_takes_the_launch_per_tier_path(gpu, orc):
+    """The persistent launch needs all its workgroups resident together.  A foreign kernel that holds most of the compute
+    units (here: 232 workgroups claiming a CU's whole LDS each, for 1.5 s) leaves room for only some of them: the ones that
+    run wait 0.5 s for the others, give up, and the launch ends itself.  tqgpu_solve then clears the sticky timeout word and
+    redoes the solve on the path without a residency requirement -- same verdict, same solution, no error -- and later solves
+    on this mirror stay there for a while (tqgpu_timeouts counts the event)."""
+    L = gpu.lib()
+    p = P.linear_chain(2, 9, 9)
+    qp = product_qp_from_lti(gpu, p)
+    flat = qp.flat()
+    ref = orc.solve(flat, lambda0=p.lambda0)
+    g = gpu.TqGpu(flat["nk"], flat["nx"], flat["nu"]).upload(flat, p.lambda0)
+    assert g.path == 2
+    r0 = g.solve()
+    assert r0["status"] == 0 and L.tqgpu_timeouts(g.h) == 0
+    assert L.tqgpu_debug_occupy(-1, 232, 160, 1500) == 0
+    r1 = g.solve()                                   # 73 workgroups, room for 24
+    assert L.tqgpu_debug_occupy_wait() == 0
+    assert r1["status"] == 0 and r1["iter"] == ref["iter"], r1
+    assert L.tqgpu_timeouts(g.h) == 1
+    assert_solution_close(g.solution(), ref, TOL)
+    r2 = g.solve()                                   # device free again: still correct (launch-per-tier path while backing off)
+    assert r2["status"] == 0 and r2["iter"] == ref["iter"] and L.tqgpu_timeouts(g.h) == 1
+    assert_solution_close(g.solution(), ref, TOL)
+    g.close()
+    # a fresh mirror is back on the persistent path and undisturbed
+    g2 = gpu.TqGpu(flat["nk"], flat["nx"], flat["nu"]).upload(flat, p.lambda0)
+    assert g2.path == 2 and g2.solve()["status"] == 0 and L.tqgpu_timeouts(g2.h) == 0
+    g2.close()

@@ -325,6 +325,9 @@ class TdunesSolver:
         self._created = False
 
     def set_option(self, name, value):
+        # validate BEFORE assigning: a rejected value must not stay in the options struct
+        if getattr(self, "_created", False) and name == "maxIter" and int(value) > self.work.maxIterAtCreate:
+            raise ValueError("maxIter cannot be increased after the solver was created")
         if name in self._INT_OPTS:
             setattr(self.opts, name, int(value))
         elif name in self._DBL_OPTS:
@@ -338,8 +341,6 @@ class TdunesSolver:
                 self.opts.qp_solver[k] = 0 if value else 1
         else:
             raise KeyError(f"unknown tdunes option {name!r}")
-        if getattr(self, "_created", False) and name == "maxIter" and int(value) > self.work.maxIterAtCreate:
-            raise ValueError("maxIter cannot be increased after the solver was created")
 
     def create(self):
         """treeqp_tdunes_calculate_size + caller-owned buffer + treeqp_tdunes_create."""

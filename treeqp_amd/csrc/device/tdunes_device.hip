@@ -91,6 +91,10 @@ struct Data {            /* device pointers, passed by value */
     const double *A, *B, *b, *Qd, *Rd, *q, *r, *xmin, *xmax, *umin, *umax;
     double *Qinv, *Rinv;
     double *qmod, *rmod, *x, *u, *xUnc, *uUnc, *QinvCal, *RinvCal;
+    /* unclipped solution of phase S of the iteration in progress: the first trial sweep of a line search saves it before it
+     * overwrites xUnc / uUnc.  The reference's trial sweeps (stage_qp_clipping_solve, clipping.c:231-260) do not write xUnc,
+     * so on a MAXIMUM_ITERATIONS exit export_mu (:386-399) pairs the x of the last trial with the xUnc of the last phase S. */
+    double *xUncS, *uUncS;
     double *lam0, *lam1, *dlam, *res, *resMod;
     double *W, *CholW, *invd, *Ut, *CholUt;
     double *fval, *part_err, *part_dot;
@@ -151,7 +155,14 @@ __device__ __forceinline__ double rows_fold(double v) {
     return IS_MAX ? fmax(y0, y1) : y0 + y1;
 }
 __device__ __forceinline__ double wsum(double v) { return rows_fold<false>(row16_sum(v)); }
-__device__ __forceinline__ double wmax(double v) { return rows_fold<true>(row16_max(v)); }
+/* Maxima that feed the termination test must PROPAGATE a NaN (the reference's MAX(error, NaN) is NaN, `error < tol` is then
+ * false and the line search ends the solve with NOT_DESCENT_DIRECTION, dual_Newton_tree.c:412-442, :949); fmax / v_max_f64
+ * return the other operand.  nanmax: NaN if either operand is.  wmax: the fast v_max tree, then NaN if any lane's input was. */
+__device__ __forceinline__ double nanmax(double a, double b) { return (b > a || b != b) ? b : a; }
+__device__ __forceinline__ double wmax(double v) {
+    const double r = rows_fold<true>(row16_max(v));
+    return __builtin_amdgcn_ballot_w64(v != v) ? __builtin_nan("") : r;
+}
 
 /* historical names, used by the generic kernels: same fixed-order reductions (a ds_bpermute butterfly cost
  * ~1.4 k cycles per call, five of them per node in the stage sweep) */
@@ -232,6 +243,7 @@ __device__ void stage_body(const Tree &T, const Data &D, int mode, int k, int la
     const double *lamc = c->cur ? D.lam1 : D.lam0;
     double *lamn = c->cur ? D.lam0 : D.lam1;
     const double step = c->tau - c->tauPrev;
+    const bool save_s = mode == 1 && c->ls_iter == 1;     /* first trial of a line search: xUnc / uUnc still hold phase S of this iteration */
 
     /* lambda of the children = dual block of node k, contiguous at xoff[kid0] */
     double *lk = lds;                   /* d doubles  */
@@ -278,7 +290,8 @@ __device__ void stage_body(const Tree &T, const Data &D, int mode, int k, int la
             double acc = 0.0;
             for (int j = 0; j < nz; j++) acc = fma(P[t + (size_t)j * nz], hm[j], acc);
             zz[t] = acc;
-            if (t < nxk) { D.x[xo + t] = acc; D.xUnc[xo + t] = acc; } else { D.u[uo + t - nxk] = acc; D.uUnc[uo + t - nxk] = acc; }
+            if (t < nxk) { if (save_s) D.xUncS[xo + t] = D.xUnc[xo + t]; D.x[xo + t] = acc; D.xUnc[xo + t] = acc; }
+            else { if (save_s) D.uUncS[uo + t - nxk] = D.uUnc[uo + t - nxk]; D.u[uo + t - nxk] = acc; D.uUnc[uo + t - nxk] = acc; }
         }
         WSYNC();
         double p_quad = 0.0, p_lin = 0.0, p_cd = 0.0;
@@ -314,6 +327,7 @@ __device__ void stage_body(const Tree &T, const Data &D, int mode, int k, int la
             const double unc = qi * v, lo = D.xmin[xo + j], hi = D.xmax[xo + j];
             double xv, cal;
             if (unc >= hi) { xv = hi; cal = 0.0; } else if (unc <= lo) { xv = lo; cal = 0.0; } else { xv = unc; cal = qi; }
+            if (save_s) D.xUncS[xo + j] = D.xUnc[xo + j];
             D.xUnc[xo + j] = unc; D.x[xo + j] = xv; D.QinvCal[xo + j] = cal;
             p_qx = fma(D.Qd[xo + j] * xv, xv, p_qx);
             p_hx = fma(v, xv, p_hx);
@@ -323,6 +337,7 @@ __device__ void stage_body(const Tree &T, const Data &D, int mode, int k, int la
             const double unc = ri * v, lo = D.umin[uo + j], hi = D.umax[uo + j];
             double uv, cal;
             if (unc >= hi) { uv = hi; cal = 0.0; } else if (unc <= lo) { uv = lo; cal = 0.0; } else { uv = unc; cal = ri; }
+            if (save_s) D.uUncS[uo + j] = D.uUnc[uo + j];
             D.uUnc[uo + j] = unc; D.u[uo + j] = uv; D.RinvCal[uo + j] = cal;
             p_ru = fma(D.Rd[uo + j] * uv, uv, p_ru);
             p_hu = fma(v, uv, p_hu);
@@ -354,14 +369,14 @@ template <bool IS_MAX>
 __device__ double block_reduce(const double *v, int n, double *sh) {
     /* strided per-thread partials, wave shuffle tree, then the (<= 16) wave results in order */
     double acc = 0.0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) acc = IS_MAX ? fmax(acc, v[i]) : acc + v[i];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) acc = IS_MAX ? nanmax(acc, v[i]) : acc + v[i];
     acc = IS_MAX ? wave_max(acc) : wave_sum(acc);
     __syncthreads();                                   /* sh may still be read from a previous call */
     if ((threadIdx.x & (WAVE - 1)) == 0) sh[threadIdx.x >> 6] = acc;
     __syncthreads();
     double r = 0.0;
     const int nw = (blockDim.x + WAVE - 1) / WAVE;
-    for (int w = 0; w < nw; w++) r = IS_MAX ? fmax(r, sh[w]) : r + sh[w];
+    for (int w = 0; w < nw; w++) r = IS_MAX ? nanmax(r, sh[w]) : r + sh[w];
     return r;
 }
 
@@ -390,7 +405,7 @@ __device__ void grad_body(const Tree &T, const Data &D, int termCondition, int k
         rv += acc;
         D.res[xo + i] = rv;
         D.resMod[xo + i] = rv;
-        part = (termCondition == 2) ? fmax(part, fabs(rv)) : fma(rv, rv, part);
+        part = (termCondition == 2) ? nanmax(part, fabs(rv)) : fma(rv, rv, part);
     }
     part = (termCondition == 2) ? wave_max(part) : wave_sum(part);
     if (lane == 0) D.part_err[k] = part;
@@ -833,6 +848,7 @@ struct tqgpu_solver {
     size_t lds_fast = 0, lds_fstage = 0;
     int use_fast = 1;         /* can be switched off (TREEQP_AMD_PATH=generic) */
     int use_persist = 1;      /* whole Newton loop in one launch when every tier workgroup can be co-resident */
+    int use_persist_orig = 1, persist_backoff = 0, n_timeouts = 0;   /* see solve_after_timeout */
     bool persist_ok = false;
     PGeom geom{};
     PSync psync{};
@@ -1361,7 +1377,7 @@ int setup_persist(tqgpu_solver *s, int device) {
     s->pab = pc; s->pcst = pc + n_ab;
     PDump hd;
     const Data &D = s->D;
-    hd.x = D.x; hd.u = D.u; hd.xUnc = D.xUnc; hd.uUnc = D.uUnc; hd.qmod = D.qmod; hd.rmod = D.rmod; hd.QinvCal = D.QinvCal; hd.RinvCal = D.RinvCal;
+    hd.x = D.x; hd.u = D.u; hd.xUnc = D.xUnc; hd.uUnc = D.uUnc; hd.xUncS = D.xUncS; hd.uUncS = D.uUncS; hd.qmod = D.qmod; hd.rmod = D.rmod; hd.QinvCal = D.QinvCal; hd.RinvCal = D.RinvCal;
     hd.lam0 = D.lam0; hd.lam1 = D.lam1; hd.dlam = D.dlam; hd.lam_init = s->d_lam_init; hd.stamps = D.stamps; hd.ls_log = D.ls_log; hd.ls_log_cap = D.ls_log_cap;
     hd.hres = s->h_res;
     PDump *dd = reinterpret_cast<PDump *>(pc + n_ab + n_cst);
@@ -1445,12 +1461,14 @@ void launch_generic_iteration(tqgpu_solver *s, const Opts &O, int h, int &launch
 __global__ void k_export_all(int n_x, int n_u, int n_lam, int x_pad, int nx0, Data D, const double *lamc, double *out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     double *ox = out, *ou = ox + n_x, *ol = ou + n_u, *od = ol + n_lam, *omx = od + n_lam, *omu = omx + n_x;
+    /* MAXIMUM_ITERATIONS_REACHED with at least one iteration done: x, u are the last trial's, the unclipped values phase S's (see Data) */
+    const bool maxit = D.ctrl->status == 1 && D.ctrl->iter > 0;
     if (i < n_x) {
         const int j = i + x_pad;
         ox[i] = D.x[j];
-        omx[i] = D.dense ? 0.0 : D.Qd[j] * fma(-1.0, D.x[j], D.xUnc[j]);
+        omx[i] = D.dense ? 0.0 : D.Qd[j] * fma(-1.0, D.x[j], (maxit ? D.xUncS : D.xUnc)[j]);
     }
-    if (i < n_u) { ou[i] = D.u[i]; omu[i] = D.dense ? 0.0 : D.Rd[i] * fma(-1.0, D.u[i], D.uUnc[i]); }
+    if (i < n_u) { ou[i] = D.u[i]; omu[i] = D.dense ? 0.0 : D.Rd[i] * fma(-1.0, D.u[i], (maxit ? D.uUncS : D.uUnc)[i]); }
     if (i < n_lam) { ol[i] = lamc[nx0 + i]; od[i] = D.dlam[nx0 + i]; }
 }
 
@@ -1489,6 +1507,7 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
         const char *env = getenv("TREEQP_AMD_PATH");
         if (env && strcmp(env, "generic") == 0) { s->use_fast = 0; s->use_gpersist = 0; }
         if (env && strcmp(env, "tiered") == 0) s->use_persist = 0;
+        s->use_persist_orig = s->use_persist;
         const char *ch = getenv("TREEQP_AMD_CHUNK");
         if (ch && atoi(ch) > 0) s->chunk = atoi(ch);
     }
@@ -1506,6 +1525,7 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
     const size_t o_Qinv = cv.take(SX * Dbl), o_Rinv = cv.take(SU * Dbl);
     const size_t o_qmod = cv.take(SX * Dbl), o_x = cv.take(SX * Dbl), o_xUnc = cv.take(SX * Dbl), o_Qcal = cv.take(SX * Dbl);
     const size_t o_rmod = cv.take(SU * Dbl), o_u = cv.take(SU * Dbl), o_uUnc = cv.take(SU * Dbl), o_Rcal = cv.take(SU * Dbl);
+    const size_t o_xUncS = cv.take(SX * Dbl), o_uUncS = cv.take(SU * Dbl);
     const size_t o_lam0 = cv.take(SX * Dbl), o_lam1 = cv.take(SX * Dbl), o_dlam = cv.take(SX * Dbl), o_res = cv.take(SX * Dbl), o_resMod = cv.take(SX * Dbl);
     const size_t o_invd = cv.take(SX * Dbl);
     const size_t o_W = cv.take(s->sum_W * Dbl), o_CW = cv.take(s->sum_W * Dbl), o_Ut = cv.take(s->sum_Ut * Dbl), o_CUt = cv.take(s->sum_Ut * Dbl);
@@ -1570,6 +1590,7 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
     D.Qinv = at<double>(base, o_Qinv); D.Rinv = at<double>(base, o_Rinv);
     D.qmod = at<double>(base, o_qmod); D.rmod = at<double>(base, o_rmod); D.x = at<double>(base, o_x); D.u = at<double>(base, o_u);
     D.xUnc = at<double>(base, o_xUnc); D.uUnc = at<double>(base, o_uUnc); D.QinvCal = at<double>(base, o_Qcal); D.RinvCal = at<double>(base, o_Rcal);
+    D.xUncS = at<double>(base, o_xUncS); D.uUncS = at<double>(base, o_uUncS);
     D.lam0 = at<double>(base, o_lam0); D.lam1 = at<double>(base, o_lam1); D.dlam = at<double>(base, o_dlam);
     D.res = at<double>(base, o_res); D.resMod = at<double>(base, o_resMod); D.invd = at<double>(base, o_invd);
     D.W = at<double>(base, o_W); D.CholW = at<double>(base, o_CW); D.Ut = at<double>(base, o_Ut); D.CholUt = at<double>(base, o_CUt);
@@ -2037,7 +2058,7 @@ int solve_end(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, tqgpu_result *
             tail_done = false;
             unsigned tmo = 0;
             HIP_TRY(hipMemcpy(&tmo, s->psync.timeout, sizeof(unsigned), hipMemcpyDeviceToHost));
-            if (tmo) return fail(TQGPU_ENODEVICE, "persistent solve kernel: a bounded inter-workgroup wait timed out");
+            if (tmo) return fail(TQGPU_ETIMEOUT, "persistent solve kernel: a bounded inter-workgroup wait timed out");
         }
     }
     const int host_iter = ev_idx;
@@ -2069,13 +2090,67 @@ int solve_end(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, tqgpu_result *
 
 }  // namespace
 
-extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *res) {
-    if (!s || !o || !res) return fail(TQGPU_EINVAL, "tqgpu_solve: bad arguments");
+/* A persistent launch needs all its workgroups resident at once; that was checked at creation against THIS process's launches.
+ * When something else holds compute units (another process, another stream), a bounded wait inside the launch gives up after
+ * 0.5 s and the launch ends itself.  That is not an error of the solve: clear the sticky word, and redo the solve from the
+ * same starting duals on the path that has no residency requirement (launch per tier, or per level).  The mirror keeps off
+ * the persistent path for the next `PERSIST_BACKOFF` solves, then tries it again. */
+constexpr int PERSIST_BACKOFF = 1000;
+
+static int solve_after_timeout(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *res) {
+    HIP_TRY(hipMemsetAsync(s->psync.timeout, 0, sizeof(unsigned), s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    s->use_persist = 0;
+    s->persist_backoff = PERSIST_BACKOFF;
+    s->n_timeouts++;
+    if (getenv("TREEQP_AMD_VERBOSE")) fprintf(stderr, "[treeqp_amd] persistent launch timed out (device shared?): solving on the launch-per-tier path\n");
     SolveCtx cx;
     int rc = solve_begin(s, o, cx);
     if (rc != TQGPU_OK) return rc;
     return solve_end(s, o, cx, res);
 }
+
+extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *res) {
+    if (!s || !o || !res) return fail(TQGPU_EINVAL, "tqgpu_solve: bad arguments");
+    if (s->persist_backoff > 0 && --s->persist_backoff == 0) s->use_persist = s->use_persist_orig;
+    SolveCtx cx;
+    int rc = solve_begin(s, o, cx);
+    if (rc != TQGPU_OK) return rc;
+    rc = solve_end(s, o, cx, res);
+    if (rc == TQGPU_ETIMEOUT) rc = solve_after_timeout(s, o, res);
+    return rc;
+}
+
+/* diagnostic / test support: a foreign kernel that holds compute units.  `blocks` workgroups of 256 threads, each claiming `lds_kb`
+ * KiB of LDS (160 = a whole CU each), spin for `ms` milliseconds of wall clock (at most 3000) on a stream of their own; the call
+ * returns at once.  tqgpu_debug_occupy_wait() waits for them.  Used by the tests to take co-residency away from a persistent launch. */
+namespace {
+__global__ void __launch_bounds__(256) k_occupy(unsigned long long ticks, int *sink) {
+    extern __shared__ __attribute__((aligned(16))) double lds_occ[];
+    const unsigned long long t0 = wall_clock64();
+    if (threadIdx.x == 0) lds_occ[0] = 1.0;
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+    if (lds_occ[0] == 2.0 && sink) *sink = 1;
+}
+hipStream_t g_occ_stream = nullptr;
+}
+extern "C" int tqgpu_debug_occupy(int device, int blocks, int lds_kb, int ms) {
+    if (blocks < 1 || lds_kb < 0 || lds_kb > 160 || ms < 1) return fail(TQGPU_EINVAL, "tqgpu_debug_occupy: bad arguments");
+    if (device >= 0) HIP_TRY(hipSetDevice(device));
+    if (!g_occ_stream) HIP_TRY(hipStreamCreateWithFlags(&g_occ_stream, hipStreamNonBlocking));
+    const size_t lds = (size_t)lds_kb * 1024;
+    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_occupy), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_occupy, dim3((unsigned)blocks), dim3(256), lds, g_occ_stream, (unsigned long long)std::min(ms, 3000) * 100000ull, (int *)nullptr);
+    HIP_TRY(hipGetLastError());
+    return TQGPU_OK;
+}
+extern "C" int tqgpu_debug_occupy_wait(void) {
+    if (g_occ_stream) HIP_TRY(hipStreamSynchronize(g_occ_stream));
+    return TQGPU_OK;
+}
+
+/* diagnostic: how often a persistent launch of this mirror timed out and the solve was redone on another path */
+extern "C" int tqgpu_timeouts(const tqgpu_solver *s) { return s ? s->n_timeouts : 0; }
 
 /* Batched multi-tree solve (the usage pattern of examples/fault_tolerance.c:486-530, one QP per
  * configuration): n independent mirrors, same options.  Mirrors on the persistent path have their launches in
@@ -2149,6 +2224,7 @@ extern "C" int tqgpu_solve_batch(tqgpu_solver **solvers, int n, const tqgpu_opts
         }
         for (int k = begun_from; k < ok_to; k++) {
             int rc = solve_end(solvers[k], o, cx[(size_t)k], &results[k]);
+            if (rc == TQGPU_ETIMEOUT) rc = solve_after_timeout(solvers[k], o, &results[k]);     /* device shared: redone on its own, see tqgpu_solve */
             if (rc != TQGPU_OK && first_err == TQGPU_OK) { first_err = rc; first_msg = g_err; }
         }
         if (first_err != TQGPU_OK) break;
@@ -2177,9 +2253,9 @@ std::vector<RangeSpec> solution_ranges(tqgpu_solver *s) {
     for (int l = lb; l <= s->Nh; l++) {
         int wl = 1; for (int i = 0; i < l; i++) wl *= MD;
         const size_t f0 = (size_t)uni_first(MD, l), w = (size_t)wl / N;
-        double *xs[] = {D.x, D.xUnc, lamc, D.dlam};
+        double *xs[] = {D.x, D.xUnc, D.xUncS, lamc, D.dlam};
         for (double *a : xs) out.push_back({a + NX * f0, w * NX});
-        if (l < s->Nh) { double *us[] = {D.u, D.uUnc}; for (double *a : us) out.push_back({a + NU * f0, w * NU}); }
+        if (l < s->Nh) { double *us[] = {D.u, D.uUnc, D.uUncS}; for (double *a : us) out.push_back({a + NU * f0, w * NU}); }
     }
     return out;
 }

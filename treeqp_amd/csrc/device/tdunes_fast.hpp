@@ -407,7 +407,7 @@ __device__ __forceinline__ void forward_block(const Data &Dt, int ii, int lane, 
 __device__ __forceinline__ bool converged_now(const Data &Dt, const Opts &O, const double *parts, int nparts, lds_iptr flag_lds) {
     if (threadIdx.x < WAVE) {
         double e = 0.0;
-        for (int i = threadIdx.x; i < nparts; i += WAVE) e = (O.termCondition == 2) ? fmax(e, parts[i]) : e + parts[i];
+        for (int i = threadIdx.x; i < nparts; i += WAVE) e = (O.termCondition == 2) ? nanmax(e, parts[i]) : e + parts[i];
         e = (O.termCondition == 2) ? wmax(e) : wsum(e);
         if (O.termCondition == 1) e = sqrt(e);
         if (threadIdx.x == 0) {
@@ -474,22 +474,22 @@ __global__ void __launch_bounds__(FW * WAVE) f_back(Tree T, Data Dt, Opts O, Sha
         for (int t = 0; t < th; t++) {
             const int nb = U::width(t), f0 = U::first(l0 + t) + s * nb;
             for (int b = 0; b < nb; b++, cnt++)
-                if ((cnt & (FW - 1)) == wave) { const double v = fast_gh<NX, NU, MD>(Dt, f0 + b, lane, O.termCondition); e = (O.termCondition == 2) ? fmax(e, v) : e + v; }
+                if ((cnt & (FW - 1)) == wave) { const double v = fast_gh<NX, NU, MD>(Dt, f0 + b, lane, O.termCondition); e = (O.termCondition == 2) ? nanmax(e, v) : e + v; }
         }
         if (Sh.gh_list) {
             for (int q = blockIdx.x * FW + wave; q < Sh.gh_n; q += gridDim.x * FW) {
                 const double v = fast_gh<NX, NU, MD>(Dt, Sh.gh_list[q], lane, O.termCondition);
-                if (q < Sh.gh_counted) e = (O.termCondition == 2) ? fmax(e, v) : e + v;
+                if (q < Sh.gh_counted) e = (O.termCondition == 2) ? nanmax(e, v) : e + v;
             }
         } else {
             const int nup = U::first(l0);
-            for (int p = s * FW + wave; p < nup; p += gridDim.x * FW) { const double v = fast_gh<NX, NU, MD>(Dt, p, lane, O.termCondition); e = (O.termCondition == 2) ? fmax(e, v) : e + v; }
+            for (int p = s * FW + wave; p < nup; p += gridDim.x * FW) { const double v = fast_gh<NX, NU, MD>(Dt, p, lane, O.termCondition); e = (O.termCondition == 2) ? nanmax(e, v) : e + v; }
         }
         if (lane == 0) L.dl[wave] = e;       /* L.dl is not used by the backward sweep */
         __syncthreads();                     /* W / Ut / resMod of this subtree are read back below */
         if (threadIdx.x == 0) {
             double acc = 0.0;
-            for (int w = 0; w < FW; w++) { const double v = L.dl[w]; acc = (O.termCondition == 2) ? fmax(acc, v) : acc + v; }
+            for (int w = 0; w < FW; w++) { const double v = L.dl[w]; acc = (O.termCondition == 2) ? nanmax(acc, v) : acc + v; }
             Dt.part_err[blockIdx.x] = acc;
         }
         stamp(Dt, O, kern, sl++);
@@ -539,7 +539,7 @@ __global__ void __launch_bounds__(FW * WAVE) f_top(Tree T, Data Dt, Opts O, Shar
     if (first) {
         double e = 0.0;
         const int nblk = U::first(l1);
-        for (int p = wave; p < nblk; p += FW) { const double v = fast_gh<NX, NU, MD>(Dt, p, lane, O.termCondition); e = (O.termCondition == 2) ? fmax(e, v) : e + v; }
+        for (int p = wave; p < nblk; p += FW) { const double v = fast_gh<NX, NU, MD>(Dt, p, lane, O.termCondition); e = (O.termCondition == 2) ? nanmax(e, v) : e + v; }
         if (lane == 0) Dt.part_err[wave] = e;
         __syncthreads();
         nparts = FW;
@@ -693,6 +693,7 @@ __global__ void __launch_bounds__(FW * WAVE) f_stage(Tree T, Data Dt, Opts O, co
         const double unc = winv * v;
         double val, cal;
         if (unc >= hib) { val = hib; cal = 0.0; } else if (unc <= lob) { val = lob; cal = 0.0; } else { val = unc; cal = winv; }
+        if (trial == 1) { if (isx) Dt.xUncS[xo + j] = Dt.xUnc[xo + j]; else Dt.uUncS[uo + j] = Dt.uUnc[uo + j]; }      /* phase S of this iteration (see Data) */
         if (isx) { Dt.qmod[xo + j] = v; Dt.xUnc[xo + j] = unc; Dt.x[xo + j] = val; Dt.QinvCal[xo + j] = cal; }
         else { Dt.rmod[uo + j] = v; Dt.uUnc[uo + j] = unc; Dt.u[uo + j] = val; Dt.RinvCal[uo + j] = cal; }
         p_q = (wd * val) * val;

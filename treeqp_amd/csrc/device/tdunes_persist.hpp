@@ -69,7 +69,7 @@ struct HostRes {
 };
 
 struct PDump {
-    double *x, *u, *xUnc, *uUnc, *qmod, *rmod, *QinvCal, *RinvCal, *lam0, *lam1, *dlam;
+    double *x, *u, *xUnc, *uUnc, *xUncS, *uUncS, *qmod, *rmod, *QinvCal, *RinvCal, *lam0, *lam1, *dlam;
     const double *lam_init;
     unsigned long long *stamps;
     int *ls_log;
@@ -170,14 +170,14 @@ __device__ __forceinline__ bool p_read_top(const PSync &Sy, const u64 *src, unsi
  * by (tau - tauPrev) * dlambda per trial, tau <- beta * tau.  Trial number n of the chain (n = 1: one step of
  * `step` from the current duals, tau0 = tau after that step) is reached by replaying those axpys in order, so
  * its duals carry the roundings of the reference's sequence whatever n the evaluation starts from. */
-struct PChain { int n; double tau0, beta; };
+struct PChain { int n; double tau0, beta; bool save_s; };      /* save_s: the sweep is the first trial of a line search: keep phase S's unclipped values (Data::xUncS) */
 
 template <int NX, int NU, int MD>
 struct PLds {
     using U = Uni<NX, NU, MD>;
     static constexpr int D = U::D, NBT = U::NBT, NZ = U::NZ;
     static constexpr int SLOTS = NBT + (MD == 2 ? 8 : MD * MD);      /* nodes a workgroup can own: its blocks' owners + (bottom tier) the leaves */
-    static constexpr int NODE = 4 * NZ;                              /* per owned node: [x | u], clipped inverse Hessian, unclipped [x | u], modified gradient */
+    static constexpr int NODE = 5 * NZ;                              /* per owned node: [x | u], clipped inverse Hessian, unclipped [x | u], modified gradient, unclipped [x | u] of phase S (see Data::xUncS) */
     /* A block's tall matrix T = [W ; rhs' ; Ut] (R = D + 1 + NX rows, D columns) lives TRANSPOSED in one region: entry (q, j) at
      * j * S + q.  The wave that factorises it holds row q in lane q, so its D loads (and later its D stores) differ only by
      * an immediate offset j * S -- one address register, no per-lane stride; consecutive lanes touch consecutive doubles (no
@@ -688,7 +688,7 @@ __device__ __forceinline__ double p_stage16(const PConst &C, const PSync &Sy, PL
         double val, cal;
         if (unc >= hib) { val = hib; cal = 0.0; } else if (unc <= lob) { val = lob; cal = 0.0; } else { val = unc; cal = winv; }
         lds_ptr ns = L.node_(q);
-        if (!dry) { ns[t] = val; ns[NZ + t] = cal; ns[2 * NZ + t] = unc; ns[3 * NZ + t] = v; }
+        if (!dry) { if (ch.save_s) ns[4 * NZ + t] = ns[2 * NZ + t]; ns[t] = val; ns[NZ + t] = cal; ns[2 * NZ + t] = unc; ns[3 * NZ + t] = v; }
         if (!dry && to_parent && q == 0 && isx) {         /* my subtree root: the parent workgroup's G + H reads x and QinvCal */
             u64 *dst = Sy.ndt + ((size_t)k * 2 * NX + t) * 2;
             st_tag(dst, val, tag); st_tag(dst + 2 * NX, cal, tag);
@@ -821,7 +821,7 @@ __device__ __forceinline__ bool p_gather3(const PSync &Sy, PLds<NX, NU, MD> &L, 
         __syncthreads();
         if (*L.abort) return false;
         if (threadIdx.x == 0) {
-            for (int v = 0; v < FW; v++) { fa += L.red[3 * v]; da += L.red[3 * v + 1]; ea = err_max ? fmax(ea, L.red[3 * v + 2]) : ea + L.red[3 * v + 2]; }
+            for (int v = 0; v < FW; v++) { fa += L.red[3 * v]; da += L.red[3 * v + 1]; ea = err_max ? nanmax(ea, L.red[3 * v + 2]) : ea + L.red[3 * v + 2]; }
         }
         __syncthreads();
     }
@@ -955,8 +955,8 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
                 const int q = i >> 4, t = i & 15;
                 const int k = p_slot_node<NX, NU, MD>(q, l0, s, C);
                 lds_ptr ns = L.node_(q);
-                if (t < NX) { ns[t] = dp->x[NX * k + t]; ns[NZ + t] = dp->QinvCal[NX * k + t]; }
-                else if (t < NZ && k < C.Np) { ns[t] = dp->u[NU * k + t - NX]; ns[NZ + t] = dp->RinvCal[NU * k + t - NX]; }
+                if (t < NX) { ns[t] = dp->x[NX * k + t]; ns[NZ + t] = dp->QinvCal[NX * k + t]; ns[2 * NZ + t] = dp->xUnc[NX * k + t]; ns[4 * NZ + t] = dp->xUncS[NX * k + t]; }
+                else if (t < NZ && k < C.Np) { ns[t] = dp->u[NU * k + t - NX]; ns[NZ + t] = dp->RinvCal[NU * k + t - NX]; ns[2 * NZ + t] = dp->uUnc[NU * k + t - NX]; ns[4 * NZ + t] = dp->uUncS[NU * k + t - NX]; }
             }
         }
         __syncthreads();
@@ -1006,10 +1006,10 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
                 p_gh_load<NX, NU, MD>(C, Sy, L, p_slot_node<NX, NU, MD>(loc0, l0, s, C), loc0, !is_bottom && loc0 >= nint, nd, lane, g0);
                 if (loc1 < nbt) p_gh_load<NX, NU, MD>(C, Sy, L, p_slot_node<NX, NU, MD>(loc1, l0, s, C), loc1, !is_bottom && loc1 >= nint, nd, lane, g1);
                 double v = p_gh_compute<NX, NU, MD>(L, loc0, lane, g0, O.termCondition);
-                err = (O.termCondition == 2) ? fmax(err, v) : err + v;
+                err = (O.termCondition == 2) ? nanmax(err, v) : err + v;
                 if (loc1 < nbt) {
                     v = p_gh_compute<NX, NU, MD>(L, loc1, lane, g1, O.termCondition);
-                    err = (O.termCondition == 2) ? fmax(err, v) : err + v;
+                    err = (O.termCondition == 2) ? nanmax(err, v) : err + v;
                 }
             }
             if (lane == 0) L.part[4 * wave] = err;
@@ -1018,7 +1018,7 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
             if (threadIdx.x == 0) {
                 /* termination partial of my blocks to the top workgroup */
                 err = 0.0;
-                for (int w = 0; w < FW; w++) { const double v = L.part[4 * w]; err = (O.termCondition == 2) ? fmax(err, v) : err + v; }
+                for (int w = 0; w < FW; w++) { const double v = L.part[4 * w]; err = (O.termCondition == 2) ? nanmax(err, v) : err + v; }
                 st_tag(Sy.errs + (size_t)wg * 2, err, tag_e);
             }
         }
@@ -1164,7 +1164,7 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
         }
         if (gone) { if (*L.abort == 2) { verdict = 2; gone = false; } else break; }
         double step = 1.0;
-        PChain ch{1, 1.0, O.beta};
+        PChain ch{1, 1.0, O.beta, true};
         if (verdict == 2) {
             /* The trial this pass was built on was rejected: drop the pass (it only touched per-iteration LDS data and
              * hand-over words tagged with this pass) and finish the line search.  A trial needs a reduction over all
@@ -1229,7 +1229,7 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
                 if (is_top && threadIdx.x == 0) __hip_atomic_store(Sy.halt, Sy.seq, RLX, AGENT);
                 break;
             }
-            ch.n = nacc;
+            ch.n = nacc; ch.save_s = false;
             decided = true;
         } else {
             have_dl = true;
@@ -1279,10 +1279,10 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
                 lds_cptr ns = L.node_(q);
                 if (t < NX) {
                     const int o = NX * k + t;
-                    dp->x[o] = ns[t]; dp->QinvCal[o] = ns[NZ + t]; dp->xUnc[o] = ns[2 * NZ + t]; dp->qmod[o] = ns[3 * NZ + t];
+                    dp->x[o] = ns[t]; dp->QinvCal[o] = ns[NZ + t]; dp->xUnc[o] = ns[2 * NZ + t]; dp->qmod[o] = ns[3 * NZ + t]; dp->xUncS[o] = ns[4 * NZ + t];
                 } else if (t < NZ && k < C.Np) {
                     const int o = NU * k + t - NX;
-                    dp->u[o] = ns[t]; dp->RinvCal[o] = ns[NZ + t]; dp->uUnc[o] = ns[2 * NZ + t]; dp->rmod[o] = ns[3 * NZ + t];
+                    dp->u[o] = ns[t]; dp->RinvCal[o] = ns[NZ + t]; dp->uUnc[o] = ns[2 * NZ + t]; dp->rmod[o] = ns[3 * NZ + t]; dp->uUncS[o] = ns[4 * NZ + t];
                 }
             }
             double *ldst = cur ? dp->lam1 : dp->lam0;

@@ -348,8 +348,9 @@ return_t treeqp_tdunes_solve(const tree_qp_in *qp_in, tree_qp_out *qp_out,
 
     treeqp_tic(&total_tmr);
     treeqp_tic(&interface_tmr);
-    assert(timings->num_iter >= opts->maxIter &&
-        "Number of iterations cannot be increased after initializing solver");
+    /* the reference asserts here ("Number of iterations cannot be increased after initializing solver"); an option the
+     * workspace was not sized for is reported like any other invalid option instead of aborting the caller */
+    if (timings->num_iter < opts->maxIter) return TREEQP_INVALID_OPTION;
 
     work->lineSearchRestartCounter = 0;
     return_t status = validate_opts(opts);
@@ -408,7 +409,12 @@ return_t treeqp_tdunes_solve(const tree_qp_in *qp_in, tree_qp_out *qp_out,
     /* --- Newton loop on the device */
     treeqp_tic(&solver_tmr);
     tqgpu_result res;
-    DEV_CALL(tqgpu_solve(work->device, &dopts, &res));
+    if (tqgpu_solve(work->device, &dopts, &res) != TQGPU_OK) {
+        /* a failure of the device at run time (a lost device, a launch that cannot be placed) is the solver's failure, not a
+         * configuration error of the caller: reported, qp_out untouched -- the caller decides (an MPC loop may hold its last input) */
+        fprintf(stderr, "[TREEQP] treeqp_tdunes_solve: device solve failed: %s\n", tqgpu_last_error());
+        return TREEQP_UNKNOWN_ERROR;
+    }
     const double solver_time = treeqp_toc(&solver_tmr);
 
     work->lsIter = res.ls_last;
