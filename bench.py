@@ -2,20 +2,28 @@
 """bench.py -- dual-Newton iterations/s of the tdunes hot path on MI355X.
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
-For N > 1 it is launched under torch.distributed.run (one rank per GPU, RCCL).
+For N > 1 it is launched under torch.distributed.run (one rank per GPU, RCCL); started WITHOUT the
+launcher (`python bench.py --gpus N`, WORLD_SIZE unset) it starts the launcher itself as a child
+process -- before anything touches a GPU -- and forwards the child's JSON line.
 
 * step      = one full tdunes solve of the workload from the same resident lambda0 (the reference's
               own timing protocol: examples/spring_mass_dual_newton_tree.c:135-140); QP data,
               index tables and lambda0 are resident in HBM before the timed region starts.
 * value     = Newton iterations of ALL ranks / wall time of the K steps (max over ranks).
-* workload  = BASELINE.json configs[1] ("C2"): linear-chain spring-mass tree nx=8, nu=3, 10 levels,
-              branching 2 -> 1023 nodes.  N > 1, default `--mode batch`: one such tree per
-              GPU (independent scenario trees, weak scaling, no data-path collective).  `--mode shard`:
-              ONE tree, subtrees partitioned over the ranks, two small RCCL all-gathers per Newton
-              iteration (strong scaling, latency-bound by construction).
+* workload  = BASELINE.json configs[1] ("C2", the configuration the metric is quoted on): linear-chain
+              spring-mass tree nx=8, nu=3, 10 levels, branching 2 -> 1023 nodes.
+              --workload C1|C3|C4|C5 run the other BASELINE configurations through the same harness
+              (C5: a batch of pruned scenario trees per step, the shape of fault_tolerance.c:486-530).
+* N > 1     = default `--mode batch`: one tree per GPU (independent scenario trees, weak scaling, no
+              data-path collective), and -- in the same line, under "sharded" -- ONE C3 tree partitioned by
+              subtrees over the N ranks with two small RCCL all-gathers per Newton iteration (SURVEY.md
+              §8e; strong scaling, latency-bound by construction).  `--mode shard` makes that the headline.
 * roofline  = algorithmic bytes of the Newton iterations (closed form of SURVEY.md §8d, evaluated
               by tqgpu_iteration_cost) / device time between HIP events recorded on the solver's own
               stream around each solve (tqgpu_get_device_times), against the 8 TB/s HBM3E peak.
+* critical_path = the dependent chain that actually bounds a solve: tree levels x measured floor of a level step in
+              isolation (tools/microbench/level_bench, profiles/r02_level_bench.txt) + tier hand-overs, against the
+              measured period of a pass (solves stopped after 1 and 2 iterations).
 * cpu_baseline = the CPU oracle ("port": restatement of the reference algorithm, NOT BLASFEO
               HIGH_PERFORMANCE) on the same workload, min over repetitions, rank 0 at N=1 only.
 """
@@ -24,6 +32,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -36,40 +45,116 @@ for p in (ROOT, ROOT / "oracle"):
         sys.path.insert(0, str(p))
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+CLOCK_GHZ = 2.4              # shader clock the level floors were measured at (cycles -> us)
 
 
 def make_workload(name: str):
-    from treeqp_amd import problems as P
+    """-> (list of flat QPs solved per step, description, solver options)"""
+    from treeqp_amd import capi, problems as P
+
+    def lti(p):
+        nk = p.nk()
+        nx = np.full(p.Nn, p.nx, dtype=np.int32)
+        nu = np.where(nk > 0, p.nu, 0).astype(np.int32)
+        qp = capi.TreeQp(nx, nu, nk).fill_lti(p)      # QP built through the reference-compatible host API
+        return dict(flat=qp.flat(), lambda0=p.lambda0, qp=qp, nodes=int(p.Nn))
+
     if name == "C2":
-        return P.linear_chain(2, 9, 9), "linear_chain nx=8 nu=3 md=2 Nr=Nh=9 (1023 nodes), |u|<=0.5, lambda0=0, default opts"
+        return [lti(P.linear_chain(2, 9, 9))], "linear_chain nx=8 nu=3 md=2 Nr=Nh=9 (1023 nodes), |u|<=0.5, lambda0=0, default opts", {}
     if name == "C3":
-        return P.linear_chain(2, 11, 11), "linear_chain nx=8 nu=3 md=2 Nr=Nh=11 (4095 nodes), |u|<=0.5"
+        return [lti(P.linear_chain(2, 11, 11))], "linear_chain nx=8 nu=3 md=2 Nr=Nh=11 (4095 nodes), |u|<=0.5", {}
     if name == "C1":
-        return P.spring_mass(), "spring_mass example data md=3 Nr=2 Nh=10 (85 nodes)"
+        return [lti(P.spring_mass())], "spring_mass example data md=3 Nr=2 Nh=10 (85 nodes)", {}
+    if name == "C4":
+        f = P.random_clipping_qp()
+        return [dict(flat=f.as_dict(), lambda0=f.lambda0, qp=None, nodes=len(f.nk))], \
+            "random_clipping_qp nx=20 nu=10 md=3, 8 levels (3280 nodes, dual blocks 60x60), unconstrained, opts of random_qp.c:131-133", dict(f.opts)
+    if name == "C5":
+        fs = [P.pruned_chain_qp(seed=7 + i) for i in range(256)]
+        return [dict(flat=f.as_dict(), lambda0=f.lambda0, qp=None, nodes=len(f.nk)) for f in fs], \
+            "256 pruned scenario trees (nx=8 nu=2, horizon 10, 1-3 children, <= 40 leaves, 50-310 nodes each; seeds 7..262), one batched call per step", dict(fs[0].opts)
     raise SystemExit(f"unknown workload {name}")
 
 
-def cpu_baseline(p, flat, budget_s: float = 12.0):
+def cpu_baseline(items, opts, budget_s: float = 12.0):
     """Oracle timed on the host cores (bounded sample)."""
     import oracle_py as orc
     ncpu = os.cpu_count() or 1
+    sample = items[:8]                      # C5: the first 8 trees of the batch
     best = {}
     for threads in sorted({1, min(ncpu, 16)}):
-        o = orc.default_opts(num_threads=threads)
+        o = orc.default_opts(num_threads=threads, **opts)
         t_end = time.perf_counter() + budget_s / 2
         tmin, iters, reps = float("inf"), 0, 0
-        while reps < 20 and (time.perf_counter() < t_end or reps < 3):
-            s = orc.solve(flat, o, p.lambda0, traces=False)
-            tmin = min(tmin, s["solver_time"])
-            iters = s["iter"]
+        while reps < 20 and (time.perf_counter() < t_end or reps < 2):
+            t, it = 0.0, 0
+            for w in sample:
+                s = orc.solve(w["flat"], o, w["lambda0"], traces=False)
+                t += s["solver_time"]
+                it += s["iter"]
+            if t < tmin:
+                tmin, iters = t, it
             reps += 1
         best[threads] = (iters / tmin, tmin, reps, iters)
     threads = max(best, key=lambda t: best[t][0])
     v, tmin, reps, iters = best[threads]
     detail = "; ".join(f"{t} thr: {best[t][0]:.0f} it/s" for t in sorted(best))
     return {"value": v, "unit": "newton_iter/s", "cores": threads, "kind": "port",
-            "sample": f"min solver_time over {reps} full solves ({iters} Newton iterations each) of the same workload; "
+            "sample": f"min solver_time over {reps} passes over {len(sample)} tree(s) of the workload ({iters} Newton iterations per pass); "
                       f"CPU restatement (oracle), gcc -O3, not BLASFEO; {detail}; host has {ncpu} logical cores"}
+
+
+def level_floors():
+    """floors of a level step in isolation (cycles), from the committed microbenchmark output"""
+    out = {}
+    f = ROOT / "profiles" / "r02_level_bench.txt"
+    if f.exists():
+        import re
+        for line in f.read_text().splitlines():
+            m = re.match(r"^(.*?)\s+(\d+) cycles\s*$", line)
+            if m:
+                out[m.group(1).strip()] = float(m.group(2))
+    return out
+
+
+def critical_path(g, p_levels: int, n_tiers: int, reps: int = 60):
+    """period of a pass = t(maxIter=2) - t(maxIter=1) (device times), against the chain of level floors"""
+    def med(k):
+        for _ in range(10):
+            g.solve(maxIter=k)
+        for _ in range(reps):
+            g.solve(maxIter=k)
+        return float(np.median(g.device_times(reps))) * 1e6
+    t1, t2 = med(1), med(2)
+    fl = level_floors()
+    back = fl.get("backward level (load, factor, store, schur, barrier)")
+    fwd = fl.get("forward sweep of a tier (3 levels, one barrier)")
+    sg = (fl.get("stage sweep, 15 nodes (+ barrier)", 0.0) + fl.get("G + H, 7 blocks (+ barrier)", 0.0))
+    handover_us = 0.8                     # MI355X_MICROARCH.md, price list row handoff-1to1 (idle, 8 B .. 4 KB)
+    out = {"pass_us": t2 - t1, "fixed_us": t1 - (t2 - t1), "levels": p_levels, "tiers": n_tiers,
+           "note": "pass = G+H, backward sweep (one dependent block factorisation per level), forward sweep, trial sweep; "
+                   "fixed = launch, state load, first sweep, last verdict, write-back"}
+    if back:
+        floor = (p_levels * back + n_tiers * (fwd or 0.0) + sg) / (CLOCK_GHZ * 1e3) + 2 * (n_tiers - 1) * handover_us
+        out.update({"floor_us": floor, "achieved_over_floor": (t2 - t1) / floor,
+                    "floor_terms": {"backward_level_cycles": back, "forward_tier_cycles": fwd, "stage_plus_gh_cycles": sg,
+                                    "handover_us": handover_us, "handovers": 2 * (n_tiers - 1)},
+                    "floor_source": "profiles/r02_level_bench.txt (tools/microbench/level_bench on MI355X), cycles at 2.4 GHz"})
+    return out
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without the launcher: start it as a child BEFORE any HIP / torch.cuda call and forward its line."""
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        sys.stderr.write(r.stdout[-2000:] + r.stderr[-4000:])
+        raise SystemExit(f"bench.py --gpus {args.gpus}: the torch.distributed.run child failed (rc {r.returncode})")
+    print(lines[-1], flush=True)
+    raise SystemExit(0)
 
 
 def main():
@@ -79,11 +164,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-batched", action="store_true", help="skip the batched-throughput leg (profiling runs: only the timed launches in the kernel statistics)")
-    ap.add_argument("--mode", choices=["batch", "shard"], default="batch", help="N > 1: independent trees (weak) or one sharded tree (strong)")
+    ap.add_argument("--no-batched", action="store_true", help="skip the batched-throughput sweep and the critical-path leg (profiling runs: only the timed launches in the kernel statistics)")
+    ap.add_argument("--mode", choices=["batch", "shard"], default="batch", help="N > 1: independent trees (weak) or one sharded tree (strong) as the headline")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--trees", type=int, default=1, help="independent trees per GPU solved by one batched call per step (throughput mode; default 1 = the latency metric)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -101,41 +189,44 @@ def main():
             torch.cuda.set_device(local_rank)
             dist.init_process_group(args.backend)
     red_dev = "cuda" if args.backend == "nccl" else "cpu"
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     from treeqp_amd import capi
     if capi.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: the tdunes hot path has no CPU fallback")
+    dev = local_rank if world > 1 else -1
 
-    p, desc = make_workload(args.workload)
-    nk = p.nk()
-    nx = np.full(p.Nn, p.nx, dtype=np.int32)
-    nu = np.where(nk > 0, p.nu, 0).astype(np.int32)
-    # QP built through the reference-compatible host API, then made resident through the C-ABI
-    qp = capi.TreeQp(nx, nu, nk).fill_lti(p)
-    flat = qp.flat()
-    g = capi.TqGpu(nk, nx, nu, device=local_rank if world > 1 else -1).upload(flat, p.lambda0)
-    extra = [capi.TqGpu(nk, nx, nu, device=local_rank if world > 1 else -1).upload(flat, p.lambda0) for _ in range(max(0, args.trees - 1))]
-    mirrors = [g] + extra
+    items, desc, opts = make_workload(args.workload)
     shard = world > 1 and args.mode == "shard"
-    if shard and extra:
-        raise SystemExit("--trees > 1 is a batch-mode option")
+    if shard and (args.trees > 1 or len(items) > 1):
+        raise SystemExit("--mode shard solves ONE tree")
+
+    def mirror(w):
+        f = w["flat"]
+        return capi.TqGpu(f["nk"], f["nx"], f["nu"], device=dev).upload(f, w["lambda0"])
+
+    mirrors = [mirror(w) for w in items for _ in range(args.trees)]
+    g = mirrors[0]
 
     def solve_step():
-        """One step: every tree of this rank once; returns (iterations, line-search trials, launches, last result)."""
-        if not extra:
-            r = g.solve()
+        """One step: every tree of this rank once; returns (iterations, line-search trials, launches, first result)."""
+        if len(mirrors) == 1:
+            r = g.solve(**opts)
             return r["iter"], r["ls_total"], r["n_launches"], r
-        rs = capi.solve_batch(mirrors)
+        rs = capi.solve_batch(mirrors, **opts)
         return sum(r["iter"] for r in rs), sum(r["ls_total"] for r in rs), sum(r["n_launches"] for r in rs), rs[0]
-    if shard:
+
+    def shard_setup(m):
         import torch
         idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
             idt.copy_(torch.frombuffer(bytearray(capi.shard_unique_id()), dtype=torch.uint8))
         dist.broadcast(idt, src=0)
-        g.shard_init(rank, world, bytes(idt.cpu().numpy().tobytes()))
+        m.shard_init(rank, world, bytes(idt.cpu().numpy().tobytes()))
+
+    if shard:
+        shard_setup(g)
 
     def barrier():
         if dist is not None:
@@ -181,21 +272,68 @@ def main():
     if shard:
         g.shard_gather_solution()
 
+    # N > 1, batch mode: ALSO the configuration north_star names -- one C3 tree sharded by subtrees over the ranks (RCCL)
+    sharded = None
+    if world > 1 and not shard:
+        try:
+            c3, c3desc, _ = make_workload("C3")
+            m3 = mirror(c3[0])
+            shard_setup(m3)
+            for _ in range(5):
+                r3 = m3.solve()
+            barrier()
+            ts = time.perf_counter()
+            ksteps = max(10, min(args.steps, 50))
+            it3 = 0
+            for _ in range(ksteps):
+                r3 = m3.solve()
+                it3 += r3["iter"]
+            m3.device_times(1)
+            barrier()
+            te = time.perf_counter() - ts
+            import torch
+            tt = torch.tensor([te], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            sharded = {"workload": f"C3: {c3desc}", "value": it3 / float(tt.item()), "unit": "newton_iter/s", "steps": ksteps, "ms_per_step": 1e3 * float(tt.item()) / ksteps,
+                       "scaling": "strong", "status": int(r3["status"]), "newton_iter_per_solve": it3 / ksteps,
+                       "parallelism": f"one tree, subtrees partitioned over {world} ranks, 2 RCCL all-gathers per Newton iteration (launch-per-tier kernels)"}
+            m3.close()
+        except Exception as e:          # the replica line must not be lost to a failure of the extra leg
+            sharded = {"error": str(e)[:300]}
+
     if rank == 0:
-        sol = g.solution()
-        import ctypes as C
-        qp.set_solution(sol)
-        kkt = qp.max_kkt_res()
-        it_per_solve = iters / args.steps / len(mirrors)
+        n_trees = len(mirrors)
+        kkt = None
+        if items[0]["qp"] is not None and n_trees == 1:
+            qp = items[0]["qp"]
+            qp.set_solution(g.solution())
+            kkt = qp.max_kkt_res()
+        it_per_solve = iters / args.steps / n_trees
         ls_per_iter = ls / max(iters, 1)
-        bytes_it, flops_it = g.iteration_cost(max(1, round(ls_per_iter)))
-        # dominant kernel: one f_persist launch = one solve (persistent path); algorithmic bytes per launch =
-        # closed-form bytes per Newton iteration x the iterations of the launch, over the launch's duration
-        achieved = bytes_it * (iters / len(mirrors)) / dev_time / 1e9          # one tree's launches (mirror 0)
+        # algorithmic bytes: bytes per Newton iteration (closed form, per tree) x the iterations of the launch
+        n_ls = max(1, round(ls_per_iter))
+        if len(items) > 1:
+            # a batch of different trees per step (C5): ONE launch per step carries them all; its duration is taken from the wall
+            # clock of the step (the per-mirror event pairs bracket the enqueue, not the shared launch)
+            rs = capi.solve_batch(mirrors, **opts)
+            costs = [m.iteration_cost(n_ls) for m in mirrors]
+            bytes_step = float(sum(b * rr["iter"] for (b, _), rr in zip(costs, rs)))
+            bytes_it = float(np.mean([b for b, _ in costs]))
+            flops_it = float(np.mean([f for _, f in costs]))
+            launch_s = tmax / args.steps
+        else:
+            bytes_it, flops_it = g.iteration_cost(n_ls)
+            bytes_step = bytes_it * it_per_solve                   # mirror 0's launch: one tree
+            launch_s = dev_time / args.steps                       # HIP events on mirror 0's stream around its launch
+        achieved = bytes_step / launch_s / 1e9
         traffic = None
         tf = ROOT / "profiles" / f"traffic_{args.workload}.json"
-        if tf.exists() and g.path == 2:
+        if tf.exists() and g.path == 2 and n_trees == 1:
             traffic = json.loads(tf.read_text()).get("bytes_per_launch")        # from the committed PMC passes
+        kernel = {2: "f_persist / f_mpersist: the whole solve in one launch (first sweep + all Newton iterations)",
+                  3: "g_persist(_batch): the whole solve in one launch of one workgroup per tree",
+                  1: "one Newton iteration = f_back x tiers, f_top, f_fwd x tiers, f_stage, k_ls_decide (tiered path)",
+                  0: "one Newton iteration = k_grad, k_check, k_hess(_w), k_factor(_w) x levels, k_forward(_w) x levels, k_ls_*, k_stage (launch per level; _w = MFMA workgroup-per-block kernels)"}[g.path]
         out = {
             "metric": "dual_newton_iterations_per_second",
             "value": tot_iters / tmax,
@@ -209,42 +347,59 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {desc}", "nodes": int(p.Nn), "newton_iter_per_solve": it_per_solve,
+            "config": {"workload": f"{args.workload}: {desc}", "nodes": int(sum(w["nodes"] for w in items)), "newton_iter_per_solve": it_per_solve,
                        "ls_trials_per_iter": ls_per_iter, "ms_per_newton_iter": 1e3 * tmax / max(iters, 1),
-                       "device_ms_per_newton_iter": 1e3 * dev_time / max(iters, 1),
-                       "kernel_launches_per_solve": launches / args.steps / len(mirrors), "max_kkt_residual": kkt, "trees_per_gpu": len(mirrors),
+                       "device_ms_per_newton_iter": 1e3 * dev_time / max(iters, 1) * (n_trees if len(items) > 1 else 1),
+                       "kernel_launches_per_solve": launches / args.steps / n_trees, "max_kkt_residual": kkt, "trees_per_gpu": n_trees,
+                       "device_path": int(g.path),
                        "parallelism": ("one tree sharded by subtrees, 2 RCCL all-gathers per Newton iteration" if shard else
                                        "1 tree per GPU (independent scenario trees), no collective") if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": ("f_persist: the whole solve in one launch (first sweep + all Newton iterations)" if g.path == 2 else "one Newton iteration = f_back x tiers, f_top, f_fwd x tiers, f_stage, k_ls_decide (tiered path)") if g.fused else
-                                   "one Newton iteration = k_grad,k_check,k_hess,k_factor x levels,k_forward x levels,k_ls_*,k_stage (generic path)",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kernel,
                          "traffic_note": "memory-side bytes per launch (FETCH_SIZE raw + WRITE_SIZE) from profiles/traffic_<workload>.json; one launch = one solve",
-                         "launch_us": 1e6 * dev_time / args.steps, "algorithmic_bytes_per_launch": bytes_it * it_per_solve,
+                         "launch_us": 1e6 * launch_s, "algorithmic_bytes_per_launch": bytes_step,
                          "algorithmic_bytes_per_iteration": bytes_it, "algorithmic_flops_per_iteration": flops_it,
-                         "note": "latency-bound: a chain of dependent 25x16 block factorisations per tree level; the solve's state is LDS-resident, so memory traffic is far below the algorithmic bytes"},
+                         "note": "latency-bound: a chain of dependent block factorisations per tree level; on the persistent paths state and constants are LDS-resident, so memory traffic is far below the algorithmic bytes"},
         }
-        if world == 1 and args.trees == 1 and g.path == 2 and not args.no_batched:
-            # throughput leg (reported beside the latency metric, never as `value`): independent trees of the same
-            # workload solved by one batched call per step -- what a scenario sweep (fault_tolerance.c:486-530) gets
-            nb = 3
-            more = [capi.TqGpu(nk, nx, nu).upload(flat, p.lambda0) for _ in range(nb - 1)]
-            batch = [g] + more
-            for _ in range(10):
-                capi.solve_batch(batch)
-            tb0 = time.perf_counter()
-            nit = 0
-            ksteps = max(20, min(args.steps, 200))
-            for _ in range(ksteps):
-                nit += sum(rr["iter"] for rr in capi.solve_batch(batch))
-            g.device_times(1)                                            # synchronises
-            tb = time.perf_counter() - tb0
-            out["batched"] = {"trees_per_gpu": nb, "value": nit / tb, "unit": "newton_iter/s", "steps": ksteps, "ms_per_step": 1e3 * tb / ksteps,
-                              "note": "independent trees per GPU, one persistent launch each, concurrently resident; throughput, not the latency metric"}
+        if sharded is not None:
+            out["sharded"] = sharded
+        if world == 1 and n_trees == 1 and g.path == 2 and not args.no_batched:
+            # the dependent chain that bounds a solve, against its measured floors
+            geo = g.geometry()
+            out["critical_path"] = critical_path(g, geo["levels"], geo["tiers"])
+            # throughput leg (reported beside the latency metric, never as `value`): independent trees of the same workload solved by
+            # one batched call per step -- what a scenario sweep (fault_tolerance.c:486-530) gets -- swept up to what is co-resident
+            cap = {"workgroups_per_tree": geo["workgroups"], "capacity": geo["capacity"], "compute_units": geo["compute_units"]}
+            sweep = []
+            more = []
+            nb = 1
+            while True:
+                while len(more) < nb - 1:
+                    more.append(mirror(items[0]))
+                batch = [g] + more[:nb - 1]
+                for _ in range(5):
+                    capi.solve_batch(batch)
+                ksteps = max(20, min(args.steps, 100))
+                tb0 = time.perf_counter()
+                nit = 0
+                for _ in range(ksteps):
+                    nit += sum(rr["iter"] for rr in capi.solve_batch(batch))
+                g.device_times(1)                                            # synchronises
+                tb = time.perf_counter() - tb0
+                sweep.append({"trees_per_gpu": nb, "value": nit / tb, "ms_per_step": 1e3 * tb / ksteps})
+                nxt = nb + 1 if nb < 4 else nb + max(1, nb // 3)
+                if nxt * cap["workgroups_per_tree"] > cap["capacity"] or nxt > 24:
+                    break
+                nb = nxt
+            best = max(sweep, key=lambda e: e["value"])
+            out["batched"] = {"trees_per_gpu": best["trees_per_gpu"], "value": best["value"], "unit": "newton_iter/s", "ms_per_step": best["ms_per_step"],
+                              "roofline_frac": best["value"] * bytes_it / 1e9 / HBM_PEAK_GBS, "sweep": sweep,
+                              "capacity": cap, "note": "independent trees per GPU, one persistent launch each, concurrently resident (every workgroup of every launch must be "
+                                                       "resident: trees_per_gpu x workgroups_per_tree <= capacity); throughput, not the latency metric"}
             for m in more:
                 m.close()
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(p, flat)
+            out["cpu_baseline"] = cpu_baseline(items, opts)
         print(json.dumps(out), flush=True)
     for m in mirrors:
         m.close()

@@ -100,6 +100,8 @@ int tqgpu_get_solution(tqgpu_solver *s, double *x, double *u, double *lam, doubl
  * 0: generic per-level kernels.  TREEQP_AMD_PATH=generic|tiered in the environment at create time
  * forces the lower paths. */
 int tqgpu_uses_fused_path(const tqgpu_solver *s);
+/* geometry of the persistent launch: block levels, tiers, workgroups per launch, co-resident workgroup capacity of the device, CUs */
+int tqgpu_geometry(const tqgpu_solver *s, int *levels, int *tiers, int *workgroups, int *capacity, int *compute_units);
 /* diagnostic: persistent launches of this mirror that timed out (device shared with other work) and were redone on another path */
 int tqgpu_timeouts(const tqgpu_solver *s);
 

@@ -527,6 +527,12 @@ class TqGpu:
         self._chk(lib().tqgpu_get_iteration_log(self.h, _ip(ls), _dp(tt), cap))
         return ls, tt
 
+    def geometry(self) -> dict:
+        """block levels, tiers and workgroups of the persistent launch, and how many such workgroups the device holds at once"""
+        v = [C.c_int() for _ in range(5)]
+        self._chk(lib().tqgpu_geometry(self.h, *[C.byref(x) for x in v]))
+        return dict(zip(("levels", "tiers", "workgroups", "capacity", "compute_units"), [x.value for x in v]))
+
     def iteration_cost(self, n_ls=1):
         b, f = C.c_double(), C.c_double()
         self._chk(lib().tqgpu_iteration_cost(self.h, int(n_ls), C.byref(b), C.byref(f)))

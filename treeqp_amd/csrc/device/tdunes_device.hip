@@ -2149,6 +2149,18 @@ extern "C" int tqgpu_debug_occupy_wait(void) {
     return TQGPU_OK;
 }
 
+/* geometry of the persistent launch of this mirror: block levels of the tree, tiers, workgroups of one launch, workgroups of
+ * such launches the device holds at once (co-residency: what tqgpu_solve_batch may have in flight together), compute units */
+extern "C" int tqgpu_geometry(const tqgpu_solver *s, int *levels, int *tiers, int *workgroups, int *capacity, int *compute_units) {
+    if (!s) return fail(TQGPU_EINVAL, "null solver");
+    if (levels) *levels = s->Nh;
+    if (tiers) *tiers = s->fast >= 0 ? s->n_tiers : 0;
+    if (workgroups) *workgroups = s->persist_ok ? s->geom.G : 0;
+    if (capacity) *capacity = s->persist_ok ? s->co_capacity : 0;
+    if (compute_units) *compute_units = s->n_cu;
+    return TQGPU_OK;
+}
+
 /* diagnostic: how often a persistent launch of this mirror timed out and the solve was redone on another path */
 extern "C" int tqgpu_timeouts(const tqgpu_solver *s) { return s ? s->n_timeouts : 0; }
 
