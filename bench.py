@@ -274,7 +274,7 @@ def main():
 
     # N > 1, batch mode: ALSO the configuration north_star names -- one C3 tree sharded by subtrees over the ranks (RCCL)
     sharded = None
-    if world > 1 and not shard:
+    if world > 1 and not shard and args.backend == "nccl":      # (a gloo rehearsal puts several ranks on one device, which RCCL refuses)
         try:
             c3, c3desc, _ = make_workload("C3")
             m3 = mirror(c3[0])

@@ -116,6 +116,11 @@ int tqgpu_get_iteration_log(tqgpu_solver *s, int *ls_iters, double *iter_times, 
  * trials (closed form of SURVEY.md §8(d) generalised to per-node dimensions) */
 int tqgpu_iteration_cost(const tqgpu_solver *s, int n_ls, double *bytes, double *flops);
 
+/* The partition plan of the sharded mode without a device: which tier is the highest partitioned one, the boundary level, the
+ * blocks above the bottom tier whose gradient / Hessian this rank computes (the first gh_counted of them enter its termination
+ * partial) and the nodes it owns.  Host arithmetic only (the CPU tests compare it with treeqp_amd/sharding.py). */
+int tqgpu_shard_plan(int md, int nx, int Nh, int nranks, int rank, int *part_top, int *boundary_level, int *gh_counted,
+                     int *gh_list, int gh_cap, int *gh_n, int *owned_nodes, int owned_cap, int *owned_n);
 /* ---- one tree sharded over several devices --------------------------------------
  * Every rank creates a mirror of the WHOLE tree and uploads the whole problem; tqgpu_shard_init then
  * restricts the rank's work to a contiguous range of subtrees (tiers above the partition boundary

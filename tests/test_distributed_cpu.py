@@ -34,6 +34,25 @@ def test_plan_covers_every_node_exactly_once():
     assert p8.lb == 3 and p8.boundary_range == (7 + 3, 1) and p8.exchange_doubles["exchange1"] == 8 * 73
 
 
+def test_product_planner_is_the_python_planner(capi):
+    """shard_build_lists (the product, C) and treeqp_amd/sharding.py (the restatement the gloo tests exercise) cannot drift apart:
+    the product's host-only planner, exported as tqgpu_shard_plan, gives the same plan for every rank of every case."""
+    import ctypes as C
+    L = capi.lib()
+    for md, Nh, n in [(2, 9, 1), (2, 9, 2), (2, 9, 4), (2, 9, 8), (2, 11, 2), (2, 11, 4), (2, 11, 8), (2, 6, 8), (3, 4, 3), (4, 4, 4)]:
+        for r in range(n):
+            pl = sharding.plan(md, Nh, n, r)
+            v = [C.c_int() for _ in range(5)]          # part_top, boundary level, gh_counted, gh_n, owned_n
+            assert L.tqgpu_shard_plan(md, 8, Nh, n, r, C.byref(v[0]), C.byref(v[1]), C.byref(v[2]), None, 0, C.byref(v[3]), None, 0, C.byref(v[4])) == 0
+            gh = (C.c_int * max(1, v[3].value))()
+            own = (C.c_int * max(1, v[4].value))()
+            assert L.tqgpu_shard_plan(md, 8, Nh, n, r, None, None, None, gh, v[3].value, None, own, v[4].value, None) == 0
+            assert (v[0].value, v[1].value, v[2].value) == (pl.part_top, pl.lb, pl.gh_counted), (md, Nh, n, r)
+            assert list(gh)[:v[3].value] == list(pl.gh_list)
+            assert list(own)[:v[4].value] == list(pl.owned_nodes)
+    assert L.tqgpu_shard_plan(2, 8, 3, 64, 0, None, None, None, None, 0, None, None, 0, None) != 0      # too many ranks
+
+
 def test_plan_rejects_too_many_ranks():
     with pytest.raises(ValueError):
         sharding.plan(2, 3, 64, 0)

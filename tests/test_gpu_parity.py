@@ -486,6 +486,9 @@ def test_fused_path_multi_trial_line_search(gpu, orc):
 # --- one tree sharded over several (virtual) ranks -----------------------------------------------
 
 SHARD_CASES = [
+    ("c3_4095_n2", lambda: P.linear_chain(2, 11, 11), 2),       # BASELINE C3: the configuration north_star shards over 8 GPUs
+    ("c3_4095_n4", lambda: P.linear_chain(2, 11, 11), 4),
+    ("c3_4095_n8", lambda: P.linear_chain(2, 11, 11), 8),
     ("c2_1023_n2", lambda: P.linear_chain(2, 9, 9), 2),
     ("c2_1023_n4", lambda: P.linear_chain(2, 9, 9), 4),
     ("c2_1023_n8", lambda: P.linear_chain(2, 9, 9), 8),
@@ -516,6 +519,31 @@ def test_sharded_virtual_ranks_match_single_device(gpu, orc, name, make, n):
         assert orc.max_kkt(flat, sol) < 1e-8
     for m in mirrors:
         m.close()
+
+
+@pytest.mark.parametrize("make", [lambda: P.linear_chain(2, 9, 9), lambda: P.linear_chain(2, 11, 11)], ids=["c2", "c3"])
+def test_sharded_path_through_rccl_with_one_rank(gpu, orc, make):
+    """The RCCL transport of the sharded mode on the one GPU this box has: a ONE-rank communicator (ncclGetUniqueId,
+    ncclCommInitRank, grouped in-place ncclAllGather on the solver's stream) carries both exchanges of every Newton iteration
+    and the final gather -- the same calls, enqueue order and buffers as with N ranks, with N = 1."""
+    p = make()
+    flat = oracle_flat_from_lti(orc, p)
+    ref = orc.solve(flat, lambda0=p.lambda0)
+    g = gpu.TqGpu(flat["nk"], flat["nx"], flat["nu"]).upload(flat, p.lambda0)
+    g.shard_init(0, 1, gpu.shard_unique_id())
+    assert g.path == 1                                   # sharded: launch-per-tier kernels
+    r = g.solve()
+    g.shard_gather_solution()
+    assert r["status"] == 0 and r["iter"] == ref["iter"] and r["ls_total"] == ref["ls_total"]
+    assert_solution_close(g.solution(), ref, TOL)
+    g.shard_init(0, 1, gpu.shard_unique_id())           # a second communicator replaces the first (no leak, still correct)
+    r = g.solve()
+    g.shard_gather_solution()
+    assert r["status"] == 0 and r["iter"] == ref["iter"]
+    assert_solution_close(g.solution(), ref, TOL)
+    g.shard_init(0, 1)                                   # back to the unsharded mirror
+    assert g.path == 2 and g.solve()["iter"] == ref["iter"]
+    g.close()
 
 
 def test_sharded_virtual_ranks_backtracking(gpu, orc):

@@ -860,6 +860,7 @@ struct tqgpu_solver {
     size_t sync_words_bytes = 0, lds_persist = 0;
     /* sharded mode */
     int nranks = 1, rank = 0, part_top = -1;      /* part_top: highest partitioned tier */
+    bool sharded = false;     /* subtree-sharded mode (nranks > 1, or ONE rank with a communicator: the same code path, used to exercise the RCCL transport on a one-GPU box) */
     int *d_gh_list = nullptr, *d_node_list = nullptr, *d_node_cnt_list = nullptr, *d_blk_list = nullptr;
     int gh_n = 0, gh_counted = 0, n_nodes = 0, n_nodes_counted = 0, n_blk_counted = 0;
     double *d_xerr = nullptr, *d_xs = nullptr;
@@ -1114,7 +1115,7 @@ int uni_first(int MD, int level) { int n = 0, w = 1; for (int l = 0; l < level; 
 
 Shard shard_desc(const tqgpu_solver *s, int tier) {
     Shard sh{};
-    if (s->nranks > 1) {
+    if (s->sharded) {
         if (tier >= 0 && tier <= s->part_top) sh.wg_off = s->rank * (s->tier_grid[tier] / s->nranks);
         sh.gh_list = s->d_gh_list; sh.gh_n = s->gh_n; sh.gh_counted = s->gh_counted;
         sh.err_src = s->d_xerr;
@@ -1181,7 +1182,7 @@ void launch_fast_phase(tqgpu_solver *s, const Opts &O, int h, int phase, int &la
     const Tree &T = s->T; const Data &D = s->D; hipStream_t st = s->stream;
     const dim3 blk(FW * WAVE);
     const int nt = s->n_tiers, N = s->nranks;
-    const bool sharded = N > 1;
+    const bool sharded = s->sharded;
     const int P = sharded ? s->part_top : -1;
     auto tgrid = [&](int i) { return (sharded && i <= P) ? s->tier_grid[i] / N : s->tier_grid[i]; };
     /* which kernel runs first / performs the termination test */
@@ -1228,9 +1229,9 @@ void launch_fast_phase(tqgpu_solver *s, const Opts &O, int h, int phase, int &la
 
 int launch_fast_iteration(tqgpu_solver *s, const Opts &O, int h, int &launches) {
     launch_fast_phase(s, O, h, 0, launches);
-    if (s->nranks > 1) { int rc = shard_exchange_rccl(s, 1); if (rc) return rc; }
+    if (s->sharded) { int rc = shard_exchange_rccl(s, 1); if (rc) return rc; }
     launch_fast_phase(s, O, h, 1, launches);
-    if (s->nranks > 1) { int rc = shard_exchange_rccl(s, 2); if (rc) return rc; }
+    if (s->sharded) { int rc = shard_exchange_rccl(s, 2); if (rc) return rc; }
     launch_fast_phase(s, O, h, 2, launches);
     return TQGPU_OK;
 }
@@ -1238,7 +1239,7 @@ int launch_fast_iteration(tqgpu_solver *s, const Opts &O, int h, int &launches) 
 /* one more line-search trial of iteration `it`; phase 0: sweep (+ pack), phase 1: decide */
 void launch_trial_phase(tqgpu_solver *s, const Opts &O, bool fast, int it, int t, int phase, int &launches) {
     const Tree &T = s->T; const Data &D = s->D; hipStream_t st = s->stream;
-    const bool sharded = s->nranks > 1;
+    const bool sharded = s->sharded;
     if (phase == 0) {
         bool done = false;
         if (fast) {
@@ -1262,7 +1263,7 @@ void launch_trial_phase(tqgpu_solver *s, const Opts &O, bool fast, int it, int t
 
 int launch_trial(tqgpu_solver *s, const Opts &O, bool fast, int it, int t, int &launches) {
     launch_trial_phase(s, O, fast, it, t, 0, launches);
-    if (s->nranks > 1) { int rc = shard_exchange_rccl(s, 2); if (rc) return rc; }
+    if (s->sharded) { int rc = shard_exchange_rccl(s, 2); if (rc) return rc; }
     launch_trial_phase(s, O, fast, it, t, 1, launches);
     return TQGPU_OK;
 }
@@ -1696,12 +1697,12 @@ extern "C" void tqgpu_destroy(tqgpu_solver *s) {
 
 /* which path a mirror takes: persistent single launch (uniform or multistage trees), tiered launches (uniform
  * trees only), single-workgroup persistent (small trees of any shape), launch per level */
-static bool persist_capable(const tqgpu_solver *s) { return s->fast >= 0 && s->use_fast && s->persist_ok && s->use_persist && s->nranks == 1; }
+static bool persist_capable(const tqgpu_solver *s) { return s->fast >= 0 && s->use_fast && s->persist_ok && s->use_persist && !s->sharded; }
 static bool tiered_capable(const tqgpu_solver *s) { return s->fast >= 0 && s->use_fast && !s->mstage; }
 /* `batch`: as a member of a batched launch (one workgroup per tree) the single-workgroup kernel also takes trees whose
  * state does not fit the LDS mirror; alone, such a tree is faster with one launch per level */
 static bool uses_gpersist(const tqgpu_solver *s, bool batch = false) {
-    return s->gpersist_ok && (s->gp_in_lds || batch) && s->use_gpersist && !s->dense && s->nranks == 1 && !persist_capable(s) && !tiered_capable(s);
+    return s->gpersist_ok && (s->gp_in_lds || batch) && s->use_gpersist && !s->dense && !s->sharded && !persist_capable(s) && !tiered_capable(s);
 }
 extern "C" int tqgpu_uses_fused_path(const tqgpu_solver *s) {
     if (!s) return 0;
@@ -1764,7 +1765,7 @@ extern "C" int tqgpu_set_objective_diag(tqgpu_solver *s, const double *Qd, const
  * all column major, then q, r.  Selects the generic device path; tqgpu_set_objective_diag selects clipping again. */
 extern "C" int tqgpu_set_objective_dense(tqgpu_solver *s, const double *Q, const double *R, const double *S, const double *q, const double *r) {
     if (!s || !Q || !q) return fail(TQGPU_EINVAL, "tqgpu_set_objective_dense: bad arguments");
-    if (s->nranks > 1) return fail(TQGPU_EINVAL, "the dense stage solver is not available in sharded mode");
+    if (s->sharded) return fail(TQGPU_EINVAL, "the dense stage solver is not available in sharded mode");
     HIP_TRY(hipSetDevice(s->device));
     std::vector<double> H((size_t)std::max(s->poff[s->Nn], 1), 0.0);
     size_t oq = 0, orr = 0, os = 0;
@@ -1930,7 +1931,7 @@ int solve_begin(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, GItem *defer
     if (O.termCondition < 0 || O.termCondition > 2 || O.regType < 0 || O.regType > 2 || O.regValue < 0)
         return fail(TQGPU_EINVAL, "invalid option value");
 
-    if (s->nranks > 1 && !s->comm) return fail(TQGPU_ECOMM, "sharded mirror without a communicator: use tqgpu_solve_virtual_ranks");
+    if (s->sharded && !s->comm) return fail(TQGPU_ECOMM, "sharded mirror without a communicator: use tqgpu_solve_virtual_ranks");
     const Tree &T = s->T; const Data &D = s->D;
     hipStream_t st = s->stream;
     const int nxu = std::max(s->sum_nx, s->sum_nu);
@@ -2272,19 +2273,30 @@ std::vector<RangeSpec> solution_ranges(tqgpu_solver *s) {
     return out;
 }
 
-int shard_build_lists(tqgpu_solver *s) {
-    const int MD = s->fMD, N = s->nranks, r = s->rank, nt = s->n_tiers;
+/* The partition of a uniform tree over `N` ranks, host arithmetic only: tiers whose subtree count is a multiple of N
+ * are partitioned by contiguous subtree ranges, the tiers above are replicated.  Used by shard_build_lists and exported as
+ * tqgpu_shard_plan (the CPU tests compare it with the Python planner the gloo protocol tests use). */
+struct ShardPlanHost {
+    int part_top = -1, lb = 0, gh_counted = 0;
+    int bnd_b0 = 0, bnd_bn = 0, bnd_own0 = 0, bnd_ownn = 0;
+    std::vector<int> gh, nodes, nodes_cnt, blks;
+};
+
+int shard_plan_host(int MD, int NX, int Nh, const std::vector<int> &tier_l0, const std::vector<int> &tier_grid, int N, int r, ShardPlanHost &P) {
+    const int nt = (int)tier_l0.size();
     /* highest partitioned tier: subtree count divisible by the number of ranks */
-    s->part_top = -1;
-    for (int i = 0; i < nt - 1; i++) if (s->tier_grid[i] % N == 0 && s->tier_grid[i] >= N) s->part_top = i;
-    if (s->part_top < 0) return fail(TQGPU_EUNSUPPORTED, "tree too small to shard over this many ranks");
-    const int lb = s->tier_l0[s->part_top], l00 = s->tier_l0[0], Nh = s->Nh;
+    P.part_top = -1;
+    for (int i = 0; i < nt - 1; i++) if (tier_grid[i] % N == 0 && tier_grid[i] >= N) P.part_top = i;
+    if (P.part_top < 0) return fail(TQGPU_EUNSUPPORTED, "tree too small to shard over this many ranks");
+    const int lb = tier_l0[P.part_top], l00 = tier_l0[0];
+    P.lb = lb;
     auto width = [&](int l) { int w = 1; for (int i = 0; i < l; i++) w *= MD; return w; };
     {
-        const int gb = width(lb), w = gb / N, NX = s->fNX;
-        s->bnd_b0 = NX * uni_first(MD, lb); s->bnd_bn = NX * gb; s->bnd_own0 = NX * r * w; s->bnd_ownn = NX * w;
+        const int gb = width(lb), w = gb / N;
+        P.bnd_b0 = NX * uni_first(MD, lb); P.bnd_bn = NX * gb; P.bnd_own0 = NX * r * w; P.bnd_ownn = NX * w;
     }
-    std::vector<int> gh, nodes, nodes_cnt, blks;
+    std::vector<int> &gh = P.gh, &nodes = P.nodes, &nodes_cnt = P.nodes_cnt, &blks = P.blks;
+    gh.clear(); nodes.clear(); nodes_cnt.clear(); blks.clear();
     /* owned */
     for (int l = lb; l <= Nh; l++) {
         const int w = width(l) / N, f0 = uni_first(MD, l) + r * w;
@@ -2294,7 +2306,7 @@ int shard_build_lists(tqgpu_solver *s) {
             if (l < l00) gh.push_back(f0 + i);
         }
     }
-    s->gh_counted = (int)gh.size();
+    P.gh_counted = (int)gh.size();
     /* replicated (levels above the boundary): computed by every rank, counted by rank 0 only */
     for (int l = 0; l < lb; l++) {
         const int w = width(l), f0 = uni_first(MD, l);
@@ -2303,7 +2315,19 @@ int shard_build_lists(tqgpu_solver *s) {
             if (r == 0) { nodes_cnt.push_back(f0 + i); blks.push_back(f0 + i); }
         }
     }
-    if (r == 0) s->gh_counted = (int)gh.size();
+    if (r == 0) P.gh_counted = (int)gh.size();
+    return TQGPU_OK;
+}
+
+int shard_build_lists(tqgpu_solver *s) {
+    const int N = s->nranks;
+    ShardPlanHost P;
+    int rcp = shard_plan_host(s->fMD, s->fNX, s->Nh, s->tier_l0, s->tier_grid, N, s->rank, P);
+    if (rcp) return rcp;
+    s->part_top = P.part_top;
+    s->bnd_b0 = P.bnd_b0; s->bnd_bn = P.bnd_bn; s->bnd_own0 = P.bnd_own0; s->bnd_ownn = P.bnd_ownn;
+    std::vector<int> &gh = P.gh, &nodes = P.nodes, &nodes_cnt = P.nodes_cnt, &blks = P.blks;
+    s->gh_counted = P.gh_counted;
     s->gh_n = (int)gh.size(); s->n_nodes = (int)nodes.size(); s->n_nodes_counted = (int)nodes_cnt.size(); s->n_blk_counted = (int)blks.size();
     const size_t ints = gh.size() + nodes.size() + nodes_cnt.size() + blks.size() + 16;
     const size_t bytes = ints * sizeof(int) + (3 * (size_t)N + 8) * sizeof(double) + 1024;
@@ -2335,16 +2359,49 @@ extern "C" int tqgpu_shard_unique_id(void *id128) {
     return TQGPU_OK;
 }
 
+/* the partition plan without a device (host arithmetic of shard_build_lists): uniform complete md-ary tree with Nh block levels, tiers
+ * of the fused path (3 levels for md = 2, 2 for md <= 4, else 1).  Lists may be NULL / caps 0 to query the sizes only. */
+extern "C" int tqgpu_shard_plan(int md, int nx, int Nh, int nranks, int rank, int *part_top, int *boundary_level, int *gh_counted,
+                                int *gh_list, int gh_cap, int *gh_n, int *owned_nodes, int owned_cap, int *owned_n) {
+    if (md < 2 || Nh < 2 || nranks < 1 || rank < 0 || rank >= nranks) return fail(TQGPU_EINVAL, "tqgpu_shard_plan: bad arguments");
+    const int TH = md == 2 ? 3 : (md <= 4 ? 2 : 1);
+    std::vector<int> l0v, gridv;
+    const int nt = (Nh + TH - 1) / TH;
+    for (int i = 0; i < nt; i++) {
+        const int l1 = Nh - i * TH, l0 = std::max(0, l1 - TH);
+        int grid = 1;
+        for (int l = 0; l < l0; l++) grid *= md;
+        l0v.push_back(l0); gridv.push_back(grid);
+    }
+    ShardPlanHost P;
+    int rc = shard_plan_host(md, nx, Nh, l0v, gridv, nranks, rank, P);
+    if (rc) return rc;
+    if (part_top) *part_top = P.part_top;
+    if (boundary_level) *boundary_level = P.lb;
+    if (gh_counted) *gh_counted = P.gh_counted;
+    if (gh_n) *gh_n = (int)P.gh.size();
+    if (gh_list) for (int i = 0; i < (int)P.gh.size() && i < gh_cap; i++) gh_list[i] = P.gh[(size_t)i];
+    /* owned nodes = the partitioned part of the node list (levels >= boundary), in level order */
+    int no = 0;
+    const int first_repl = uni_first(md, P.lb);
+    for (int v : P.nodes) if (v >= first_repl) { if (owned_nodes && no < owned_cap) owned_nodes[no] = v; no++; }
+    if (owned_n) *owned_n = no;
+    return TQGPU_OK;
+}
+
 extern "C" int tqgpu_shard_init(tqgpu_solver *s, int rank, int nranks, const void *id128) {
     if (!s || nranks < 1 || rank < 0 || rank >= nranks) return fail(TQGPU_EINVAL, "tqgpu_shard_init: bad arguments");
     HIP_TRY(hipSetDevice(s->device));
-    if (nranks == 1) { s->nranks = 1; s->rank = 0; return TQGPU_OK; }
+    if (s->comm) { (void)g_rccl.CommDestroy(s->comm); s->comm = nullptr; }      /* a second call replaces the communicator, it does not leak it */
+    /* one rank WITHOUT a communicator = back to the unsharded mirror; one rank WITH one = the sharded code path on a single device
+     * (every exchange is a one-rank in-place all-gather): exercises rccl_load / ncclCommInitRank / ncclAllGather where only one GPU exists */
+    if (nranks == 1 && !id128) { s->nranks = 1; s->rank = 0; s->sharded = false; return TQGPU_OK; }
     if (s->fast < 0 || !s->use_fast || s->mstage) return fail(TQGPU_EUNSUPPORTED, "sharding needs the fused uniform-tree path");
-    s->nranks = nranks; s->rank = rank;
+    s->nranks = nranks; s->rank = rank; s->sharded = true;
     int rc = shard_build_lists(s);
-    if (rc) { s->nranks = 1; s->rank = 0; return rc; }
+    if (rc) { s->nranks = 1; s->rank = 0; s->sharded = false; return rc; }
     if (id128) {
-        if ((rc = rccl_load())) return rc;
+        if ((rc = rccl_load())) { s->nranks = 1; s->rank = 0; s->sharded = false; return rc; }
         RcclApi::UniqueId id;
         memcpy(&id, id128, sizeof(id));
         NCCL_TRY(g_rccl.CommInitRank(&s->comm, nranks, id, rank));
@@ -2356,7 +2413,7 @@ extern "C" int tqgpu_shard_init(tqgpu_solver *s, int rank, int nranks, const voi
  * nodes: gather the partitioned ranges so that tqgpu_get_solution returns the full solution */
 extern "C" int tqgpu_shard_gather_solution(tqgpu_solver *s) {
     if (!s) return fail(TQGPU_EINVAL, "null solver");
-    if (s->nranks == 1) return TQGPU_OK;
+    if (!s->sharded) return TQGPU_OK;
     if (!s->comm) return fail(TQGPU_ECOMM, "no communicator (virtual ranks gather through tqgpu_solve_virtual_ranks)");
     HIP_TRY(hipSetDevice(s->device));
     auto ranges = solution_ranges(s);
