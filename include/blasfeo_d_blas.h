@@ -20,6 +20,10 @@ void blasfeo_dgemv_n(int m, int n, double alpha, struct blasfeo_dmat *sA, int ai
 void blasfeo_dgemv_t(int m, int n, double alpha, struct blasfeo_dmat *sA, int ai, int aj, struct blasfeo_dvec *sx, int xi, double beta, struct blasfeo_dvec *sy, int yi, struct blasfeo_dvec *sz, int zi);
 /* z = beta*y + alpha*A*x, A symmetric, lower part referenced */
 void blasfeo_dsymv_l(int m, int n, double alpha, struct blasfeo_dmat *sA, int ai, int aj, struct blasfeo_dvec *sx, int xi, double beta, struct blasfeo_dvec *sy, int yi, struct blasfeo_dvec *sz, int zi);
+/* lower Cholesky of the leading m x m part (a non-positive pivot gives a zero column); _mn: m x n, m >= n */
+void blasfeo_dpotrf_l(int m, struct blasfeo_dmat *sC, int ci, int cj, struct blasfeo_dmat *sD, int di, int dj);
+void blasfeo_dpotrf_l_mn(int m, int n, struct blasfeo_dmat *sC, int ci, int cj, struct blasfeo_dmat *sD, int di, int dj);
+
 #ifdef __cplusplus
 }
 #endif

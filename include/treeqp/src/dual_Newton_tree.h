@@ -26,6 +26,26 @@ extern "C" {
 #include <blasfeo_target.h>
 #include <blasfeo_common.h>
 
+/* The reference's per-node plug-in interface for stage solvers (dual_Newton_tree.h:48-63), kept as a TYPE for source
+ * compatibility.  This build has no per-node indirect calls: the entries' work is done for all nodes of a level by batched
+ * kernels (solve_extended / solve / eval_dual_term -> the stage sweep; set_CmPnCmT / add_EPmE / add_CmPnCkT -> the dual-Hessian
+ * kernels; init -> k_init / k_dense_init; export_mu -> the export kernel), selected per node by opts->qp_solver[]. */
+typedef struct stage_qp_fcn_ptrs_ {
+    answer_t (*is_applicable)(const tree_qp_in *qp_in, int idx);
+    int (*calculate_size)(int nx, int nu, int nc);
+    void (*assign_structs)(void **data, char **c_double_ptr);
+    void (*assign_blasfeo_data)(int nx, int nu, void *data, char **c_double_ptr);
+    void (*assign_data)(int nx, int nu, int nc, void *data, char **c_double_ptr);
+    return_t (*init)(const tree_qp_in *qp_in, int idx, stage_qp_t solver_dad, void *work);
+    return_t (*solve_extended)(const tree_qp_in *qp_in, int idx, void *work);
+    return_t (*solve)(const tree_qp_in *qp_in, int idx, void *work);
+    void (*set_CmPnCmT)(const tree_qp_in *qp_in, int idx, int idxdad, int offset, void *work_);
+    void (*add_EPmE)(const tree_qp_in *qp_in, int idx, int idxdad, int offset, void *work_);
+    void (*add_CmPnCkT)(const tree_qp_in *qp_in, int idx, int idxsib, int idxdad, int row_offset, int col_offset, void *work_);
+    void (*eval_dual_term)(const tree_qp_in *qp_in, int idx, void *work_);
+    void (*export_mu)(tree_qp_out *qp_out, int idx, void *work_);
+} stage_qp_fcn_ptrs;
+
 typedef struct treeqp_tdunes_opts_t_ {
     int maxIter;
     stage_qp_t *qp_solver;          /* per node */

@@ -82,6 +82,9 @@ int tqgpu_set_objective_diag(tqgpu_solver *s, const double *Qd, const double *Rd
  * tree_qp_in_set_ltv_objective_colmajor (tree_qp_common.c:2010-2050): per node Q (nx x nx), R (nu x nu),
  * S (nu x nx) column major, then q, r.  Bounds are ignored while it is selected. */
 int tqgpu_set_objective_dense(tqgpu_solver *s, const double *Q, const double *R, const double *S, const double *q, const double *r);
+/* the same with a per-node choice (opts->qp_solver[] of the reference, dual_Newton_tree.c:124-162): kind[k] = 0 clipping (the
+ * diagonals of Q_k and R_k are the weights; off-diagonals and S_k must be zero), 1 dense unconstrained; NULL = all dense */
+int tqgpu_set_objective_mixed(tqgpu_solver *s, const int *kind, const double *Q, const double *R, const double *S, const double *q, const double *r);
 int tqgpu_set_bounds(tqgpu_solver *s, const double *xmin, const double *xmax, const double *umin, const double *umax);
 /* Everything above in one call (NULL = leave alone) plus the starting duals: compared with a pinned host mirror of
  * what the device holds, only what changed is uploaded, without synchronisation.  This is what the drop-in

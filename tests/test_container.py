@@ -159,3 +159,50 @@ def test_json_front_end_rejects_malformed_input(tmp_path):
     bad.write_text('{"nodes": [{"q": [1, 2], "r": []}], "edges": [')
     out = subprocess.run([str(_json_tool()), "--dims", str(bad)], capture_output=True, text=True, timeout=60)
     assert out.returncode == 2 and "solve_qp_json" in out.stderr
+
+
+def test_regularised_cholesky_utilities(capi):
+    """treeqp_dpotrf_l(_mn)_with_reg_opts (dual_Newton_common.c:36-123): NO / ALWAYS / ON_THE_FLY, zero column for a
+    non-positive pivot, M modified when regularised."""
+    import ctypes as C
+    L = capi.lib()
+    L.treeqp_dpotrf_l_with_reg_opts.argtypes = [C.POINTER(capi.Dmat), C.POINTER(capi.Dmat), C.c_int, C.c_double, C.c_double]
+    L.treeqp_dpotrf_l_mn_with_reg_opts.argtypes = L.treeqp_dpotrf_l_with_reg_opts.argtypes
+    rng = np.random.Generator(np.random.PCG64(5))
+
+    def dmat(a):
+        a = np.asfortranarray(a, dtype=np.float64)
+        m = capi.Dmat()
+        L.blasfeo_allocate_dmat(a.shape[0], a.shape[1], C.byref(m))
+        L.blasfeo_pack_dmat(a.shape[0], a.shape[1], a.ctypes.data_as(C.POINTER(C.c_double)), a.shape[0], C.byref(m), 0, 0)
+        return m
+
+    def arr(m, r, c):
+        return np.ctypeslib.as_array(m.pA, shape=(c, r)).T.copy()
+
+    B = rng.standard_normal((6, 6))
+    W = B @ B.T + 0.5 * np.eye(6)
+    for reg, val in ((0, 0.0), (1, 1e-3), (2, 1e-3)):
+        M, Lc = dmat(W), dmat(np.zeros((6, 6)))
+        res = L.treeqp_dpotrf_l_with_reg_opts(C.byref(M), C.byref(Lc), reg, 1e-6, val)
+        Wreg = W + (val if reg == 1 else 0.0) * np.eye(6)
+        assert res == (1 if reg == 1 else 0)
+        assert np.allclose(np.tril(arr(Lc, 6, 6)), np.linalg.cholesky(Wreg), rtol=0, atol=1e-12)
+        assert np.allclose(arr(M, 6, 6), Wreg, rtol=0, atol=0)
+    # singular block: ON_THE_FLY notices the zero diagonal of the first factor, shifts and refactorises
+    v = rng.standard_normal((6, 2))
+    Ws = v @ v.T
+    M, Lc = dmat(Ws), dmat(np.zeros((6, 6)))
+    assert L.treeqp_dpotrf_l_with_reg_opts(C.byref(M), C.byref(Lc), 2, 1e-6, 1e-4) == 1
+    assert np.allclose(np.tril(arr(Lc, 6, 6)), np.linalg.cholesky(Ws + 1e-4 * np.eye(6)), rtol=0, atol=1e-9)
+    # without regularisation the non-positive pivot gives a ZERO column, not NaN
+    M, Lc = dmat(np.diag([4.0, -1.0, 9.0])), dmat(np.zeros((3, 3)))
+    assert L.treeqp_dpotrf_l_with_reg_opts(C.byref(M), C.byref(Lc), 0, 1e-6, 0.0) == 0
+    assert np.array_equal(np.diag(arr(Lc, 3, 3)), [2.0, 0.0, 3.0])
+    # tall variant: the rows below the square part are divided through (trsm fused into the factorisation)
+    T = np.vstack([W, rng.standard_normal((3, 6))])
+    M, Lc = dmat(T), dmat(np.zeros((9, 6)))
+    assert L.treeqp_dpotrf_l_mn_with_reg_opts(C.byref(M), C.byref(Lc), 0, 1e-6, 0.0) == 0
+    Lw = np.linalg.cholesky(W)
+    got = arr(Lc, 9, 6)
+    assert np.allclose(np.tril(got[:6]), Lw, rtol=0, atol=1e-12) and np.allclose(got[6:], T[6:] @ np.linalg.inv(Lw).T, rtol=0, atol=1e-11)

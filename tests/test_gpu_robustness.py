@@ -142,3 +142,95 @@ def test_shared_device_takes_the_launch_per_tier_path(gpu, orc):
     g2 = gpu.TqGpu(flat["nk"], flat["nx"], flat["nu"]).upload(flat, p.lambda0)
     assert g2.path == 2 and g2.solve()["status"] == 0 and L.tqgpu_timeouts(g2.h) == 0
     g2.close()
+
+
+def _mixed_problem(seed, dense_blocks=True):
+    """irregular tree; every second level uses the dense unconstrained stage solver (full Q, R, S), the others clipping
+    (diagonal weights, box bounds on the inputs that become active)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    f = P.random_shape_qp(seed, depth=4, max_kids=3, nx_range=(2, 4), nu_range=(1, 3), ubound=0.15)
+    d = {k: np.array(v, copy=True) for k, v in f.as_dict().items()}
+    nk, nx, nu = d["nk"], d["nx"], d["nu"]
+    Nn = len(nk)
+    dad = P.parents_of(nk)
+    stage = np.zeros(Nn, dtype=int)
+    for k in range(1, Nn):
+        stage[k] = stage[dad[k]] + 1
+    kind = (stage % 2 == 1).astype(np.int32)
+    xo, uo = np.concatenate([[0], np.cumsum(nx)]), np.concatenate([[0], np.cumsum(nu)])
+    Q, R, S = [], [], []
+    for k in range(Nn):
+        Qk, Rk, Sk = np.diag(d["Qd"][xo[k]:xo[k + 1]]), np.diag(d["Rd"][uo[k]:uo[k + 1]]), np.zeros((nu[k], nx[k]))
+        if kind[k]:
+            d["xmin"][xo[k]:xo[k + 1]] = -1e12; d["xmax"][xo[k]:xo[k + 1]] = 1e12
+            d["umin"][uo[k]:uo[k + 1]] = -1e12; d["umax"][uo[k]:uo[k + 1]] = 1e12
+            if dense_blocks:
+                nz = nx[k] + nu[k]
+                M = 0.3 * rng.standard_normal((nz, nz))
+                H = np.block([[Qk, Sk.T], [Sk, Rk]]) + M @ M.T
+                Qk, Rk, Sk = H[:nx[k], :nx[k]], H[nx[k]:, nx[k]:], H[nx[k]:, :nx[k]]
+        Q.append(Qk.ravel(order="F")); R.append(Rk.ravel(order="F")); S.append(Sk.ravel(order="F"))
+    d["Q"], d["R"], d["S"] = np.concatenate(Q), np.concatenate(R), np.concatenate(S)
+    return d, kind
+
+
+@pytest.mark.parametrize("seed", [3, 8])
+def test_per_node_mix_of_stage_solvers(gpu, orc, seed):
+    """opts->qp_solver[] per node (dual_Newton_tree.c:124-162): clipping and dense unconstrained stage solvers in ONE tree.
+    (i) With diagonal weights everywhere the mixed solve is the all-clipping solve (the oracle's) -- the kind of a node only
+    selects the code that solves its stage QP.  (ii) With genuinely dense stage Hessians on the dense nodes there is no oracle:
+    the solution is checked against the KKT conditions of the QP (convex: KKT point = solution), with the reference's own
+    residual measure (tree_qp_out_max_KKT_res, dense Q/R/S)."""
+    d, kind = _mixed_problem(seed, dense_blocks=False)
+    assert 0 < kind.sum() < len(kind)
+    ref = orc.solve(d)
+    g = gpu.TqGpu(d["nk"], d["nx"], d["nu"]).upload_mixed(d, kind)
+    assert g.path == 0
+    r = g.solve()
+    assert r["status"] == ref["status"] == 0 and r["iter"] == ref["iter"]
+    assert_solution_close(g.solution(), ref, TOL)
+    g.close()
+    d, kind = _mixed_problem(seed, dense_blocks=True)
+    g = gpu.TqGpu(d["nk"], d["nx"], d["nu"]).upload_mixed(d, kind)
+    r = g.solve(stationarityTolerance=1e-10)
+    sol = g.solution()
+    g.close()
+    assert r["status"] == 0
+    assert orc.max_kkt(d, sol, dense=True) < 1e-9
+    active = int(np.sum((sol["u"] >= d["umax"]) | (sol["u"] <= d["umin"])))
+    assert active > 0                                   # the clipping nodes do clip
+
+
+def test_per_node_mix_through_the_dropin_api(gpu, orc):
+    """the same through tree_qp_in / opts.qp_solver[] / treeqp_tdunes_solve"""
+    d, kind = _mixed_problem(3, dense_blocks=False)
+    ref = orc.solve(d)
+    f = P.FlatProblem(name="mixed", **{k: d[k] for k in ("nk", "nx", "nu", "A", "B", "b", "Qd", "Rd", "q", "r", "xmin", "xmax", "umin", "umax")})
+    qp = product_qp_from_flat(gpu, f)
+    s = gpu.TdunesSolver(qp)
+    for k in range(qp.N):
+        s.opts.qp_solver[k] = int(kind[k])             # TREEQP_QPOASES_SOLVER = 1 on the unconstrained nodes
+    assert s.solve() == 0
+    assert qp.info["iter"] == ref["iter"]
+    assert_solution_close(qp.solution(), ref, TOL)
+    s.destroy()
+
+
+def test_launch_per_level_path_with_changing_iteration_limits(gpu, orc):
+    """The launch-per-level path enqueues a predicted number of iterations ahead, the last one as its termination test only.
+    When the line search before that test needs more than its first trial, the test finds the search pending and is a no-op:
+    it must run again with the rest of its iteration (regression: a solve with maxIter = 2 after one with maxIter = 1 took
+    its second Newton step from a stale gradient)."""
+    d, _ = _mixed_problem(8, dense_blocks=False)
+    os.environ["TREEQP_AMD_PATH"] = "generic"
+    try:
+        g = gpu.TqGpu(d["nk"], d["nx"], d["nu"]).upload(d)
+        assert g.path == 0
+        for k in (1, 2, 3, 2, 50, 1, 4):
+            r = g.solve(maxIter=k)
+            ref = orc.solve(d, orc.default_opts(maxIter=k))
+            assert (r["status"], r["iter"], r["ls_total"]) == (ref["status"], ref["iter"], ref["ls_total"]), k
+            assert_solution_close(g.solution(), ref, TOL)
+        g.close()
+    finally:
+        del os.environ["TREEQP_AMD_PATH"]

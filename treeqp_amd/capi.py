@@ -498,6 +498,20 @@ class TqGpu:
         self.set_lambda(lambda0)
         return self
 
+    def upload_mixed(self, p, kind, lambda0=None):
+        """Per-node choice of the stage solver: kind[k] = 0 clipping (diagonal Q_k, R_k, S_k = 0, box bounds), 1 dense unconstrained
+        (full Q_k, R_k, S_k, bounds at infinity).  p holds A, B, b, Q, R, S (dense layout, column major), q, r and the bounds."""
+        g = (lambda k: getattr(p, k)) if not isinstance(p, dict) else (lambda k: p[k])
+        L = lib()
+        keep = {k: _f64(g(k)) for k in ("A", "B", "b", "Q", "R", "S", "q", "r", "xmin", "xmax", "umin", "umax")}
+        kd = _i32(kind)
+        assert len(kd) == len(self.nk)
+        self._chk(L.tqgpu_set_dynamics(self.h, _dp(keep["A"]), _dp(keep["B"]), _dp(keep["b"])))
+        self._chk(L.tqgpu_set_objective_mixed(self.h, _ip(kd), _dp(keep["Q"]), _dp(keep["R"]), _dp(keep["S"]), _dp(keep["q"]), _dp(keep["r"])))
+        self._chk(L.tqgpu_set_bounds(self.h, _dp(keep["xmin"]), _dp(keep["xmax"]), _dp(keep["umin"]), _dp(keep["umax"])))
+        self.set_lambda(lambda0)
+        return self
+
     def set_lambda(self, lam):
         a = None if lam is None else _f64(lam)
         if a is not None:

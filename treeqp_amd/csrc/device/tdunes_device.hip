@@ -105,7 +105,8 @@ struct Data {            /* device pointers, passed by value */
     int ls_log_cap;
     /* dense unconstrained stage solver (generic path only; dual_Newton_tree_qpoases.c restricted to no bounds):
      * per node the stage Hessian H = [Q S'; S R] ((nx+nu)^2, column major) and its inverse P = H^-1 */
-    int dense;
+    int dense;                /* some nodes use the dense unconstrained stage solver */
+    const int *kind;          /* [Nn] per node: 0 clipping, 1 dense unconstrained (read only when dense != 0) */
     const double *Hd;
     double *Pd;
     const int *poff;          /* [Nn+1] offsets of the (nx+nu)^2 blocks */
@@ -195,7 +196,7 @@ __global__ void __launch_bounds__(WAVE) k_dense_init(Tree T, Data D) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int k = blockIdx.x, lane = threadIdx.x;
     const int nz = T.nx[k] + T.nu[k];
-    if (nz == 0) return;
+    if (nz == 0 || !D.kind[k]) return;
     const double *H = D.Hd + D.poff[k];
     double *P = D.Pd + D.poff[k];
     double *Lm = lds;                      /* nz x nz, ld = nz */
@@ -264,7 +265,7 @@ __device__ void stage_body(const Tree &T, const Data &D, int mode, int k, int la
     }
     WSYNC();
 
-    if (D.dense) {
+    if (D.dense && D.kind[k]) {
         /* dense unconstrained stage QP: z = P hmod; dual term -1/2 z'Hz + hmod'z - cmod */
         const int nz = nxk + nuk;
         double *hm = lds + d + nxk, *zz = hm + nz;
@@ -441,6 +442,7 @@ __device__ void hess_body(const Tree &T, const Data &D, int p, int lane, double 
     double *CP = lds + (size_t)d * nz;
     const int k0 = T.kid0[p], ko = T.xoff[k0];
     const double *Qc = D.QinvCal + T.xoff[p], *Rc = D.RinvCal + T.uoff[p];
+    const bool pdense = D.dense && D.kind[p];           /* the parent's elimination matrix: dense P_p = H_p^-1, or diag(QinvCal_p, RinvCal_p) */
     /* stage the children's [A B] rows */
     int rowoff = 0;
     for (int cc = 0; cc < T.nk[p]; cc++) {
@@ -450,12 +452,12 @@ __device__ void hess_body(const Tree &T, const Data &D, int p, int lane, double 
             const int i = e % nxc, col = e / nxc;
             const double a = col < nxp ? A[i + (size_t)col * nxc] : B[i + (size_t)(col - nxp) * nxc];
             Cs[rowoff + i + (size_t)col * d] = a;
-            if (!D.dense) { const double pc = col < nxp ? Qc[col] : Rc[col - nxp]; CP[rowoff + i + (size_t)col * d] = a * pc; }
+            if (!pdense) { const double pc = col < nxp ? Qc[col] : Rc[col - nxp]; CP[rowoff + i + (size_t)col * d] = a * pc; }
         }
         rowoff += nxc;
     }
     WSYNC();
-    if (D.dense) {
+    if (pdense) {
         /* CP = C P_p with the dense elimination matrix of the parent (build_M of the qpOASES stage solver) */
         const double *P = D.Pd + D.poff[p];
         for (int e = lane; e < d * nz; e += WAVE) {
@@ -476,11 +478,16 @@ __device__ void hess_body(const Tree &T, const Data &D, int p, int lane, double 
         double w = acc + acc2;
         if (!D.dense) { if (i == j) w += D.QinvCal[ko + i]; }
         else {
-            /* add_EPmE: the state block of the child's own elimination matrix on the diagonal block */
+            /* add_EPmE: the state block of the CHILD's own elimination matrix on the diagonal block -- dense P_kid, or the
+             * clipped inverse weights of a clipping child (the solver kinds of a node and of its children need not agree:
+             * per-node opts->qp_solver[], dual_Newton_tree.c:124-162) */
             int ro = 0;
             for (int cc = 0; cc < T.nk[p]; cc++) {
                 const int kid = k0 + cc, nxc = T.nx[kid];
-                if (i >= ro && i < ro + nxc && j >= ro && j < ro + nxc) { const int nzk = nxc + T.nu[kid]; w += D.Pd[D.poff[kid] + (i - ro) + (size_t)(j - ro) * nzk]; }
+                if (i >= ro && i < ro + nxc && j >= ro && j < ro + nxc) {
+                    if (D.kind[kid]) { const int nzk = nxc + T.nu[kid]; w += D.Pd[D.poff[kid] + (i - ro) + (size_t)(j - ro) * nzk]; }
+                    else if (i == j) w += D.QinvCal[ko + i];
+                }
                 ro += nxc;
             }
         }
@@ -795,6 +802,7 @@ struct tqgpu_solver {
     size_t lds_hess_w = 0, lds_factor_w = 0, lds_forward_w = 0;
     bool dense = false, need_dense_init = false;   /* dense unconstrained stage solver selected (generic path only) */
     double *d_Hd = nullptr;      /* writable alias of Data.Hd */
+    int *d_kind = nullptr;       /* writable alias of Data.kind */
     std::vector<int> poff;
     int use_fast_orig = 1;
     void *slab = nullptr;
@@ -1467,9 +1475,9 @@ __global__ void k_export_all(int n_x, int n_u, int n_lam, int x_pad, int nx0, Da
     if (i < n_x) {
         const int j = i + x_pad;
         ox[i] = D.x[j];
-        omx[i] = D.dense ? 0.0 : D.Qd[j] * fma(-1.0, D.x[j], (maxit ? D.xUncS : D.xUnc)[j]);
+        omx[i] = D.Qd[j] * fma(-1.0, D.x[j], (maxit ? D.xUncS : D.xUnc)[j]);      /* dense nodes: Qd = 0 (no bounds, no multipliers) */
     }
-    if (i < n_u) { ou[i] = D.u[i]; omu[i] = D.dense ? 0.0 : D.Rd[i] * fma(-1.0, D.u[i], (maxit ? D.uUncS : D.uUnc)[i]); }
+    if (i < n_u) { ou[i] = D.u[i]; omu[i] = D.Rd[i] * fma(-1.0, D.u[i], (maxit ? D.uUncS : D.uUnc)[i]); }
     if (i < n_lam) { ol[i] = lamc[nx0 + i]; od[i] = D.dlam[nx0 + i]; }
 }
 
@@ -1537,6 +1545,7 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
     const size_t o_lami = cv.take(SX * Dbl);
     s->poff.assign(Nn + 1, 0);
     for (int k = 0; k < Nn; k++) s->poff[k + 1] = s->poff[k] + (s->nx[k] + s->nu[k]) * (s->nx[k] + s->nu[k]);
+    const size_t o_kind = cv.take(Nn * I);
     const size_t o_poff = cv.take((Nn + 1) * I), o_Hd = cv.take((size_t)std::max(s->poff[Nn], 1) * Dbl), o_Pd = cv.take((size_t)std::max(s->poff[Nn], 1) * Dbl);
     const size_t o_ctrl = cv.take(sizeof(Ctrl));
     const size_t o_stamps = cv.take((8 * 32 * 2 + 1024) * sizeof(unsigned long long));   /* + 1024: placement census of the persistent launch (diagnostic builds) */
@@ -1599,7 +1608,7 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
     D.Sbuf = at<double>(base, o_sbuf); D.ybuf = at<double>(base, o_ybuf);
     D.stamps = at<unsigned long long>(base, o_stamps);
     D.ctrl = at<Ctrl>(base, o_ctrl); D.ls_log = at<int>(base, o_log); D.ls_log_cap = s->ls_log_cap;
-    D.dense = 0; s->d_Hd = at<double>(base, o_Hd); D.Hd = s->d_Hd; D.Pd = at<double>(base, o_Pd); D.poff = at<int>(base, o_poff);
+    D.dense = 0; s->d_kind = at<int>(base, o_kind); D.kind = s->d_kind; s->d_Hd = at<double>(base, o_Hd); D.Hd = s->d_Hd; D.Pd = at<double>(base, o_Pd); D.poff = at<int>(base, o_poff);
     s->use_fast_orig = s->use_fast;
     s->d_mu_x = at<double>(base, o_mux); s->d_mu_u = at<double>(base, o_muu);
     s->d_lam_init = at<double>(base, o_lami);
@@ -1764,14 +1773,33 @@ extern "C" int tqgpu_set_objective_diag(tqgpu_solver *s, const double *Qd, const
  * tree_qp_in_set_ltv_objective_colmajor (tree_qp_common.c): per node Q (nx x nx), R (nu x nu), S (nu x nx),
  * all column major, then q, r.  Selects the generic device path; tqgpu_set_objective_diag selects clipping again. */
 extern "C" int tqgpu_set_objective_dense(tqgpu_solver *s, const double *Q, const double *R, const double *S, const double *q, const double *r) {
-    if (!s || !Q || !q) return fail(TQGPU_EINVAL, "tqgpu_set_objective_dense: bad arguments");
+    return tqgpu_set_objective_mixed(s, nullptr, Q, R, S, q, r);
+}
+
+/* The same with a per-node choice of the stage solver (opts->qp_solver[] of the reference, dual_Newton_tree.c:124-162):
+ * kind[k] = 0: clipping (the diagonals of Q_k, R_k are its weights; their off-diagonals and S_k must be zero), 1: dense
+ * unconstrained.  kind == NULL: every node dense. */
+extern "C" int tqgpu_set_objective_mixed(tqgpu_solver *s, const int *kind, const double *Q, const double *R, const double *S, const double *q, const double *r) {
+    if (!s || !Q || !q) return fail(TQGPU_EINVAL, "tqgpu_set_objective_mixed: bad arguments");
     if (s->sharded) return fail(TQGPU_EINVAL, "the dense stage solver is not available in sharded mode");
     HIP_TRY(hipSetDevice(s->device));
     std::vector<double> H((size_t)std::max(s->poff[s->Nn], 1), 0.0);
+    std::vector<double> Qd((size_t)std::max(s->sum_nx, 1), 0.0), Rd((size_t)std::max(s->sum_nu, 1), 0.0);
+    std::vector<int> kd((size_t)s->Nn, 1);
+    if (kind) for (int k = 0; k < s->Nn; k++) kd[(size_t)k] = kind[k] ? 1 : 0;
     size_t oq = 0, orr = 0, os = 0;
     for (int k = 0; k < s->Nn; k++) {
         const int nu = s->nu[k], nz = s->nx[k] + nu;
         double *Hk = H.data() + s->poff[k];
+        if (!kd[(size_t)k]) {
+            /* clipping node: diagonal weights (phantom root states of an embedded x0-eliminated tree keep their unit weight) */
+            const int nxc = s->nx[k] - ((k == 0) ? s->x_pad : 0);
+            for (int i = 0; i < ((k == 0) ? s->x_pad : 0); i++) Qd[(size_t)i] = 1.0;
+            for (int i = 0; i < nxc; i++) Qd[(size_t)s->xoff[k] + ((k == 0) ? s->x_pad : 0) + i] = Q[oq + i + (size_t)i * nxc];
+            for (int i = 0; i < nu; i++) Rd[(size_t)s->uoff[k] + i] = R ? R[orr + i + (size_t)i * nu] : 0.0;
+            oq += (size_t)nxc * nxc; orr += (size_t)nu * nu; os += (size_t)nu * nxc;
+            continue;
+        }
         if (k == 0 && s->x_pad) {
             /* phantom root states: identity weight, no coupling; the caller's node 0 has no Q and no S */
             for (int i = 0; i < s->x_pad; i++) Hk[i + (size_t)i * nz] = 1.0;
@@ -1791,11 +1819,12 @@ extern "C" int tqgpu_set_objective_dense(tqgpu_solver *s, const double *Q, const
     }
     s->in_valid = false;
     H2D(s->d_Hd, H.data(), s->poff[s->Nn]);
+    HIP_TRY(hipMemcpyAsync(s->d_kind, kd.data(), sizeof(int) * (size_t)s->Nn, hipMemcpyHostToDevice, s->stream));      /* ints: not H2D (doubles) */
     H2D(s->q + s->x_pad, q, s->sum_nx - s->x_pad); H2D(s->r, r, s->sum_nu);
-    if (s->sum_nx - s->x_pad > 0) HIP_TRY(hipMemsetAsync(s->Qd + s->x_pad, 0, sizeof(double) * (size_t)(s->sum_nx - s->x_pad), s->stream));
-    HIP_TRY(hipMemsetAsync(s->Rd, 0, sizeof(double) * (size_t)std::max(s->sum_nu, 1), s->stream));
+    /* weights: zero on dense nodes (their multipliers of bounds are zero by construction), the diagonals on clipping nodes */
+    H2D(s->Qd, Qd.data(), s->sum_nx); H2D(s->Rd, Rd.data(), s->sum_nu);
     HIP_TRY(hipStreamSynchronize(s->stream));
-    s->dense = true; s->need_dense_init = true; s->D.dense = 1;
+    s->dense = true; s->need_dense_init = true; s->D.dense = 1; s->need_init = true;
     s->use_fast = 0;                                       /* per-node dense blocks: generic kernels */
     return TQGPU_OK;
 }
@@ -1952,7 +1981,7 @@ int solve_begin(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, GItem *defer
     s->solve_no++;
     HIP_TRY(hipEventRecord(cx.ev0, st));
     if (!cx.persist) HIP_TRY(hipMemsetAsync(D.ctrl, 0, sizeof(Ctrl), st));     /* persistent path: reset by the launch's prologue */
-    if (s->need_init && !s->dense && !cx.gpersist) {     /* g_persist recomputes the reciprocal weights itself */
+    if (s->need_init && !cx.gpersist) {     /* g_persist recomputes the reciprocal weights itself; dense nodes never read theirs */
         hipLaunchKernelGGL(k_init, dim3((nxu + 255) / 256), dim3(256), 0, st, s->sum_nx, s->sum_nu, D); cx.launches++;
         s->need_init = false;
     }
@@ -2043,8 +2072,10 @@ int solve_end(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, tqgpu_result *
           if (hp_n % 200 == 0) { fprintf(stderr, "[hostprof] pre %.2f us, launch %.2f us, readback+sync %.2f us (avg of %ld)\n", hp_acc[0] / hp_n, hp_acc[1] / hp_n, hp_acc[2] / hp_n, hp_n); } }
 #endif
         tail_done = persist;
+        bool extra_trials = false;
         while (!s->h_ctrl->done && s->h_ctrl->ls_pending) {
             tail_done = false;
+            extra_trials = true;
             /* the line search of iteration `iter` wants more trials (rare): a batch of them */
             const int it = s->h_ctrl->iter, t0 = s->h_ctrl->ls_iter;
             for (int t = t0; t < t0 + 8 && t <= O.lsMaxIter; t++) { int rcx = launch_trial(s, O, fast, it, t, launches); if (rcx != TQGPU_OK) return rcx; }
@@ -2054,7 +2085,10 @@ int solve_end(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, tqgpu_result *
         finished = s->h_ctrl->done != 0;
         chunk = s->chunk;
         predicted = false;
-        rest_due = (!finished && deferred == h) ? h : -1;
+        /* the termination test of the deferred iteration was enqueued behind the FIRST trial of the line search before it: when that
+         * line search needed further trials (enqueued above, after the read-back), the test found the search pending and did nothing --
+         * it is then due again with the rest of its iteration */
+        rest_due = (!finished && deferred == h && !extra_trials) ? h : -1;
         if (persist && !finished && !cx.gpersist) {
             tail_done = false;
             unsigned tmo = 0;

@@ -1,8 +1,9 @@
 /*
  * blasfeo_compat.c -- from-scratch, column-major implementation of the BLASFEO-named routines
  * the treeqp_amd HOST layer uses (containers, marshalling, level-1/2 algebra for the KKT check
- * and x0 elimination).  Not a port of BLASFEO: no panel-major storage, no kernels, no level-3
- * and no factorizations (those exist only as HIP device code in this build).
+ * and x0 elimination).  Not a port of BLASFEO: no panel-major storage, no kernels, no level-3.
+ * The one factorisation (blasfeo_dpotrf_l / _l_mn, plain loops) is here for the utility routines of dual_Newton_common.h that a
+ * caller may link against; the solver's own factorisations exist only as HIP device code.
  */
 #include <blasfeo_common.h>
 #include <blasfeo_d_aux.h>
@@ -10,6 +11,7 @@
 #include <blasfeo_d_blas.h>
 #include <blasfeo_v_aux_ext_dep.h>
 
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -187,3 +189,22 @@ void blasfeo_print_dvec(int m, struct blasfeo_dvec *sa, int ai) { print_mat(m, 1
 void blasfeo_print_exp_dvec(int m, struct blasfeo_dvec *sa, int ai) { print_mat(m, 1, sa->pa + ai, m > 0 ? m : 1, "%9.5e\t"); }
 void blasfeo_print_tran_dvec(int m, struct blasfeo_dvec *sa, int ai) { print_mat(1, m, sa->pa + ai, 1, "%9.5f "); }
 void blasfeo_print_exp_tran_dvec(int m, struct blasfeo_dvec *sa, int ai) { print_mat(1, m, sa->pa + ai, 1, "%9.5e\t"); }
+
+/* ---- Cholesky, lower, of the leading m x m part; with _mn the n columns of an m x n matrix (m >= n: the rows below the
+ * square part are divided through as well).  BLASFEO's convention for a non-positive pivot: the column of the factor is ZERO
+ * (reciprocal pivot 0), not NaN -- treeQP's `<= regTol` test of the diagonal relies on it (dual_Newton_common.c:62). ---- */
+void blasfeo_dpotrf_l_mn(int m, int n, struct blasfeo_dmat *sC, int ci, int cj, struct blasfeo_dmat *sD, int di, int dj) {
+    for (int j = 0; j < n; j++) {
+        for (int i = j; i < m; i++) {
+            double acc = EL(sC, ci + i, cj + j);
+            for (int k = 0; k < j; k++) acc -= EL(sD, di + i, dj + k) * EL(sD, di + j, dj + k);
+            EL(sD, di + i, dj + j) = acc;
+        }
+        const double piv = EL(sD, di + j, dj + j);
+        const double rinv = piv > 0.0 ? 1.0 / sqrt(piv) : 0.0;
+        for (int i = j; i < m; i++) EL(sD, di + i, dj + j) *= rinv;
+    }
+}
+void blasfeo_dpotrf_l(int m, struct blasfeo_dmat *sC, int ci, int cj, struct blasfeo_dmat *sD, int di, int dj) {
+    blasfeo_dpotrf_l_mn(m, m, sC, ci, cj, sD, di, dj);
+}

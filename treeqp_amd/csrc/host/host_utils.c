@@ -390,3 +390,37 @@ void regularization_print_status(regType_t reg_type, reg_result_t reg_res)
 }
 
 void blasfeo_print_target(void) { printf("BLASFEO target: treeqp_amd column-major compat layer (host) + HIP gfx950 (device)\n"); }
+
+/* ------------------------------------------------------------------------------------- */
+/* regularised Cholesky utility (dual_Newton_common.c:36-123); one body for both shapes   */
+/* ------------------------------------------------------------------------------------- */
+#include "treeqp/src/dual_Newton_common.h"
+#include <blasfeo_d_aux.h>
+#include <blasfeo_d_blas.h>
+
+static reg_result_t potrf_reg(struct blasfeo_dmat *M, struct blasfeo_dmat *CholM, int ncol, regType_t reg_type, double reg_tol, double reg_val)
+{
+    const int m = M->m;
+    reg_result_t res = TREEQP_NO_REGULARIZATION_ADDED;
+    if (reg_type == TREEQP_ALWAYS_LEVENBERG_MARQUARDT) { blasfeo_ddiare(m, reg_val, M, 0, 0); res = TREEQP_REGULARIZATION_ADDED; }
+    blasfeo_dpotrf_l_mn(m, ncol, M, 0, 0, CholM, 0, 0);
+    if (reg_type != TREEQP_ON_THE_FLY_LEVENBERG_MARQUARDT) return res;
+    int small = 0;
+    for (int j = 0; j < m && j < ncol && !small; j++) small = BLASFEO_DMATEL(CholM, j, j) <= reg_tol;
+    if (small) {
+        blasfeo_ddiare(m, reg_val, M, 0, 0);
+        blasfeo_dpotrf_l_mn(m, ncol, M, 0, 0, CholM, 0, 0);
+        res = TREEQP_REGULARIZATION_ADDED;
+    }
+    return res;
+}
+
+reg_result_t treeqp_dpotrf_l_with_reg_opts(struct blasfeo_dmat *M, struct blasfeo_dmat *CholM, regType_t reg_type, double reg_tol, double reg_val)
+{
+    return potrf_reg(M, CholM, M->m, reg_type, reg_tol, reg_val);
+}
+
+reg_result_t treeqp_dpotrf_l_mn_with_reg_opts(struct blasfeo_dmat *M, struct blasfeo_dmat *CholM, regType_t reg_type, double reg_tol, double reg_val)
+{
+    return potrf_reg(M, CholM, M->n, reg_type, reg_tol, reg_val);
+}

@@ -191,9 +191,8 @@ void treeqp_tdunes_create(const tree_qp_in *qp_in, const treeqp_tdunes_opts_t *o
         else if (opts->qp_solver[k] == TREEQP_QPOASES_SOLVER) { require_dense_unconstrained(qp_in, k); n_dense++; }
         else fatal("Unknown stage QP solver.", NULL);
     }
-    if (n_dense != 0 && n_dense != Nn)
-        fatal("Mixing stage QP solvers across nodes is not available in the MI355X build.", NULL);
-    work->denseStageSolver = n_dense == Nn;
+    /* any mix of the two kinds across nodes is fine (the reference binds the vtable per node, dual_Newton_tree.c:124-162) */
+    work->denseStageSolver = n_dense > 0;
 
     /* integer tables: dual_Newton_tree.c:166-194 */
     work->npar = (int *)c_ptr; c_ptr += (size_t)(Nh + 1) * sizeof(int);
@@ -380,8 +379,15 @@ return_t treeqp_tdunes_solve(const tree_qp_in *qp_in, tree_qp_out *qp_out,
         double *Rf = stage; for (int k = 0; k < Nn; k++) for (int j = 0; j < qp_in->nu[k]; j++) for (int i = 0; i < qp_in->nu[k]; i++) *stage++ = BLASFEO_DMATEL(&qp_in->R[k], i, j);
         double *Sf = stage; for (int k = 0; k < Nn; k++) for (int j = 0; j < qp_in->nx[k]; j++) for (int i = 0; i < qp_in->nu[k]; i++) *stage++ = BLASFEO_DMATEL(&qp_in->S[k], i, j);
         assert(stage <= work->stage + work->stage_doubles);
-        for (int k = 0; k < Nn; k++) require_dense_unconstrained(qp_in, k);
-        DEV_CALL(tqgpu_set_objective_dense(work->device, Qf, Rf, Sf, q, r));
+        int *kind = malloc(sizeof(int) * (size_t)Nn);
+        for (int k = 0; k < Nn; k++) {
+            kind[k] = opts->qp_solver[k] == TREEQP_QPOASES_SOLVER;
+            if (kind[k]) require_dense_unconstrained(qp_in, k); else require_clipping_applicable(qp_in, k);
+        }
+        int rc_obj = tqgpu_set_objective_mixed(work->device, kind, Qf, Rf, Sf, q, r);
+        free(kind);
+        if (rc_obj != TQGPU_OK) fatal("device call failed in treeqp_tdunes_solve", tqgpu_last_error());
+        DEV_CALL(tqgpu_set_bounds(work->device, xmin, xmax, umin, umax));
         /* warm start from whatever slambda holds (set_dual_initialization or the previous solve) */
         DEV_CALL(tqgpu_set_lambda(work->device, flat_of_vecs(work->slambda, Np, &stage)));
     } else {
