@@ -53,7 +53,7 @@ typedef struct tqgpu_opts {
     int lineSearchMaxIter;
     double lineSearchGamma, lineSearchBeta;
     int lineSearchRestartTrigger;
-    int profile;                 /* 0: total device time only; 1: per-iteration event timing */
+    int profile;                 /* 0: total device time only; 1: per-iteration event timing; 3: + per-phase event timing (launch-per-level path) */
 } tqgpu_opts;
 
 typedef struct tqgpu_result {
@@ -115,6 +115,10 @@ int tqgpu_dims(const tqgpu_solver *s, int *sum_nx, int *sum_nu, int *sum_lam, in
  * length >= iter; times are NaN unless opts.profile != 0 */
 int tqgpu_get_iteration_log(tqgpu_solver *s, int *ls_iters, double *iter_times, int cap);
 
+/* opts.profile >= 3: device time per Newton iteration of the reference's phases (treeqp/utils/profiling.h:58-67): build_dual,
+ * newton_direction, line_search; stage_qps[0] = first sweep of the solve, 0 afterwards (phase S of a later iteration IS the accepted
+ * trial sweep of the line search before it).  Arrays of length >= cap (any may be NULL); returns the number of iterations written. */
+int tqgpu_get_phase_log(tqgpu_solver *s, double *stage_qps, double *build_dual, double *newton_direction, double *line_search, int cap);
 /* roofline support: algorithmic bytes and flops of ONE Newton iteration with n_ls line-search
  * trials (closed form of SURVEY.md §8(d) generalised to per-node dimensions) */
 int tqgpu_iteration_cost(const tqgpu_solver *s, int n_ls, double *bytes, double *flops);

@@ -234,3 +234,33 @@ def test_launch_per_level_path_with_changing_iteration_limits(gpu, orc):
         g.close()
     finally:
         del os.environ["TREEQP_AMD_PATH"]
+
+
+def test_per_phase_timers_of_profile_level_3(gpu, orc):
+    """treeqp/utils/profiling.h level 3: time per key operation per iteration (stage_qps, build_dual, newton_direction, line_search).
+    TREEQP_AMD_PROFILE=3 solves on the launch-per-level kernels (whose launches ARE those phases) with HIP events between the phase
+    groups; result and iteration count are those of the default path, every phase of every iteration has a positive device time
+    and the phases of an iteration add up to no more than the iteration."""
+    p = P.linear_chain(2, 5, 5, ubound=0.2)
+    qp = product_qp_from_lti(gpu, p)
+    s = gpu.TdunesSolver(qp)
+    s.set_dual_initialization(p.lambda0)
+    assert s.solve() == 0
+    base_iter, base = qp.info["iter"], qp.solution()
+    assert base_iter >= 2
+    os.environ["TREEQP_AMD_PROFILE"] = "3"
+    try:
+        s.set_dual_initialization(p.lambda0)
+        assert s.solve() == 0
+    finally:
+        del os.environ["TREEQP_AMD_PROFILE"]
+    assert qp.info["iter"] == base_iter
+    assert_solution_close(qp.solution(), base, TOL)
+    t = s.work.timings
+    arr = lambda ptr: np.ctypeslib.as_array(ptr, shape=(t.num_iter,))[:base_iter].copy()
+    sq, bd, nd, ls, it = arr(t.stage_qps_times), arr(t.build_dual_times), arr(t.newton_direction_times), arr(t.line_search_times), arr(t.iter_times)
+    assert sq[0] > 0 and np.all(sq[1:] == 0)
+    for a in (bd, nd, ls):
+        assert np.all(np.isfinite(a)) and np.all(a > 0) and np.all(a < 1e-2)
+    assert np.all(bd + nd + ls <= it * 1.05 + 1e-6)
+    s.destroy()

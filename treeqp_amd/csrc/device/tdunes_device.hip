@@ -837,6 +837,12 @@ struct tqgpu_solver {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> iter_ev;
     std::vector<double> iter_times;
+    /* profile level 3 (profiling.h:38-68): events around the phase groups of every iteration on the launch-per-level path:
+     * [iteration][0..4] = start, gradient + termination test + dual Hessian done, factorisation + substitution done, line search done */
+    std::vector<hipEvent_t> phase_ev;
+    std::vector<double> phase_times;      /* [iteration][3]: build_dual, newton_direction, line_search (seconds) */
+    double first_sweep_time = NAN;        /* phase S of iteration 0 (the later ones are the accepted trial sweeps of the line searches) */
+    hipEvent_t sweep_ev0 = nullptr, sweep_ev1 = nullptr;
     int last_iter = 0;
     bool need_init = true;
     /* fused path for uniform complete trees */
@@ -1437,8 +1443,10 @@ int launch_persist(tqgpu_solver *s, const Opts &O, int &launches, int prologue) 
 /* one Newton iteration on the generic path = its termination test (gradient + check) and the rest (Newton system, step,
  * first trial); `parts` bit 0 / bit 1 select them.  The host enqueues the iteration it expects to be the last one
  * (warm: as many as the previous solve needed) without the rest: ~17 launches that would only find `done` set. */
-void launch_generic_iteration(tqgpu_solver *s, const Opts &O, int h, int &launches, int parts = 3) {
+void launch_generic_iteration(tqgpu_solver *s, const Opts &O, int h, int &launches, int parts = 3, bool phases = false) {
     const Tree &T = s->T; const Data &D = s->D; hipStream_t st = s->stream;
+    auto mark = [&](int i) { if (phases && (size_t)(4 * h + i) < s->phase_ev.size()) (void)hipEventRecord(s->phase_ev[(size_t)(4 * h + i)], st); };
+    mark(0);
     if (parts & 1) {
         hipLaunchKernelGGL(k_grad, dim3(T.Nn - 1), dim3(WAVE), 0, st, T, D, O.termCondition, h); launches++;
         hipLaunchKernelGGL(k_check, dim3(1), dim3(256), 0, st, T, D, O, h); launches++;
@@ -1448,6 +1456,7 @@ void launch_generic_iteration(tqgpu_solver *s, const Opts &O, int h, int &launch
     if (wide) hipLaunchKernelGGL(k_hess_w, dim3(T.Np), dim3(WT), s->lds_hess_w, st, T, D, h);
     else hipLaunchKernelGGL(k_hess, dim3(T.Np), dim3(WAVE), s->lds_hess, st, T, D, h);
     launches++;
+    mark(1);
     for (int lvl = T.Nh - 1; lvl >= 0; lvl--) {
         const int first = s->lvl_first[lvl], count = s->lvl_first[lvl + 1] - first;
         if (wide) hipLaunchKernelGGL(k_factor_w, dim3(count), dim3(WT), s->lds_factor_w, st, T, D, O, first, h);
@@ -1460,9 +1469,11 @@ void launch_generic_iteration(tqgpu_solver *s, const Opts &O, int h, int &launch
         else hipLaunchKernelGGL(k_forward, dim3(count), dim3(WAVE), s->lds_forward, st, T, D, first, h);
         launches++;
     }
+    mark(2);
     hipLaunchKernelGGL(k_ls_begin, dim3(1), dim3(256), 0, st, T, D, h); launches++;
     hipLaunchKernelGGL(k_stage, dim3(T.Nn), dim3(WAVE), s->lds_stage, st, T, D, 1, h, 1); launches++;
     hipLaunchKernelGGL(k_ls_decide, dim3(1), dim3(256), 0, st, T, D, O, h, 1, 0); launches++;
+    mark(3);
 }
 
 /* solution export in one piece: out = [x | u | lam | dlam | mu_x | mu_u] (x and mu_x without the phantom root
@@ -1681,6 +1692,9 @@ extern "C" void tqgpu_destroy(tqgpu_solver *s) {
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (auto &ev : s->iter_ev) (void)hipEventDestroy(ev);
+    for (auto &ev : s->phase_ev) (void)hipEventDestroy(ev);
+    if (s->sweep_ev0) (void)hipEventDestroy(s->sweep_ev0);
+    if (s->sweep_ev1) (void)hipEventDestroy(s->sweep_ev1);
     for (auto &ev : s->ring_ev0) if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : s->ring_ev1) if (ev) (void)hipEventDestroy(ev);
     if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -1940,7 +1954,7 @@ struct SolveCtx {
     Opts O;
     int launches = 0, ring = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool fast = false, persist = false, first_launch = true, prelaunched = false, gpersist = false;
+    bool fast = false, persist = false, first_launch = true, prelaunched = false, gpersist = false, phases = false;
 #ifdef TQ_HOSTPROF
     std::chrono::steady_clock::time_point hp0, hp1, hp2;
 #endif
@@ -1972,7 +1986,14 @@ int solve_begin(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, GItem *defer
     }
     s->iter_times.assign((size_t)std::max(o->maxIter, 1), NAN);
 
-    cx.fast = tiered_capable(s);
+    cx.fast = tiered_capable(s) && o->profile < 3;          /* level 3: the launch-per-level kernels, whose launches ARE the reference's phases */
+    cx.phases = o->profile >= 3;
+    if (cx.phases) {
+        while ((int)s->phase_ev.size() < 4 * (o->maxIter + 1)) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); s->phase_ev.push_back(ev); }
+        if (!s->sweep_ev0) { HIP_TRY(hipEventCreate(&s->sweep_ev0)); HIP_TRY(hipEventCreate(&s->sweep_ev1)); }
+    }
+    s->phase_times.assign((size_t)3 * std::max(o->maxIter, 1), NAN);
+    s->first_sweep_time = NAN;
     cx.persist = persist_capable(s) && !o->profile && o->maxIter > 0;
     cx.gpersist = !cx.persist && uses_gpersist(s, defer != nullptr) && !o->profile && o->maxIter > 0;
     if (cx.gpersist) cx.persist = true;                  /* same host flow: one launch, verdict through the result block */
@@ -1993,8 +2014,10 @@ int solve_begin(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, GItem *defer
         /* the current buffer is lam0 at the start of every solve */
         HIP_TRY(hipMemcpyAsync(D.lam0, s->d_lam_init, sizeof(double) * (size_t)s->sum_nx, hipMemcpyDeviceToDevice, st));
         /* first sweep at lambda0 (phase S of iteration 0 + fval0); the persistent launch does it as its prologue */
+        if (cx.phases) HIP_TRY(hipEventRecord(s->sweep_ev0, st));
         hipLaunchKernelGGL(k_stage, dim3(T.Nn), dim3(WAVE), s->lds_stage, st, T, D, 0, 0, 0); cx.launches++;
         hipLaunchKernelGGL(k_fval_init, dim3(1), dim3(256), 0, st, T, D); cx.launches++;
+        if (cx.phases) HIP_TRY(hipEventRecord(s->sweep_ev1, st));
     } else {
 #ifdef TQ_HOSTPROF
         cx.hp1 = HP_NOW();
@@ -2040,6 +2063,7 @@ int solve_end(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, tqgpu_result *
     if (o->profile) HIP_TRY(hipEventRecord(s->iter_ev[0], st));
     int chunk = s->last_iter > 0 ? std::min(s->last_iter + 1, 16) : s->chunk;
     bool predicted = s->last_iter > 0 && !fast && !persist;     /* the chunk is a prediction: its last iteration should only find convergence */
+    if (cx.phases) { chunk = 1; predicted = false; }            /* phase timing: one iteration per read-back, so that every recorded event belongs to work that ran */
     int rest_due = -1;                                          /* iteration whose termination test ran, whose step did not */
     while (!finished) {
         const int n = persist ? 0 : std::min(chunk, o->maxIter - h);
@@ -2060,7 +2084,7 @@ int solve_end(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, tqgpu_result *
                 int parts = 3;
                 if (rest_due == h + i) parts &= ~1;                                   /* its test already ran */
                 if (predicted && i == n - 1) { parts &= ~2; deferred = h + i; }
-                if (parts) launch_generic_iteration(s, O, h + i, launches, parts);
+                if (parts) launch_generic_iteration(s, O, h + i, launches, parts, cx.phases);
             }
             if (o->profile && ev_idx + 1 < (int)s->iter_ev.size()) HIP_TRY(hipEventRecord(s->iter_ev[++ev_idx], st));
         }
@@ -2083,7 +2107,7 @@ int solve_end(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, tqgpu_result *
         }
         h = s->h_ctrl->iter;
         finished = s->h_ctrl->done != 0;
-        chunk = s->chunk;
+        chunk = cx.phases ? 1 : s->chunk;
         predicted = false;
         /* the termination test of the deferred iteration was enqueued behind the FIRST trial of the line search before it: when that
          * line search needed further trials (enqueued above, after the read-back), the test found the search pending and did nothing --
@@ -2110,6 +2134,13 @@ int solve_end(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, tqgpu_result *
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return fail(TQGPU_ENODEVICE, std::string("kernel launch failed: ") + hipGetErrorString(le));
 
+    if (cx.phases) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, s->sweep_ev0, s->sweep_ev1) == hipSuccess) s->first_sweep_time = 1e-3 * t;
+        for (int i = 0; i < host_iter && (size_t)(4 * i + 3) < s->phase_ev.size() && (size_t)(3 * i + 2) < s->phase_times.size(); i++)
+            for (int ph = 0; ph < 3; ph++)
+                if (hipEventElapsedTime(&t, s->phase_ev[(size_t)(4 * i + ph)], s->phase_ev[(size_t)(4 * i + ph + 1)]) == hipSuccess) s->phase_times[(size_t)(3 * i + ph)] = 1e-3 * t;
+    }
     if (o->profile) {
         for (int i = 0; i < host_iter && i + 1 < (int)s->iter_ev.size() && i < (int)s->iter_times.size(); i++) {
             float t = 0.f;
@@ -2565,6 +2596,24 @@ extern "C" int tqgpu_get_iteration_log(tqgpu_solver *s, int *ls_iters, double *i
         if (iter_times) iter_times[i] = i < (int)s->iter_times.size() ? s->iter_times[i] : NAN;
     }
     return TQGPU_OK;
+}
+
+/* profile level 3: per Newton iteration the device time of the reference's phases (profiling.h:58-67) on the launch-per-level path:
+ * build_dual = gradient, termination test, dual Hessian; newton_direction = backward factorisation + forward substitution;
+ * line_search = direction test + first trial sweep + Armijo decision (further trials of a backtracking search are enqueued after the
+ * read-back and are NOT in this figure).  stage_qps[0] = the first sweep of the solve; phase S of every later iteration IS the accepted
+ * trial sweep of the line search before it, so stage_qps[i > 0] = 0.  NaN where nothing was recorded (opts.profile < 3). */
+extern "C" int tqgpu_get_phase_log(tqgpu_solver *s, double *stage_qps, double *build_dual, double *newton_direction, double *line_search, int cap) {
+    if (!s) return fail(TQGPU_EINVAL, "null solver");
+    const int n = std::min(cap, s->last_iter);
+    for (int i = 0; i < n; i++) {
+        const bool have = (size_t)(3 * i + 2) < s->phase_times.size();
+        if (stage_qps) stage_qps[i] = i == 0 ? s->first_sweep_time : (std::isnan(s->first_sweep_time) ? NAN : 0.0);
+        if (build_dual) build_dual[i] = have ? s->phase_times[(size_t)(3 * i)] : NAN;
+        if (newton_direction) newton_direction[i] = have ? s->phase_times[(size_t)(3 * i + 1)] : NAN;
+        if (line_search) line_search[i] = have ? s->phase_times[(size_t)(3 * i + 2)] : NAN;
+    }
+    return n;
 }
 
 /* Device times (HIP events on the solver's stream, first to last enqueued operation of a solve) of the

@@ -407,7 +407,7 @@ return_t treeqp_tdunes_solve(const tree_qp_in *qp_in, tree_qp_out *qp_out,
     dopts.lineSearchBeta = opts->lineSearchBeta;
     dopts.lineSearchRestartTrigger = opts->lineSearchRestartTrigger;
     const char *penv = getenv("TREEQP_AMD_PROFILE");
-    dopts.profile = (penv && atoi(penv) > 0) ? 1 : 0;
+    dopts.profile = (penv && atoi(penv) > 0) ? atoi(penv) : 0;      /* 1, 2: per-iteration times; 3: per-phase times as well (profiling.h levels) */
 
     double interface_time = treeqp_toc(&interface_tmr);
     const double t_upload = interface_time;
@@ -459,6 +459,11 @@ return_t treeqp_tdunes_solve(const tree_qp_in *qp_in, tree_qp_out *qp_out,
     timings->total_time = qp_out->info.total_time;
     for (int i = 0; i < timings->num_iter; i++) { timings->ls_iters[i] = 0; timings->iter_times[i] = NAN; }
     tqgpu_get_iteration_log(work->device, timings->ls_iters, timings->iter_times, timings->num_iter);
+    for (int i = 0; i < timings->num_iter; i++)
+        timings->stage_qps_times[i] = timings->build_dual_times[i] = timings->newton_direction_times[i] = timings->line_search_times[i] = NAN;
+    if (dopts.profile >= 3)
+        tqgpu_get_phase_log(work->device, timings->stage_qps_times, timings->build_dual_times, timings->newton_direction_times,
+                            timings->line_search_times, timings->num_iter);
     timers_update(timings);
 
     return status;
