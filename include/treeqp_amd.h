@@ -54,6 +54,11 @@ typedef struct tqgpu_opts {
     double lineSearchGamma, lineSearchBeta;
     int lineSearchRestartTrigger;
     int profile;                 /* 0: total device time only; 1: per-iteration event timing; 3: + per-phase event timing (launch-per-level path) */
+    int checkLastActiveSet;      /* treeqp_tdunes_opts_t.checkLastActiveSet (dual_Newton_tree.c:98, default 1 there).  In the reference the option
+                                    changes the work, never the result (a kept Cholesky factor is bit-identical to a rebuilt one), so 0 and 1 both
+                                    run the default kernel, which rebuilds every pass.  2 selects the kernel variant that keeps the factor data of
+                                    a workgroup (tier subtree) whose active set did not change and only substitutes (persistent path only); its
+                                    steps agree with rebuilt ones to rounding, not bit for bit -- see DESIGN.md "checkLastActiveSet" */
 } tqgpu_opts;
 
 typedef struct tqgpu_result {

@@ -264,3 +264,37 @@ def test_per_phase_timers_of_profile_level_3(gpu, orc):
         assert np.all(np.isfinite(a)) and np.all(a > 0) and np.all(a < 1e-2)
     assert np.all(bd + nd + ls <= it * 1.05 + 1e-6)
     s.destroy()
+
+
+KEEP_CASES = [("c2", lambda: P.linear_chain(2, 9, 9), False, None, {}),
+              ("c1_58_iterations", lambda: P.spring_mass(xmax1=0.2), True, None, {}),
+              ("chain_far_start", lambda: P.linear_chain(2, 6, 6, ubound=0.1), False, 3.0, dict(lineSearchBeta=0.9, lineSearchMaxIter=40)),
+              ("multistage_far_start", lambda: P.spring_mass(md=3, Nr=2, Nh=7), False, 3.0, {})]
+
+
+@pytest.mark.parametrize("name,make,elim,scale,o", KEEP_CASES, ids=[c[0] for c in KEEP_CASES])
+def test_factor_keeping_kernel_variant(gpu, orc, name, make, elim, scale, o):
+    """checkLastActiveSet == 2: the kernel variant in which a workgroup whose active set (and that of everything below it) did
+    not change keeps its factor data and only substitutes -- dual_Newton_tree.c:334-405, 556-614 at workgroup granularity.  The
+    reference's option never changes a result, so the expectation is the oracle's solve, whatever its own setting: same status,
+    same iteration and trial counts, solution within TOL.  Also through the drop-in API (opts.checkLastActiveSet = 2)."""
+    p = make()
+    qp = product_qp_from_lti(gpu, p, eliminate_x0=elim)
+    flat = qp.flat()
+    lam0 = p.lambda0 if scale is None else scale * np.random.Generator(np.random.PCG64(0)).standard_normal(len(p.lambda0))
+    ref = orc.solve(flat, orc.default_opts(**o), lam0)
+    assert ref["status"] == 0
+    g = gpu.TqGpu(flat["nk"], flat["nx"], flat["nu"]).upload(flat, lam0)
+    assert g.path == 2
+    for mode in (2, 1, 2):                                  # either kernel after the other on one mirror
+        g.set_lambda(lam0)
+        r = g.solve(checkLastActiveSet=mode, **o)
+        assert (r["status"], r["iter"], r["ls_total"]) == (0, ref["iter"], ref["ls_total"]), mode
+        assert_solution_close(g.solution(), ref, TOL)
+    g.close()
+    if scale is None:
+        s = gpu.TdunesSolver(qp, checkLastActiveSet=2)
+        s.set_dual_initialization(lam0)
+        assert s.solve() == 0 and qp.info["iter"] == ref["iter"]
+        assert_solution_close(qp.solution(), ref, TOL)
+        s.destroy()

@@ -107,8 +107,8 @@ __global__ void __launch_bounds__(FW * WAVE) sg_bench(PConst C, Opts O, PSync Sy
                 GhRegs<NX, NU, MD> g0, g1;
                 p_gh_load<NX, NU, MD>(C, Sy, L, p_slot_node<NX, NU, MD>(loc0, l0, s, C), loc0, false, 1u, lane, g0);
                 if (loc1 < nbt) p_gh_load<NX, NU, MD>(C, Sy, L, p_slot_node<NX, NU, MD>(loc1, l0, s, C), loc1, false, 1u, lane, g1);
-                acc += p_gh_compute<NX, NU, MD>(L, loc0, lane, g0, O.termCondition);
-                if (loc1 < nbt) acc += p_gh_compute<NX, NU, MD>(L, loc1, lane, g1, O.termCondition);
+                acc += p_gh_compute<NX, NU, MD>(L, loc0, lane, g0, O.termCondition, true);
+                if (loc1 < nbt) acc += p_gh_compute<NX, NU, MD>(L, loc1, lane, g1, O.termCondition, true);
             }
             __syncthreads();
         }

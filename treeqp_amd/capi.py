@@ -98,7 +98,7 @@ class GpuOpts(C.Structure):
     _fields_ = [("maxIter", C.c_int), ("termCondition", C.c_int), ("stationarityTolerance", C.c_double),
                 ("regType", C.c_int), ("regTol", C.c_double), ("regValue", C.c_double),
                 ("lineSearchMaxIter", C.c_int), ("lineSearchGamma", C.c_double), ("lineSearchBeta", C.c_double),
-                ("lineSearchRestartTrigger", C.c_int), ("profile", C.c_int)]
+                ("lineSearchRestartTrigger", C.c_int), ("profile", C.c_int), ("checkLastActiveSet", C.c_int)]
 
 
 class GpuResult(C.Structure):
@@ -410,7 +410,7 @@ def shard_unique_id() -> bytes:
 def solve_virtual_ranks(mirrors, **kw) -> dict:
     """Lock-step sharded solve of n mirrors of one problem in this process (diagnostic / tests)."""
     o = GpuOpts(maxIter=100, termCondition=2, stationarityTolerance=1e-8, regType=2, regTol=1e-6, regValue=1e-6,
-                lineSearchMaxIter=50, lineSearchGamma=0.1, lineSearchBeta=0.6, lineSearchRestartTrigger=-1, profile=0)
+                lineSearchMaxIter=50, lineSearchGamma=0.1, lineSearchBeta=0.6, lineSearchRestartTrigger=-1, profile=0, checkLastActiveSet=1)
     for k, v in kw.items():
         if not hasattr(o, k):
             raise KeyError(k)
@@ -426,7 +426,7 @@ def solve_virtual_ranks(mirrors, **kw) -> dict:
 def solve_batch(mirrors, profile=0, **kw) -> list:
     """Batched multi-tree solve: independent mirrors, same options; persistent launches run concurrently."""
     o = GpuOpts(maxIter=100, termCondition=2, stationarityTolerance=1e-8, regType=2, regTol=1e-6, regValue=1e-6,
-                lineSearchMaxIter=50, lineSearchGamma=0.1, lineSearchBeta=0.6, lineSearchRestartTrigger=-1, profile=profile)
+                lineSearchMaxIter=50, lineSearchGamma=0.1, lineSearchBeta=0.6, lineSearchRestartTrigger=-1, profile=profile, checkLastActiveSet=1)
     for k, v in kw.items():
         if not hasattr(o, k):
             raise KeyError(k)
@@ -520,7 +520,7 @@ class TqGpu:
 
     def solve(self, profile=0, **kw) -> dict:
         o = GpuOpts(maxIter=100, termCondition=2, stationarityTolerance=1e-8, regType=2, regTol=1e-6, regValue=1e-6,
-                    lineSearchMaxIter=50, lineSearchGamma=0.1, lineSearchBeta=0.6, lineSearchRestartTrigger=-1, profile=profile)
+                    lineSearchMaxIter=50, lineSearchGamma=0.1, lineSearchBeta=0.6, lineSearchRestartTrigger=-1, profile=profile, checkLastActiveSet=1)
         for k, v in kw.items():
             if not hasattr(o, k):
                 raise KeyError(k)

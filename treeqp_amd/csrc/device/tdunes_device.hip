@@ -114,6 +114,7 @@ struct Data {            /* device pointers, passed by value */
 
 struct Opts {
     int maxIter, termCondition, regType, lsMaxIter, lsRestartTrigger, stamps;
+    int reuse;               /* checkLastActiveSet: keep the factors of workgroups whose active set did not change (persistent path) */
     double tol, regTol, regValue, gamma, beta;
 };
 
@@ -1292,7 +1293,7 @@ int setup_persist(tqgpu_solver *s, int device) {
     int wg = 0;
     for (int i = 0; i < s->n_tiers; i++) { G.l0[i] = s->tier_l0[i]; G.l1[i] = s->tier_l1[i]; G.grid[i] = s->tier_grid[i]; G.chain[i] = s->tier_chain[i]; G.wg0[i] = wg; wg += s->tier_grid[i]; }
     G.G = wg;
-    int per_cu = 0;
+    int per_cu = 0, per_cu_r = 1 << 20;      /* _r: the variant that can keep factors (checkLastActiveSet == 2) */
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     if (!s->mstage) {
@@ -1300,7 +1301,8 @@ int setup_persist(tqgpu_solver *s, int device) {
 #define X(idx, nx, nu, md)                                                                                                   \
     case idx:                                                                                                                \
         s->lds_persist = PLds<nx, nu, md>::DOUBLES * sizeof(double);                                                         \
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f_persist<nx, nu, md>, FW * WAVE, s->lds_persist));    \
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f_persist<nx, nu, md, false>, FW * WAVE, s->lds_persist)); \
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_r, f_persist<nx, nu, md, true>, FW * WAVE, s->lds_persist)); \
         break;
             FAST_TABLE(X)
 #undef X
@@ -1311,7 +1313,8 @@ int setup_persist(tqgpu_solver *s, int device) {
 #define X(idx, nx, nu, md)                                                                                                   \
     case idx:                                                                                                                \
         s->lds_persist = std::max(PLds<nx, nu, md>::DOUBLES, PLds<nx, nu, 1>::DOUBLES) * sizeof(double);                     \
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f_mpersist<nx, nu, md>, FW * WAVE, s->lds_persist));   \
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f_mpersist<nx, nu, md, false>, FW * WAVE, s->lds_persist)); \
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_r, f_mpersist<nx, nu, md, true>, FW * WAVE, s->lds_persist)); \
         break;
             MSTAGE_TABLE(X)
 #undef X
@@ -1321,7 +1324,7 @@ int setup_persist(tqgpu_solver *s, int device) {
     if (const char *e = getenv("TREEQP_AMD_LDS_PAD")) {      /* experiment: force fewer workgroups per CU */
         s->lds_persist += (size_t)atoi(e) * 1024;
         switch (s->fast) {
-#define X(idx, nx, nu, md) case idx: if (!s->mstage) { allow_lds(f_persist<nx, nu, md>, s->lds_persist); HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f_persist<nx, nu, md>, FW * WAVE, s->lds_persist)); } break;
+#define X(idx, nx, nu, md) case idx: if (!s->mstage) { allow_lds(f_persist<nx, nu, md, false>, s->lds_persist); HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f_persist<nx, nu, md, false>, FW * WAVE, s->lds_persist)); } break;
             FAST_TABLE(X)
 #undef X
             default: break;
@@ -1329,6 +1332,7 @@ int setup_persist(tqgpu_solver *s, int device) {
     }
     /* every workgroup must be resident at once (they wait for each other); keep one block per CU of
      * margin against the occupancy query over-reporting (MI355X guide, "Residency and cooperative launch") */
+    per_cu = std::min(per_cu, per_cu_r);
     /* one workgroup per CU needs no margin (the figure is exact when registers allow a single 4-wave workgroup);
      * with more per CU keep half a CU-load of workgroups in hand */
     const int capacity = per_cu <= 1 ? prop.multiProcessorCount * per_cu : prop.multiProcessorCount * per_cu - prop.multiProcessorCount / 2;
@@ -1341,7 +1345,8 @@ int setup_persist(tqgpu_solver *s, int device) {
     const size_t n_sch = (size_t)s->Nn * (nx0 * nx0 + nx0) * 2, n_dlt = (size_t)s->sum_nx * 2, n_ndt = (size_t)s->Nn * 2 * nx0 * 2;
     const size_t n_parts = (size_t)G.G * 4, n_errs = (size_t)G.G * 2;
     const size_t n_bparts = (size_t)G.G * 16;
-    const size_t bytes = (n_sch + n_dlt + n_ndt + n_parts + n_errs + 32 + n_bparts) * sizeof(unsigned long long);
+    const size_t n_sgt = (size_t)s->Nn * 2, n_rfl = (size_t)s->Nn * 2;      /* active-set signature / reuse flag of a tier subtree root (one tagged double each) */
+    const size_t bytes = (n_sch + n_dlt + n_ndt + n_parts + n_errs + 32 + n_bparts + n_sgt + n_rfl) * sizeof(unsigned long long);
     HIP_TRY(hipMalloc(&s->sync_slab, bytes));
     HIP_TRY(hipMemset(s->sync_slab, 0, bytes));
     s->sync_bytes = bytes;
@@ -1353,6 +1358,7 @@ int setup_persist(tqgpu_solver *s, int device) {
     s->psync.cmd = s->psync.errs + n_errs + 24;          /* same 256-byte block: halt | timeout | cmd | vrd */
     s->psync.vrd = s->psync.errs + n_errs + 28;
     s->psync.bparts = s->psync.errs + n_errs + 32;
+    s->psync.sgt = s->psync.bparts + n_bparts; s->psync.rfl = s->psync.sgt + n_sgt;
     s->psync.seq = 0; s->psync.trip = 0;
     /* XCD-aware placement: the hardware deals workgroups round-robin over the 8 XCDs (workgroup b -> XCD b % 8)
      * and every XCD has its own L2.  A tier subtree talks to its parent and its children only, so whole
@@ -1423,14 +1429,16 @@ int launch_persist(tqgpu_solver *s, const Opts &O, int &launches, int prologue) 
     }
     if (!s->mstage) {
         switch (s->fast) {
-#define X(idx, nx, nu, md) case idx: hipLaunchKernelGGL((f_persist<nx, nu, md>), dim3(s->geom.G), dim3(FW * WAVE), s->lds_persist, st, s->pconst, O, s->geom, s->psync, prologue); break;
+#define X(idx, nx, nu, md) case idx: if (O.reuse) hipLaunchKernelGGL((f_persist<nx, nu, md, true>), dim3(s->geom.G), dim3(FW * WAVE), s->lds_persist, st, s->pconst, O, s->geom, s->psync, prologue); \
+                                    else hipLaunchKernelGGL((f_persist<nx, nu, md, false>), dim3(s->geom.G), dim3(FW * WAVE), s->lds_persist, st, s->pconst, O, s->geom, s->psync, prologue); break;
             FAST_TABLE(X)
 #undef X
             default: break;
         }
     } else {
         switch (s->fast) {
-#define X(idx, nx, nu, md) case idx: hipLaunchKernelGGL((f_mpersist<nx, nu, md>), dim3(s->geom.G), dim3(FW * WAVE), s->lds_persist, st, s->pconst, O, s->geom, s->psync, prologue); break;
+#define X(idx, nx, nu, md) case idx: if (O.reuse) hipLaunchKernelGGL((f_mpersist<nx, nu, md, true>), dim3(s->geom.G), dim3(FW * WAVE), s->lds_persist, st, s->pconst, O, s->geom, s->psync, prologue); \
+                                    else hipLaunchKernelGGL((f_mpersist<nx, nu, md, false>), dim3(s->geom.G), dim3(FW * WAVE), s->lds_persist, st, s->pconst, O, s->geom, s->psync, prologue); break;
             MSTAGE_TABLE(X)
 #undef X
             default: break;
@@ -1967,7 +1975,7 @@ int solve_begin(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, GItem *defer
     HIP_TRY(hipSetDevice(s->device));
     Opts &O = cx.O;
     O.maxIter = o->maxIter; O.termCondition = o->termCondition; O.regType = o->regType;
-    O.lsMaxIter = o->lineSearchMaxIter; O.lsRestartTrigger = o->lineSearchRestartTrigger;
+    O.lsMaxIter = o->lineSearchMaxIter; O.lsRestartTrigger = o->lineSearchRestartTrigger; O.reuse = o->checkLastActiveSet == 2 ? 1 : 0;
     O.tol = o->stationarityTolerance; O.regTol = o->regTol; O.regValue = o->regValue;
     O.gamma = o->lineSearchGamma; O.beta = o->lineSearchBeta;
     { const char *e = getenv("TREEQP_AMD_STAMPS"); O.stamps = e ? std::max(1, atoi(e)) : 0; }
@@ -2499,7 +2507,7 @@ extern "C" int tqgpu_solve_virtual_ranks(tqgpu_solver **R, int n, const tqgpu_op
     HIP_TRY(hipSetDevice(R[0]->device));
     Opts O;
     O.maxIter = o->maxIter; O.termCondition = o->termCondition; O.regType = o->regType;
-    O.lsMaxIter = o->lineSearchMaxIter; O.lsRestartTrigger = o->lineSearchRestartTrigger;
+    O.lsMaxIter = o->lineSearchMaxIter; O.lsRestartTrigger = o->lineSearchRestartTrigger; O.reuse = o->checkLastActiveSet == 2 ? 1 : 0;
     O.tol = o->stationarityTolerance; O.regTol = o->regTol; O.regValue = o->regValue;
     O.gamma = o->lineSearchGamma; O.beta = o->lineSearchBeta; O.stamps = 0;
     int launches = 0;

@@ -106,6 +106,8 @@ struct PSync {
     u64 *cmd;               /* [2][2]            top -> everybody: the trial of pass `tag` was rejected; {tau - tauPrev, tau} of the next one */
     u64 *vrd;               /* [2]               top -> everybody: verdict on a batch of trials (tag: batch): accepted chain length, 0 = none */
     u64 *bparts;            /* [G][8][2]         per-workgroup dual-function partials of a batch of trials (tag: batch) */
+    u64 *sgt;               /* [nodes][2]        active-set signature (x part) of a tier subtree root node, child -> parent (tag: stage sweep) */
+    u64 *rfl;               /* [nodes][2]        1.0: the child workgroup rooted here keeps its factors this pass, child -> parent (tag: pass) */
     unsigned *halt;         /* == seq: the top workgroup ended this launch                            */
     unsigned *timeout;      /* sticky: a bounded spin gave up                                         */
     unsigned seq;           /* launch number << 16 (low 16 bits of the number are never 0)            */
@@ -197,10 +199,17 @@ struct PLds {
      * ever queues behind a hand-over store (vmcnt is one in-order counter for loads AND stores on gfx9). */
     static constexpr int LDA = NX + 2;
     static constexpr int EDGE = NZ * LDA, CST = NZ * 5;
+    /* active-set reuse (checkLastActiveSet): Schur record of my subtree root as last computed; v of every block (child -> parent inside the
+     * workgroup when nothing is rebuilt); integer words: signature of every owned node (bit t: entry t at its upper bound, bit 16 + t:
+     * at its lower bound), signatures per block now (owner, children's x parts) and when its factor was built, flags */
+    static constexpr int ISIG = SLOTS + 2 * NBT * (1 + MD) + 8;
     static constexpr int DOUBLES = NBT * D * S + D * S + NBT * D * LDM + 2 * NBT * D + 16 + SLOTS * NODE + 2 * NBT * D + 3 * NX + 4 * FW
-                                   + FW * U::WAVE_LDS + 32 + 64 + NBT * MD * EDGE + NBT * D + SLOTS * CST + 16;
+                                   + FW * U::WAVE_LDS + 32 + 64 + NBT * MD * EDGE + NBT * D + SLOTS * CST + 16
+                                   + U::SCH + NBT * NX + ISIG / 2 + 2;
     lds_ptr tt, idt, mz, res, dl, red, node, lamb, lamroot, droot, part, wave0, wave, bat;     /* red: reductions of the top workgroup; bat: 64 doubles, reductions of a batch of trials */
     lds_ptr cab, cb, ccst, ctl;                                      /* ctl: the control block, kept by the top workgroup for the launch */
+    lds_ptr srec, vrec;
+    lds_iptr nsig, csig, bsig, fvalid, ruse;                         /* fvalid: my blocks' factor data are those of bsig; ruse: this pass keeps them */
     lds_iptr flag, abort;                                            /* abort: a poll gave up (launch over), leave at the next uniform point */
     __device__ PLds(double *base, int wave_id) {
         tt = to_lds(base); idt = tt + NBT * D * S; mz = idt + D * S; res = mz + NBT * D * LDM; dl = res + NBT * D; red = dl + NBT * D;
@@ -208,6 +217,8 @@ struct PLds {
         lamroot = lamb + 2 * NBT * D; droot = lamroot + 2 * NX; part = droot + NX; wave0 = part + 4 * FW; wave = wave0 + wave_id * U::WAVE_LDS;
         flag = (lds_iptr)(wave0 + FW * U::WAVE_LDS); abort = flag + 1; bat = wave0 + FW * U::WAVE_LDS + 32;
         cab = bat + 64; cb = cab + NBT * MD * EDGE; ccst = cb + NBT * D; ctl = ccst + SLOTS * CST;
+        srec = ctl + 16; vrec = srec + U::SCH;
+        nsig = (lds_iptr)(vrec + NBT * NX); csig = nsig + SLOTS; bsig = csig + NBT * (1 + MD); fvalid = bsig + NBT * (1 + MD); ruse = fvalid + 1;
     }
     __device__ __forceinline__ lds_ptr cab_(int loc, int child) const { return cab + (loc * MD + child) * EDGE; }      /* entry (r, column c) at c * LDA + r */
     __device__ __forceinline__ lds_ptr cb_(int loc) const { return cb + loc * D; }
@@ -288,7 +299,7 @@ __device__ __forceinline__ void p_gh_load(const PConst &C, const PSync &Sy, cons
 }
 
 template <int NX, int NU, int MD>
-__device__ __forceinline__ double p_gh_compute(PLds<NX, NU, MD> &L, int loc, int lane, const GhRegs<NX, NU, MD> &G, int termCondition) {
+__device__ __forceinline__ double p_gh_compute(PLds<NX, NU, MD> &L, int loc, int lane, const GhRegs<NX, NU, MD> &G, int termCondition, bool build) {
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D;
     constexpr int S = PLds<NX, NU, MD>::S;
@@ -301,22 +312,22 @@ __device__ __forceinline__ double p_gh_compute(PLds<NX, NU, MD> &L, int loc, int
     for (int s = 0; s < U::KS; s++) {
         const int cc = g + 4 * s;
         const double ap = G.a[s] * G.pc[s];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(G.a[s], ap, acc, 0, 0, 0);
+        if (build) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(G.a[s], ap, acc, 0, 0, 0);
         part = fma(G.a[s], G.z[s], part);
-        if (live && cc < NX) Tt[D + 1 + cc] = -1.0 * ap;
+        if (build && live && cc < NX) Tt[D + 1 + cc] = -1.0 * ap;
     }
     part = rows_fold<false>(part);
     double e = 0.0;
     if (live && g == 0) {
         const double rv = fma(-1.0, G.xk, G.bk) + part;
         L.res[loc * D + row] = rv;                        /* the gradient itself (res' * dlam); the copy in the tall matrix takes the children's updates */
-        Tt[D] = rv;
+        if (build) Tt[D] = rv;
         e = (termCondition == 2) ? fabs(rv) : rv * rv;
     }
 #pragma unroll
     for (int rr = 0; rr < 4; rr++) {
         const int i = g + 4 * rr;
-        if (live && i < D) {
+        if (build && live && i < D) {
             double w = acc[rr];
             if (i == row) w += G.qk;
             Tt[i] = w;
@@ -484,7 +495,7 @@ __device__ __forceinline__ void p_store_factor(const PLds<NX, NU, MD> &L, int lo
  * GLOBAL: the parent is another workgroup: the record travels as tagged words.  Otherwise the parent block `ploc` is
  * mine and the record is subtracted from its tall matrix in place (child number `cidx`: rows / columns cidx NX ..): the
  * parent's wave then loads rows that already carry its children -- nothing to subtract on its critical path. */
-template <int NX, int NU, int MD, bool GLOBAL>
+template <int NX, int NU, int MD, bool GLOBAL, bool RU = false>
 __device__ __forceinline__ void p_schur(const PLds<NX, NU, MD> &L, int loc, int lane, int ploc, int cidx, u64 *sdst_glb, unsigned tag) {
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D, S = PLds<NX, NU, MD>::S;
@@ -513,7 +524,7 @@ __device__ __forceinline__ void p_schur(const PLds<NX, NU, MD> &L, int loc, int 
     for (int rr = 0; rr < 4; rr++) {
         const int ip = g + 4 * rr;
         if (ip < NX && i <= NX) {
-            if (GLOBAL) { const int off = (i < NX) ? ip + i * NX : NX * NX + ip; st_tag(sdst_glb + 2 * off, acc[rr], tag); }
+            if (GLOBAL) { const int off = (i < NX) ? ip + i * NX : NX * NX + ip; st_tag(sdst_glb + 2 * off, acc[rr], tag); if (RU) L.srec[off] = acc[rr]; }      /* kept: re-posted by passes that keep the factors */
             else dst[rr * dstp] = old[rr] - acc[rr];
         }
     }
@@ -628,7 +639,7 @@ __device__ __forceinline__ double p_forward_tier(const PConst &C, const PSync &S
  * subtree root's x and QinvCal also go to the parent workgroup as tagged words (to_parent).
  * init: first sweep of a solve -- evaluate at the current duals themselves.
  * Returns the node's dual-function term (valid in every lane of the group). */
-template <int NX, int NU, int MD>
+template <int NX, int NU, int MD, bool RU>
 __device__ __forceinline__ double p_stage16(const PConst &C, const PSync &Sy, PLds<NX, NU, MD> &L, int q, int k, int t, lds_ptr gl /* group scratch: D + NX */,
                                             double step, int cb, bool active, bool init, bool to_parent, unsigned tag, const PChain &ch, bool dry) {
     using U = Uni<NX, NU, MD>;
@@ -673,6 +684,7 @@ __device__ __forceinline__ double p_stage16(const PConst &C, const PSync &Sy, PL
     }
     lds_fence();
     double p_q = 0.0, p_h = 0.0;
+    bool at_hi = false, at_lo = false;                        /* the node's active set (dveccl_mask, clipping.c:212-218) */
     if (live) {
         double v = isx ? fma(-1.0, lin, gl[D + t]) : -1.0 * lin;
         if (parent) {
@@ -686,7 +698,7 @@ __device__ __forceinline__ double p_stage16(const PConst &C, const PSync &Sy, PL
         }
         const double unc = winv * v;
         double val, cal;
-        if (unc >= hib) { val = hib; cal = 0.0; } else if (unc <= lob) { val = lob; cal = 0.0; } else { val = unc; cal = winv; }
+        if (unc >= hib) { val = hib; cal = 0.0; at_hi = true; } else if (unc <= lob) { val = lob; cal = 0.0; at_lo = true; } else { val = unc; cal = winv; }
         lds_ptr ns = L.node_(q);
         if (!dry) { if (ch.save_s) ns[4 * NZ + t] = ns[2 * NZ + t]; ns[t] = val; ns[NZ + t] = cal; ns[2 * NZ + t] = unc; ns[3 * NZ + t] = v; }
         if (!dry && to_parent && q == 0 && isx) {         /* my subtree root: the parent workgroup's G + H reads x and QinvCal */
@@ -695,6 +707,16 @@ __device__ __forceinline__ double p_stage16(const PConst &C, const PSync &Sy, PL
         }
         p_q = (wd * val) * val;
         p_h = v * val;
+    }
+    if (RU && !dry) {
+        /* signature of the node's active set: bit t = entry t sits at its upper bound, bit 16 + t = at its lower bound (x entries first).
+         * What the reference keeps as xas / uas for compare_with_previous_active_set (dual_Newton_tree.c:334-368). */
+        const int sh = (threadIdx.x & 48);
+        const unsigned code = (unsigned)((__builtin_amdgcn_ballot_w64(at_hi) >> sh) & 0xFFFFull) | ((unsigned)((__builtin_amdgcn_ballot_w64(at_lo) >> sh) & 0xFFFFull) << 16);
+        if (active && t == 0) {
+            L.nsig[q] = (int)code;
+            if (to_parent && q == 0) st_tag(Sy.sgt + (size_t)k * 2, (double)(code & (((1u << NX) - 1u) * 0x10001u)), tag);      /* x part: my parent's block depends on it */
+        }
     }
     const double qx = row16_sum(isx ? p_q : 0.0), hx = row16_sum(isx ? p_h : 0.0);
     const double ru = row16_sum(isx ? 0.0 : p_q), hu = row16_sum(isx ? 0.0 : p_h);
@@ -770,9 +792,137 @@ __device__ __forceinline__ bool p_sub_children_tagged(const PSync &Sy, const u64
     return ok;
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* checkLastActiveSet (dual_Newton_tree.c:334-405, 556-614, 681-709): keep factors whose blocks did not change */
+/* ------------------------------------------------------------------------------------------ */
+/* The dual Hessian block of a parent depends on the ACTIVE SET of its owner node (x and u) and of its children (x) only:
+ * W = C P C' + blockdiag(P_kids) with P = the clipped inverse weights, which are the inverse weights where a bound is inactive
+ * and zero where it is active.  The reference therefore compares the active set of every node with the previous one and
+ * factorises again only up to the last block that changed; the others keep their Cholesky factor and only substitute.
+ * Here the unit of reuse is the WORKGROUP (a tier subtree): it keeps its factor data -- L^-1, CholUt, M, the Schur record of
+ * its root -- when (a) the signatures of all its blocks equal those of the pass that built the data and (b) every workgroup
+ * below it does the same (its Schur records are then unchanged too); condition (b) travels upwards as one tagged word per
+ * subtree root (rfl), the x signature of a subtree root node as another (sgt).  A pass that keeps the factors replaces, per
+ * block, G + H's Hessian build and the factorisation (5 k cycles) by three small matrix-vector products with the stored
+ * L^-1 / CholUt: y = L^-1 (res - sum of the children's v), v = CholUt y, z0 = L^-T y (0.7 k cycles).
+ * Wave 0 decides; the result is *L.ruse (and `csig`: the signatures of this pass, saved as `bsig` when a build completes). */
+template <int NX, int NU, int MD>
+__device__ __noinline__ void p_reuse_decide(const PConst &C, const PSync &Sy, PLds<NX, NU, MD> &L, int l0, int s, int th, int nbt,
+                                               bool is_top, bool is_bottom, bool can, unsigned tag_sweep, unsigned tag_pass, int lane) {
+    using U = Uni<NX, NU, MD>;
+    const int nint = U::first(th - 1);
+    const unsigned xm = ((1u << NX) - 1u) * 0x10001u;
+    const bool mine = lane < nbt;
+    const int loc = mine ? lane : 0;
+    const bool foreign = mine && !is_bottom && loc >= nint;
+    const int node = p_slot_node<NX, NU, MD>(loc, l0, s, C);
+    int cur[1 + MD];
+    cur[0] = L.nsig[loc];
+#pragma unroll
+    for (int c = 0; c < MD; c++) cur[1 + c] = foreign ? 0 : (L.nsig[MD * loc + 1 + c] & (int)xm);
+    bool ok = true, kids = true;
+    if (can && !is_bottom) {
+        /* children of my last level live in the tier below: their x signatures and whether their workgroups keep their factors */
+        const u64 t0 = wall_clock64();
+        for (;;) {
+            PollGuard pg;
+            ok = true;
+            kids = true;
+            if (foreign) {
+#pragma unroll
+                for (int c = 0; c < MD; c++) {
+                    const size_t kid = (size_t)(kid0g<MD>(node, C) + c);
+                    cur[1 + c] = (int)(unsigned)ld_tag(Sy.sgt + kid * 2, tag_sweep, ok);
+                    kids = kids && ld_tag(Sy.rfl + kid * 2, tag_pass, ok) != 0.0;
+                }
+            }
+            pg.load(Sy);
+            ok = __all(ok);
+            if (ok || !pg.go_on(Sy, t0)) { pg.settle(); break; }
+        }
+        if (!ok && lane == 0) *L.abort = p_abort_code(Sy);
+    }
+    bool same = can && ok && kids && *L.fvalid != 0;
+#pragma unroll
+    for (int c = 0; c <= MD; c++) {
+        same = same && cur[c] == L.bsig[loc * (1 + MD) + c];
+        if (mine) L.csig[loc * (1 + MD) + c] = cur[c];
+    }
+    const bool all_same = __all(!mine || same);
+    if (lane == 0) {
+        *L.ruse = all_same ? 1 : 0;
+        if (!is_top && ok) st_tag(Sy.rfl + (size_t)p_slot_node<NX, NU, MD>(0, l0, s, C) * 2, all_same ? 1.0 : 0.0, tag_pass);
+    }
+}
+
+/* one block of a backward sweep that keeps the factors (see p_reuse_decide); scr: 2 D doubles of the wave's scratch.
+ * Returns the per-lane term of res' * dlam for the root block of the tree (0 otherwise). */
+template <int NX, int NU, int MD>
+__device__ __noinline__ double p_reuse_block(const PConst &C, const PSync &Sy, PLds<NX, NU, MD> &L, int loc, int ii, int t, int th, bool is_bottom, bool is_root,
+                                                unsigned tag, int lane, lds_ptr scr) {
+    using U = Uni<NX, NU, MD>;
+    constexpr int D = U::D, S = PLds<NX, NU, MD>::S, LDM = PLds<NX, NU, MD>::LDM;
+    const int li = lane < D ? lane : 0;
+    const int c = li / NX, j = li - c * NX;
+    double r = L.res[loc * D + li];
+    bool ok = true;
+    if (t < th - 1) r -= L.vrec[(MD * loc + 1 + c) * NX + j];               /* my children are mine: they left their v in LDS */
+    else if (!is_bottom) {
+        /* children in the tier below: the v part of their (re-posted) Schur records */
+        const u64 *src = Sy.sch + ((size_t)(kid0g<MD>(ii, C) + c) * U::SCH + NX * NX + j) * 2;
+        const u64 t0 = wall_clock64();
+        double vv = 0.0;
+        for (;;) {
+            PollGuard pg;
+            ok = true;
+            vv = ld_tag(src, tag, ok);
+            pg.load(Sy);
+            ok = __all(ok);
+            if (ok || !pg.go_on(Sy, t0)) { pg.settle(); break; }
+        }
+        if (!ok && lane == 0) *L.abort = p_abort_code(Sy);
+        r -= ok ? vv : 0.0;
+    }
+    if (lane < D) scr[lane] = r;
+    lds_fence();
+    lds_cptr X = L.tt_(loc);
+    double y0 = 0.0, y1 = 0.0;                                             /* y = L^-1 r: row li of L^-1 is contiguous */
+#pragma unroll
+    for (int k = 0; k < D; k += 2) { y0 = fma(X[li * S + 1 + NX + k], scr[k], y0); y1 = fma(X[li * S + 2 + NX + k], scr[k + 1], y1); }
+    const double y = y0 + y1;
+    if (lane < D) scr[D + lane] = y;
+    lds_fence();
+    const int lr = lane < NX ? lane : 0;
+    double z0 = 0.0, z1 = 0.0, v0 = 0.0, v1 = 0.0;                         /* z = L^-T y (the block's forward record z0), v = CholUt y */
+#pragma unroll
+    for (int k = 0; k < D; k += 2) {
+        const double ya = scr[D + k], yb = scr[D + k + 1];
+        z0 = fma(X[k * S + 1 + NX + li], ya, z0); z1 = fma(X[(k + 1) * S + 1 + NX + li], yb, z1);
+        v0 = fma(X[k * S + 1 + lr], ya, v0); v1 = fma(X[(k + 1) * S + 1 + lr], yb, v1);
+    }
+    const double z = z0 + z1, v = v0 + v1;
+    double pd = 0.0;
+    if (lane < D) L.mz_(loc)[lane * LDM] = z;
+    if (is_root) {
+        if (lane < D) {
+            if (th == 1 && !is_bottom && ok) st_tag(Sy.dlt + (size_t)(NX * kid0g<MD>(0, C) + lane) * 2, z, tag);
+            L.dl[lane] = z; pd = L.res[lane] * z;
+        }
+    } else if (t > 0) {
+        if (lane < NX) L.vrec[loc * NX + lane] = v;
+    } else if (ok) {
+        /* my subtree root: the parent workgroup gets the record again -- S as it was built, v of this pass */
+        u64 *dst = Sy.sch + (size_t)ii * U::SCH * 2;
+        if (lane < NX * NX) st_tag(dst + 2 * lane, L.srec[lane], tag);
+        if (lane < NX) st_tag(dst + 2 * (NX * NX + lane), v, tag);
+    }
+    lds_fence();
+    return pd;
+}
+
 /* stage sweep over the nodes this workgroup owns (the owner nodes of its blocks in heap order, then --
  * bottom tier -- the leaves below), four nodes per wave; returns the wave's sum of the node terms */
-template <int NX, int NU, int MD>
+template <int NX, int NU, int MD, bool RU>
 __device__ __forceinline__ double p_stage_owned(const PConst &C, const PSync &Sy, PLds<NX, NU, MD> &L, int l0, int nown, int s, int wave, int lane,
                                                 double step, int cb, bool init, bool to_parent, unsigned tag, const PChain &ch, bool dry) {
     using U = Uni<NX, NU, MD>;
@@ -784,7 +934,7 @@ __device__ __forceinline__ double p_stage_owned(const PConst &C, const PSync &Sy
         const int q = base + wave * 4 + grp;
         const bool active = q < nown;
         const int k = active ? p_slot_node<NX, NU, MD>(q, l0, s, C) : 0;
-        fsum += p_stage16<NX, NU, MD>(C, Sy, L, active ? q : 0, k, t16, gl, step, cb, active, init, to_parent, tag, ch, dry);
+        fsum += p_stage16<NX, NU, MD, RU>(C, Sy, L, active ? q : 0, k, t16, gl, step, cb, active, init, to_parent, tag, ch, dry);
     }
     return rows_fold<false>(fsum);       /* every lane of a 16-lane group holds its group's sum */
 }
@@ -878,7 +1028,7 @@ __device__ __forceinline__ bool p_gather_batch(const PSync &Sy, PLds<NX, NU, MD>
 }
 
 /* the life of one workgroup = one tier subtree: tier `tier`, subtree (complete part) or scenario (chain part) `s` */
-template <int NX, int NU, int MD>
+template <int NX, int NU, int MD, bool RU>
 __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeom &Gm, const PSync &Sy_in, int prologue, int wg, int tier, int s, double *lds_all) {
     using U = Uni<NX, NU, MD>;
     PSync Sy = Sy_in;
@@ -915,6 +1065,9 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
             c->done = 0; c->status = 0; c->iter = 0; c->cur = 0; c->ls_pending = 0; c->ls_iter = 0; c->ls_total = 0; c->ls_last = 0;
             c->restart_counter = 0; c->n_reg = 0; c->tau = 0.0; c->tauPrev = 0.0; c->fval0 = 0.0; c->fval = 0.0; c->dot = 0.0; c->err = 0.0;
             cg->n_reg = 0;                                                    /* counted in global memory by whoever regularises a block */
+#ifdef TQ_REUSE_DEBUG
+            c->pad0 = 0;
+#endif
         }
     } else {
         if (__hip_atomic_load(&cg->done, RLX, AGENT) || __hip_atomic_load(&cg->ls_pending, RLX, AGENT)) return;
@@ -925,7 +1078,7 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
     /* ---- load the state this workgroup owns: duals of my blocks and of my root, node store ---- */
     {
         const PDump *dp = C.dump;
-        if (threadIdx.x == 0) *L.abort = 0;
+        if (threadIdx.x == 0) { *L.abort = 0; *L.fvalid = 0; *L.ruse = 0; }
         for (int i = threadIdx.x; i < D * PLds<NX, NU, MD>::S; i += FW * WAVE) {      /* identity rows of the tall matrices: entry (m, j) at j * S + m */
             const int j = i / PLds<NX, NU, MD>::S, m = i - j * PLds<NX, NU, MD>::S;
             L.idt[i] = (m == j) ? 1.0 : 0.0;
@@ -1004,7 +1157,7 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
     pstamp(C, O, (unsigned)O.stamps, tier, s, 26);                     /* 26: state and constants loaded */
     if (prologue) {
         /* ---- first sweep of the solve: stage QPs at lambda0, fval0 ---- */
-        const double fsum = p_stage_owned<NX, NU, MD>(C, Sy, L, l0, nown, s, wave, lane, 0.0, cur, true, !is_top, Sy.seq | 1u, PChain{1, 0.0, 0.0}, false);
+        const double fsum = p_stage_owned<NX, NU, MD, RU>(C, Sy, L, l0, nown, s, wave, lane, 0.0, cur, true, !is_top, Sy.seq | 1u, PChain{1, 0.0, 0.0}, false);
         if (lane == 0) { L.part[4 * wave + 2] = fsum; L.part[4 * wave + 1] = 0.0; }
         __syncthreads();
         nd = 1u;
@@ -1026,6 +1179,17 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
 #ifdef TQ_STAMPS
         pstamp(C, O, e, tier, s, 31);                                     /* slot 31 - slot 0 = cost of one stamp */
 #endif
+        /* ---- do I keep my factors this pass? (checkLastActiveSet) ---- */
+        bool build = true;
+        if (RU) {
+            if (wave == 0) p_reuse_decide<NX, NU, MD>(C, Sy, L, l0, s, th, nbt, is_top, is_bottom, nd > 0u, Sy.seq | nd, tag_e, lane);
+            __syncthreads();
+            build = *L.ruse == 0;
+            if (build && threadIdx.x == 0) *L.fvalid = 0;                       /* G + H overwrites the tall matrices, i.e. the factor data */
+#ifdef TQ_REUSE_DEBUG
+            if (!build && is_top && threadIdx.x == 0) c->pad0 += 1;
+#endif
+        }
         /* ---- G + H for my blocks (heap order inside the subtree), two blocks per wave in flight; the
          * children of my bottom-level blocks were staged by the child workgroups (polled) ---- */
         {
@@ -1036,10 +1200,10 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
                 GhRegs<NX, NU, MD> g0, g1;
                 p_gh_load<NX, NU, MD>(C, Sy, L, p_slot_node<NX, NU, MD>(loc0, l0, s, C), loc0, !is_bottom && loc0 >= nint, nd, lane, g0);
                 if (loc1 < nbt) p_gh_load<NX, NU, MD>(C, Sy, L, p_slot_node<NX, NU, MD>(loc1, l0, s, C), loc1, !is_bottom && loc1 >= nint, nd, lane, g1);
-                double v = p_gh_compute<NX, NU, MD>(L, loc0, lane, g0, O.termCondition);
+                double v = p_gh_compute<NX, NU, MD>(L, loc0, lane, g0, O.termCondition, build);
                 err = (O.termCondition == 2) ? nanmax(err, v) : err + v;
                 if (loc1 < nbt) {
-                    v = p_gh_compute<NX, NU, MD>(L, loc1, lane, g1, O.termCondition);
+                    v = p_gh_compute<NX, NU, MD>(L, loc1, lane, g1, O.termCondition, build);
                     err = (O.termCondition == 2) ? nanmax(err, v) : err + v;
                 }
             }
@@ -1115,14 +1279,19 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
                 const int nb = U::width(t);
                 /* waves without a block on this level prepare the forward steps of the levels below (at most two each) */
                 const int idle = FW - nb, lo = U::first(t + 1);
-                if (wave >= nb) {
+                if (wave >= nb && build) {
                     for (int r = 0; r < 2; r++) {
                         const int loc = prep_next - (r * idle + (wave - nb));
                         if (loc >= lo) p_prep_forward<NX, NU, MD>(L, loc, lane);
                     }
                 }
                 { const int avail = prep_next - lo + 1, take = avail < 2 * idle ? avail : 2 * idle; prep_next -= take > 0 ? take : 0; }
-                if (wave < nb) {
+                if (RU && wave < nb && !build) {
+                    const int loc = U::first(t) + wave;
+                    const double pd = p_reuse_block<NX, NU, MD>(C, Sy, L, loc, p_slot_node<NX, NU, MD>(loc, l0, s, C), t, th, is_bottom, is_top && t == 0, tag_e, lane, L.wave);
+                    if (is_top && t == 0) dotp = pd;
+                }
+                if (wave < nb && build) {
                     const int loc = U::first(t) + wave, ii = p_slot_node<NX, NU, MD>(loc, l0, s, C);
                     const bool is_root = is_top && t == 0;
                     bool ok = true;
@@ -1150,10 +1319,11 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
                     if (!is_root) {
                         p_store_factor<NX, NU, MD>(L, loc, lane, Tc);
                         FSTAMP(3);
-                        if (t == 0) { if (ok) p_schur<NX, NU, MD, true>(L, loc, lane, 0, 0, Sy.sch + (size_t)ii * U::SCH * 2, tag_e); }
+                        if (t == 0) { if (ok) p_schur<NX, NU, MD, true, RU>(L, loc, lane, 0, 0, Sy.sch + (size_t)ii * U::SCH * 2, tag_e); }
                         else p_schur<NX, NU, MD, false>(L, loc, lane, U::first(t - 1) + wave / MD, wave % MD, nullptr, 0u);
                         FSTAMP(4);
                     } else {
+                        if (RU) p_store_factor<NX, NU, MD>(L, loc, lane, Tc);          /* a later pass may keep the root's factor as well */
                         /* root: dlam_0 = L^-T (L^-1 res) = (L^-1)' y -- lane R + i holds column i of L^-1 (the identity rows of the
                          * factorisation), lane D holds y: D independent multiply-adds per lane, no substitution chain */
                         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -1182,7 +1352,12 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
         pstamp(C, O, e, tier, s, sl++);                                   /* backward done */
         if (verdict != 2) {
             /* what is left to prepare (the subtree root, which was factorised last; the root block of the tree needs none) */
-            for (int loc = prep_next - wave; loc >= (is_top ? 1 : 0); loc -= FW) p_prep_forward<NX, NU, MD>(L, loc, lane);
+            if (build) for (int loc = prep_next - wave; loc >= (is_top ? 1 : 0); loc -= FW) p_prep_forward<NX, NU, MD>(L, loc, lane);
+            if (RU && build && !gone && wave == 0) {
+                /* a complete build: these factor data belong to the signatures of this pass */
+                for (int i = lane; i < nbt * (1 + MD); i += WAVE) L.bsig[i] = L.csig[i];
+                if (lane == 0) *L.fvalid = 1;
+            }
             lds_barrier();
         }
 
@@ -1220,7 +1395,7 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
                 nbat += 1u;
                 const unsigned tag_b = Sy.seq | nbat;
                 for (int k = 0; k < K; k++) {
-                    const double f = p_stage_owned<NX, NU, MD>(C, Sy, L, l0, nown, s, wave, lane, step, cur, false, false, 0u, PChain{n0 + k + 1, cv[1], O.beta}, true);
+                    const double f = p_stage_owned<NX, NU, MD, RU>(C, Sy, L, l0, nown, s, wave, lane, step, cur, false, false, 0u, PChain{n0 + k + 1, cv[1], O.beta}, true);
                     if (lane == 0) L.bat[wave * 8 + k] = f;
                 }
                 __syncthreads();
@@ -1271,7 +1446,7 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
 
         /* ---- next trial (after a full pass: the first one, tau = 1; after a batch: the accepted point) on the nodes this
          * workgroup owns; then straight on to the next pass at that point: the top workgroup checks that it was accepted ---- */
-        const double fsum = p_stage_owned<NX, NU, MD>(C, Sy, L, l0, nown, s, wave, lane, step, cur, false, !is_top, Sy.seq | (nd + 1u), ch, false);
+        const double fsum = p_stage_owned<NX, NU, MD, RU>(C, Sy, L, l0, nown, s, wave, lane, step, cur, false, !is_top, Sy.seq | (nd + 1u), ch, false);
         if (lane == 0) L.part[4 * wave + 2] = fsum;
         __syncthreads();
         nd += 1u;
@@ -1291,6 +1466,9 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
             /* the verdict goes straight to the host (system-scope stores to pinned memory, then the sequence word) */
             HostRes *hr = dp->hres;
             c->n_reg = __hip_atomic_load(&cg->n_reg, RLX, AGENT);
+#ifdef TQ_REUSE_DEBUG
+            c->ls_last = c->pad0;
+#endif
             *cg = *c;                                                         /* for the next launch and for the stream-ordered readers */
             const unsigned long long *src = reinterpret_cast<const unsigned long long *>(c);
             unsigned long long *dst = reinterpret_cast<unsigned long long *>(&hr->c);
@@ -1335,13 +1513,13 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
 #ifndef TQ_WPS
 #define TQ_WPS 2
 #endif
-template <int NX, int NU, int MD>
+template <int NX, int NU, int MD, bool RU>
 __global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_persist(PConst C, Opts O, PGeom Gm, PSync Sy, int prologue) {
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     const int wg = Gm.wg_of_block[blockIdx.x];
     int tier = 0;
     for (int i = 0; i < Gm.n_tiers; i++) if (wg >= Gm.wg0[i]) tier = i;
-    p_run<NX, NU, MD>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
+    p_run<NX, NU, MD, RU>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
 }
 
 /* multistage trees (branching for Nr stages, then one child per node -- the reference's setup_multistage_tree
@@ -1349,14 +1527,14 @@ __global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_persist(PConst C, Opts O,
  * chain below is one more tier subtree with ONE block per level (instantiation MD = 1: blocks of nx rows).  A
  * chain workgroup spreads G + H and the stage sweep over its four waves; its backward / forward sweeps are one
  * wave walking down the chain, which is what a chain is. */
-template <int NX, int NU, int MD>
+template <int NX, int NU, int MD, bool RU>
 __global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_mpersist(PConst C, Opts O, PGeom Gm, PSync Sy, int prologue) {
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     const int wg = Gm.wg_of_block[blockIdx.x];
     int tier = 0;
     for (int i = 0; i < Gm.n_tiers; i++) if (wg >= Gm.wg0[i]) tier = i;
-    if (Gm.chain[tier]) p_run<NX, NU, 1>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
-    else p_run<NX, NU, MD>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
+    if (Gm.chain[tier]) p_run<NX, NU, 1, RU>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
+    else p_run<NX, NU, MD, RU>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
 }
 
 /* packed constants of the persistent path (run whenever the QP data changed): [A | B] per edge and

@@ -406,6 +406,7 @@ return_t treeqp_tdunes_solve(const tree_qp_in *qp_in, tree_qp_out *qp_out,
     dopts.lineSearchGamma = opts->lineSearchGamma;
     dopts.lineSearchBeta = opts->lineSearchBeta;
     dopts.lineSearchRestartTrigger = opts->lineSearchRestartTrigger;
+    dopts.checkLastActiveSet = opts->checkLastActiveSet;
     const char *penv = getenv("TREEQP_AMD_PROFILE");
     dopts.profile = (penv && atoi(penv) > 0) ? atoi(penv) : 0;      /* 1, 2: per-iteration times; 3: per-phase times as well (profiling.h levels) */
 
