@@ -1028,7 +1028,7 @@ __device__ __forceinline__ bool p_gather_batch(const PSync &Sy, PLds<NX, NU, MD>
 }
 
 /* the life of one workgroup = one tier subtree: tier `tier`, subtree (complete part) or scenario (chain part) `s` */
-template <int NX, int NU, int MD, bool RU>
+template <int NX, int NU, int MD, bool RU, int ROLE = 0, bool FULLTH = false>      /* ROLE: 0 found at run time; 1 bottom tier, 2 a tier in between, 3 top tier (of two or more tiers); FULLTH: the tier has Uni::TH levels */
 __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeom &Gm, const PSync &Sy_in, int prologue, int wg, int tier, int s, double *lds_all) {
     using U = Uni<NX, NU, MD>;
     PSync Sy = Sy_in;
@@ -1042,8 +1042,8 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     PLds<NX, NU, MD> L(lds_all, wave);
     Ctrl *c = reinterpret_cast<Ctrl *>((double *)L.ctl);
-    const int l0 = Gm.l0[tier], th = Gm.l1[tier] - l0;
-    const bool is_top = tier == Gm.n_tiers - 1, is_bottom = tier == 0;
+    const int l0 = Gm.l0[tier], th = FULLTH ? U::TH : Gm.l1[tier] - l0;
+    const bool is_top = ROLE == 0 ? tier == Gm.n_tiers - 1 : ROLE == 3, is_bottom = ROLE == 0 ? tier == 0 : ROLE == 1;
     const int nbt = U::first(th);                                      /* my blocks */
     const int nown = nbt + (is_bottom ? U::width(th) : 0);             /* nodes I own */
     const int root_blk = p_slot_node<NX, NU, MD>(0, l0, s, C);         /* subtree root block (= node) */
@@ -1519,6 +1519,15 @@ __global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_persist(PConst C, Opts O,
     const int wg = Gm.wg_of_block[blockIdx.x];
     int tier = 0;
     for (int i = 0; i < Gm.n_tiers; i++) if (wg >= Gm.wg0[i]) tier = i;
+    /* one instantiation of the pass loop per ROLE: each carries only its own branches and live state (the common one was at the
+     * register limit with ~210 spilled scalars; per role the C2 solve is 10 % faster).  Bottom and middle tiers of a uniform tree
+     * always have Uni::TH levels. */
+    if (!RU && Gm.n_tiers > 1) {
+        if (tier == 0) p_run<NX, NU, MD, RU, 1, true>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
+        else if (tier == Gm.n_tiers - 1) p_run<NX, NU, MD, RU, 3>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
+        else p_run<NX, NU, MD, RU, 2, true>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
+        return;
+    }
     p_run<NX, NU, MD, RU>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
 }
 
@@ -1533,6 +1542,14 @@ __global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_mpersist(PConst C, Opts O
     const int wg = Gm.wg_of_block[blockIdx.x];
     int tier = 0;
     for (int i = 0; i < Gm.n_tiers; i++) if (wg >= Gm.wg0[i]) tier = i;
+    if (!RU) {             /* per role as in f_persist; a multistage tree has two tiers or more (chains below the branching part) */
+        if (Gm.chain[tier]) {
+            if (tier == 0) p_run<NX, NU, 1, RU, 1>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
+            else p_run<NX, NU, 1, RU, 2>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
+        } else if (tier == Gm.n_tiers - 1) p_run<NX, NU, MD, RU, 3>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
+        else p_run<NX, NU, MD, RU, 2>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
+        return;
+    }
     if (Gm.chain[tier]) p_run<NX, NU, 1, RU>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
     else p_run<NX, NU, MD, RU>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
 }
