@@ -157,6 +157,10 @@ int tqgpu_solve_batch(tqgpu_solver **solvers, int n, const tqgpu_opts *opts, tqg
  * the kernel's own clock from launch start to verdict instead, so that tqgpu_solve can return as soon
  * as the verdict is in pinned host memory. */
 int tqgpu_get_device_times(tqgpu_solver *s, double *out, int n);
+/* Per-solve event pairs on (default) or off.  Off: a solve that is ONE persistent launch is enqueued with nothing around it
+ * (two queue packets fewer per solve); tqgpu_get_device_times then reports NaN for such solves.  No counterpart in the
+ * reference (its timers are host timers, treeqp/utils/timing.c:39-61). */
+int tqgpu_set_event_timing(tqgpu_solver *s, int on);
 
 /* diagnostic in-kernel time stamps of the last fused iteration (TREEQP_AMD_STAMPS=1) */
 int tqgpu_get_stamps(tqgpu_solver *s, unsigned long long *out, int cap);

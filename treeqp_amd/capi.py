@@ -518,13 +518,22 @@ class TqGpu:
             assert len(a) == self.sum_lam
         self._chk(lib().tqgpu_set_lambda(self.h, _dp(a)))
 
+    def event_timing(self, on: bool) -> None:
+        """Per-solve HIP event pairs on / off (off: device_times() gives NaN for single-launch solves)."""
+        self._chk(lib().tqgpu_set_event_timing(self.h, int(bool(on))))
+
     def solve(self, profile=0, **kw) -> dict:
-        o = GpuOpts(maxIter=100, termCondition=2, stationarityTolerance=1e-8, regType=2, regTol=1e-6, regValue=1e-6,
-                    lineSearchMaxIter=50, lineSearchGamma=0.1, lineSearchBeta=0.6, lineSearchRestartTrigger=-1, profile=profile, checkLastActiveSet=1)
-        for k, v in kw.items():
-            if not hasattr(o, k):
-                raise KeyError(k)
-            setattr(o, k, v)
+        key = (profile, tuple(sorted(kw.items())))
+        cache = self.__dict__.setdefault("_opts_cache", {})
+        o = cache.get(key)
+        if o is None:                       # the options struct of a (profile, kwargs) combination is built once
+            o = GpuOpts(maxIter=100, termCondition=2, stationarityTolerance=1e-8, regType=2, regTol=1e-6, regValue=1e-6,
+                        lineSearchMaxIter=50, lineSearchGamma=0.1, lineSearchBeta=0.6, lineSearchRestartTrigger=-1, profile=profile, checkLastActiveSet=1)
+            for k, v in kw.items():
+                if not hasattr(o, k):
+                    raise KeyError(k)
+                setattr(o, k, v)
+            cache[key] = o
         r = GpuResult()
         self._chk(lib().tqgpu_solve(self.h, C.byref(o), C.byref(r)))
         return {f: getattr(r, f) for f, _ in GpuResult._fields_}

@@ -832,6 +832,8 @@ struct tqgpu_solver {
     Ctrl *h_ctrl = nullptr;      /* = &h_res->c */
     std::vector<hipEvent_t> ring_ev0, ring_ev1;   /* events of the last solves (device times on request) */
     long solve_no = 0;
+    std::vector<char> ring_ok;                    /* the event pair of that ring slot was recorded by the solve that owns it */
+    bool ev_timing = true;                        /* record a HIP event pair around every solve (tqgpu_set_event_timing) */
     int *h_ls_log = nullptr;     /* pinned */
     int ls_log_cap = 0;
     hipStream_t stream = nullptr;
@@ -1576,7 +1578,7 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
     if (hipMalloc(&s->slab, s->slab_bytes) != hipSuccess) { delete s; return fail(TQGPU_ENOMEM, "hipMalloc failed for the device mirror"); }
     if (hipMemset(s->slab, 0, s->slab_bytes) != hipSuccess) return cleanup_fail(fail(TQGPU_ENODEVICE, "hipMemset failed"));
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) return cleanup_fail(fail(TQGPU_ENODEVICE, "hipStreamCreate failed"));
-    s->ring_ev0.assign(EV_RING, nullptr); s->ring_ev1.assign(EV_RING, nullptr);
+    s->ring_ev0.assign(EV_RING, nullptr); s->ring_ev1.assign(EV_RING, nullptr); s->ring_ok.assign(EV_RING, 0);
     for (int i = 0; i < EV_RING; i++)
         if (hipEventCreate(&s->ring_ev0[i]) != hipSuccess || hipEventCreate(&s->ring_ev1[i]) != hipSuccess) return cleanup_fail(fail(TQGPU_ENODEVICE, "hipEventCreate failed"));
     if (hipHostMalloc((void **)&s->h_res, sizeof(HostRes), hipHostMallocDefault) != hipSuccess) return cleanup_fail(fail(TQGPU_ENOMEM, "hipHostMalloc failed"));
@@ -1962,7 +1964,7 @@ struct SolveCtx {
     Opts O;
     int launches = 0, ring = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool fast = false, persist = false, first_launch = true, prelaunched = false, gpersist = false, phases = false;
+    bool fast = false, persist = false, first_launch = true, prelaunched = false, gpersist = false, phases = false, events = true;
 #ifdef TQ_HOSTPROF
     std::chrono::steady_clock::time_point hp0, hp1, hp2;
 #endif
@@ -2008,7 +2010,11 @@ int solve_begin(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, GItem *defer
     cx.ring = (int)(s->solve_no % EV_RING);
     cx.ev0 = s->ring_ev0[cx.ring]; cx.ev1 = s->ring_ev1[cx.ring];
     s->solve_no++;
-    HIP_TRY(hipEventRecord(cx.ev0, st));
+    /* the event pair costs two more packets on the queue per solve; a single persistent launch reports its own clock (launch
+     * start to verdict) anyway, so there the pair is optional */
+    cx.events = s->ev_timing || !cx.persist;
+    s->ring_ok[(size_t)cx.ring] = cx.events ? 1 : 0;
+    if (cx.events) HIP_TRY(hipEventRecord(cx.ev0, st));
     if (!cx.persist) HIP_TRY(hipMemsetAsync(D.ctrl, 0, sizeof(Ctrl), st));     /* persistent path: reset by the launch's prologue */
     if (s->need_init && !cx.gpersist) {     /* g_persist recomputes the reciprocal weights itself; dense nodes never read theirs */
         hipLaunchKernelGGL(k_init, dim3((nxu + 255) / 256), dim3(256), 0, st, s->sum_nx, s->sum_nu, D); cx.launches++;
@@ -2046,7 +2052,7 @@ int solve_begin(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, GItem *defer
         if (rcx != TQGPU_OK) return rcx;
         cx.first_launch = false; cx.prelaunched = true;
         /* the launch normally ends the solve: close the timing here */
-        HIP_TRY(hipEventRecord(cx.ev1, st));
+        if (cx.events) HIP_TRY(hipEventRecord(cx.ev1, st));
 #ifdef TQ_HOSTPROF
         cx.hp2 = HP_NOW();
 #endif
@@ -2081,7 +2087,7 @@ int solve_end(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, tqgpu_result *
                 int rcx = launch_persist(s, O, launches, cx.first_launch ? 1 : 0);
                 if (rcx != TQGPU_OK) return rcx;
                 cx.first_launch = false;
-                HIP_TRY(hipEventRecord(cx.ev1, st));
+                if (cx.events) HIP_TRY(hipEventRecord(cx.ev1, st));
             }
             cx.prelaunched = false;
         }
@@ -2131,9 +2137,10 @@ int solve_end(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, tqgpu_result *
     const int host_iter = ev_idx;
     float ms = 0.f;
     if (!tail_done) {
-        HIP_TRY(hipEventRecord(cx.ev1, st));
+        if (cx.events) HIP_TRY(hipEventRecord(cx.ev1, st));
         HIP_TRY(hipStreamSynchronize(st));
-        HIP_TRY(hipEventElapsedTime(&ms, cx.ev0, cx.ev1));
+        if (cx.events) HIP_TRY(hipEventElapsedTime(&ms, cx.ev0, cx.ev1));
+        else ms = 1e-5f * (float)(s->h_res->t_end - s->h_res->t_start);      /* several persistent launches (relaunch): the last one's own clock */
     } else {
         /* single persistent launch: the kernel's own clock, launch start to verdict (the event pair of this
          * solve can be read later through tqgpu_get_device_times, which synchronises) */
@@ -2633,9 +2640,18 @@ extern "C" int tqgpu_get_device_times(tqgpu_solver *s, double *out, int n) {
     for (long i = 0; i < have; i++) {
         const int ring = (int)((s->solve_no - have + i) % EV_RING);
         float ms = 0.f;
-        out[i] = hipEventElapsedTime(&ms, s->ring_ev0[ring], s->ring_ev1[ring]) == hipSuccess ? 1e-3 * ms : NAN;
+        out[i] = (s->ring_ok[(size_t)ring] && hipEventElapsedTime(&ms, s->ring_ev0[ring], s->ring_ev1[ring]) == hipSuccess) ? 1e-3 * ms : NAN;
     }
     return (int)have;
+}
+
+/* per-solve HIP event pairs on or off (default on).  Off: a single persistent launch is enqueued with nothing around it -- two
+ * queue packets fewer per solve -- and tqgpu_get_device_times reports NaN for such solves; tqgpu_result.device_time is the
+ * kernel's own clock (launch start to verdict) either way.  The other paths always record (their device time IS the pair). */
+extern "C" int tqgpu_set_event_timing(tqgpu_solver *s, int on) {
+    if (!s) return fail(TQGPU_EINVAL, "null solver");
+    s->ev_timing = on != 0;
+    return TQGPU_OK;
 }
 
 /* Algorithmic bytes / flops of one Newton iteration (every input read once, every output written

@@ -344,7 +344,13 @@ __device__ __forceinline__ double pivot_rsqrt3(double p) {
     const double e = fma(-(p * y0), y0, 1.0);
     const double h = fma(0.375, e, 0.5);
     const double y = fma(y0 * e, h, y0);
+#ifdef TQ_PIVOT_SELECT     /* compare + two conditional moves per pivot */
     return p > 0.0 ? y : 0.0;
+#else
+    /* p <= 0 or NaN: v_rsq_f64 gives inf / NaN, the correction turns both into NaN, and v_max_f64 returns its other operand for a
+     * NaN: one instruction instead of three on a chain that is issue-bound (tools/microbench/potrf_dpp_bench: 2803 -> 2667 cycles) */
+    return __builtin_fmax(y, 0.0);
+#endif
 }
 
 /* T[j][lane j] = K[j][lane j] + a for every j, other lanes T[j] = K[j] -- without lane masks (the masks of
@@ -1279,6 +1285,14 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
                 const int nb = U::width(t);
                 /* waves without a block on this level prepare the forward steps of the levels below (at most two each) */
                 const int idle = FW - nb, lo = U::first(t + 1);
+#ifdef TQ_TAIL_POLL      /* measured: the look costs more per pass than it saves at the end of a 3-iteration solve (C2 launch 98.8 -> 100.4 us) */
+                /* bottom tier: its backward sweep meets no poll, so after the last verdict it would finish a sweep nobody wants (the
+                 * launch ends when the last workgroup has left).  The last wave is idle on the level below the tier's bottom one: it
+                 * looks at the halt word there, and the workgroup leaves after that level's barrier. */
+                unsigned halt_seen = 0u;
+                const bool tail_look = is_bottom && th >= 2 && t == th - 2 && wave == FW - 1 && nb < FW;
+                if (tail_look) halt_seen = __hip_atomic_load(Sy.halt, RLX, AGENT);
+#endif
                 if (wave >= nb && build) {
                     for (int r = 0; r < 2; r++) {
                         const int loc = prep_next - (r * idle + (wave - nb));
@@ -1343,8 +1357,14 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
                         lds_fence();
                     }
                 }
+#ifdef TQ_TAIL_POLL
+                if (tail_look && halt_seen == Sy.seq && lane == 0) *L.abort = 1;
+#endif
                 lds_barrier();
                 if (t == th - 1 && !is_bottom && *L.abort) { gone = true; break; }    /* a child never delivered: the launch is over, or the pass is dropped */
+#ifdef TQ_TAIL_POLL
+                if (is_bottom && th >= 2 && t == th - 2 && *L.abort) { gone = true; break; }     /* the launch is over (see tail_look) */
+#endif
                 pstamp(C, O, e, tier, s, sl++);                           /* 3.. : one per backward level */
             }
         }
@@ -1524,7 +1544,13 @@ __global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_persist(PConst C, Opts O,
      * always have Uni::TH levels. */
     if (!RU && Gm.n_tiers > 1) {
         if (tier == 0) p_run<NX, NU, MD, RU, 1, true>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
-        else if (tier == Gm.n_tiers - 1) p_run<NX, NU, MD, RU, 3>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
+        else if (tier == Gm.n_tiers - 1) {
+#ifdef TQ_TOP_FULLTH
+            if (Gm.l1[tier] - Gm.l0[tier] == Uni<NX, NU, MD>::TH) p_run<NX, NU, MD, RU, 3, true>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
+            else
+#endif
+            p_run<NX, NU, MD, RU, 3>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
+        }
         else p_run<NX, NU, MD, RU, 2, true>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
         return;
     }
