@@ -35,4 +35,4 @@ for rnd in range(2):
             continue
         d = json.loads(line[-1])
         print(f"{label:28s} {workload} {d['value']:9.0f} it/s  step {1e3 * d['ms_per_step']:7.1f} us  launch {d['roofline']['launch_us']:7.1f} us  "
-              f"iters {d['config']['newton_iter_per_solve']:.0f} kkt {d['config']['max_kkt_residual']:.1e}", flush=True)
+              f"iters {d['config']['newton_iter_per_solve']:.0f} kkt {d['config']['max_kkt_residual'] if d['config']['max_kkt_residual'] is not None else float('nan'):.1e}", flush=True)

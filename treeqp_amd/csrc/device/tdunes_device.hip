@@ -801,6 +801,9 @@ struct tqgpu_solver {
     size_t lds_stage = 0, lds_hess = 0, lds_factor = 0, lds_forward = 0, lds_dense = 0;
     bool wide = false;              /* larger blocks (16 < d <= 64): workgroup-per-block MFMA kernels (tdunes_wide.hpp) */
     size_t lds_hess_w = 0, lds_factor_w = 0, lds_forward_w = 0;
+    unsigned long long *fw_words = nullptr;   /* wide path: the steps of a forward sweep as tagged words (k_forward_all_w), [sum_nx][2] */
+    unsigned fw_epoch = 0;              /* tag of the last fused forward launch */
+    bool fw_fused = true;               /* TREEQP_AMD_WIDE_FWD=levels: one launch per level instead */
     bool dense = false, need_dense_init = false;   /* dense unconstrained stage solver selected (generic path only) */
     double *d_Hd = nullptr;      /* writable alias of Data.Hd */
     int *d_kind = nullptr;       /* writable alias of Data.kind */
@@ -1473,6 +1476,13 @@ void launch_generic_iteration(tqgpu_solver *s, const Opts &O, int h, int &launch
         else hipLaunchKernelGGL(k_factor, dim3(count), dim3(WAVE), s->lds_factor, st, T, D, O, first, h);
         launches++;
     }
+    if (wide && s->fw_words && s->fw_fused && T.Np > 1) {
+        /* all levels below the root in one launch: a block waits for its parent's step inside the kernel */
+        s->fw_epoch++;
+        if (s->fw_epoch == 0) s->fw_epoch = 1;
+        hipLaunchKernelGGL(k_forward_all_w, dim3(T.Np - 1), dim3(WT), s->lds_forward_w, st, T, D, s->fw_words, s->fw_epoch, h);
+        launches++;
+    } else
     for (int lvl = 1; lvl < T.Nh; lvl++) {
         const int first = s->lvl_first[lvl], count = s->lvl_first[lvl + 1] - first;
         if (wide) hipLaunchKernelGGL(k_forward_w, dim3(count), dim3(WT), s->lds_forward_w, st, T, D, first, h);
@@ -1649,11 +1659,19 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
     if ((rc = allow_lds(k_stage, s->lds_stage)) || (rc = allow_lds(k_hess, s->lds_hess)) ||
         (rc = allow_lds(k_factor, s->lds_factor)) || (rc = allow_lds(k_forward, s->lds_forward)))
         return cleanup_fail(rc);
-    if (s->wide && ((rc = allow_lds(k_hess_w, s->lds_hess_w)) || (rc = allow_lds(k_factor_w, s->lds_factor_w)) || (rc = allow_lds(k_forward_w, s->lds_forward_w))))
+    if (s->wide && ((rc = allow_lds(k_hess_w, s->lds_hess_w)) || (rc = allow_lds(k_factor_w, s->lds_factor_w)) || (rc = allow_lds(k_forward_w, s->lds_forward_w)) || (rc = allow_lds(k_forward_all_w, s->lds_forward_w))))
         return cleanup_fail(rc);
     if (s->fast >= 0) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) != hipSuccess || prop.maxThreadsPerBlock < FW * WAVE) s->fast = -1;
+    }
+    if (s->wide) {
+        /* hand-over words of the fused forward sweep (zeroed once; every launch brings its own tag) */
+        const size_t bytes = sizeof(unsigned long long) * 2 * (size_t)std::max(s->sum_nx, 1);
+        if (hipMalloc(&s->fw_words, bytes) != hipSuccess || hipMemset(s->fw_words, 0, bytes) != hipSuccess)
+            return cleanup_fail(fail(TQGPU_ENOMEM, "hipMalloc failed for the forward hand-over words"));
+        const char *m = getenv("TREEQP_AMD_WIDE_FWD");
+        s->fw_fused = !(m && strcmp(m, "levels") == 0);
     }
     if ((rc = setup_persist(s, device))) return cleanup_fail(rc);
     {
@@ -1715,6 +1733,7 @@ extern "C" void tqgpu_destroy(tqgpu_solver *s) {
     if (s->pconst_slab) (void)hipFree(s->pconst_slab);
     if (s->wg_map) (void)hipFree(s->wg_map);
     if (s->d_desc) (void)hipFree(s->d_desc);
+    if (s->fw_words) (void)hipFree(s->fw_words);
     if (s->d_gitems) (void)hipFree(s->d_gitems);
     if (s->h_gitems) (void)hipHostFree(s->h_gitems);
     if (s->batch_ev) (void)hipEventDestroy(s->batch_ev);

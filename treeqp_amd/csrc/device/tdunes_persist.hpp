@@ -1285,14 +1285,6 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
                 const int nb = U::width(t);
                 /* waves without a block on this level prepare the forward steps of the levels below (at most two each) */
                 const int idle = FW - nb, lo = U::first(t + 1);
-#ifdef TQ_TAIL_POLL      /* measured: the look costs more per pass than it saves at the end of a 3-iteration solve (C2 launch 98.8 -> 100.4 us) */
-                /* bottom tier: its backward sweep meets no poll, so after the last verdict it would finish a sweep nobody wants (the
-                 * launch ends when the last workgroup has left).  The last wave is idle on the level below the tier's bottom one: it
-                 * looks at the halt word there, and the workgroup leaves after that level's barrier. */
-                unsigned halt_seen = 0u;
-                const bool tail_look = is_bottom && th >= 2 && t == th - 2 && wave == FW - 1 && nb < FW;
-                if (tail_look) halt_seen = __hip_atomic_load(Sy.halt, RLX, AGENT);
-#endif
                 if (wave >= nb && build) {
                     for (int r = 0; r < 2; r++) {
                         const int loc = prep_next - (r * idle + (wave - nb));
@@ -1357,14 +1349,8 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
                         lds_fence();
                     }
                 }
-#ifdef TQ_TAIL_POLL
-                if (tail_look && halt_seen == Sy.seq && lane == 0) *L.abort = 1;
-#endif
                 lds_barrier();
                 if (t == th - 1 && !is_bottom && *L.abort) { gone = true; break; }    /* a child never delivered: the launch is over, or the pass is dropped */
-#ifdef TQ_TAIL_POLL
-                if (is_bottom && th >= 2 && t == th - 2 && *L.abort) { gone = true; break; }     /* the launch is over (see tail_look) */
-#endif
                 pstamp(C, O, e, tier, s, sl++);                           /* 3.. : one per backward level */
             }
         }

@@ -43,15 +43,16 @@ __device__ __forceinline__ int wide_ld(int rows_padded) { return rows_padded | 1
 /* z <- L^-T z for one wave, entry j of z on lane j (d <= 64): the strictly-lower part of column `lane` of L is
  * fetched into registers in one go, then every step is two readlanes and one FMA -- no memory in the chain.
  * L column major in LDS with leading dimension ld; myinv = 1 / L[lane][lane].  Returns the solution entry. */
-__device__ __forceinline__ double wide_backsolve(const double *L, int ld, int d, int lane, double z, double myinv) {
+__device__ __forceinline__ void wide_backsolve_load(const double *L, int ld, int d, int lane, double (&Lc)[64]) {
     const int lc = lane < d ? lane : 0;
-    double Lc[64];
 #pragma unroll
     for (int k = 1; k < 64; k++) {
         const bool use = k < d && k > lane;
         const double v = L[(use ? k : 0) + (size_t)lc * ld];
         Lc[k] = use ? -v : 0.0;
     }
+}
+__device__ __forceinline__ double wide_backsolve_chain(const double (&Lc)[64], int d, double z, double myinv) {
 #pragma unroll
     for (int k = 63; k >= 1; k--) {
         if (k < d) {
@@ -60,6 +61,11 @@ __device__ __forceinline__ double wide_backsolve(const double *L, int ld, int d,
         }
     }
     return z * myinv;
+}
+__device__ __forceinline__ double wide_backsolve(const double *L, int ld, int d, int lane, double z, double myinv) {
+    double Lc[64];
+    wide_backsolve_load(L, ld, d, lane, Lc);
+    return wide_backsolve_chain(Lc, d, z, myinv);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -381,6 +387,90 @@ __global__ void __launch_bounds__(WT) k_forward_w(Tree T, Data D, int first, int
     const double mine = wide_backsolve(L, ld, d, lane, rhs, myinv);
     double pd = 0.0;
     if (lane < d) { D.dlam[bo + lane] = mine; pd = rv * mine; }
+    pd = wave_sum(pd);
+    if (lane == 0) D.part_dot[ii] = pd;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* the forward sweep of ALL levels as one launch                                               */
+/* ------------------------------------------------------------------------------------------ */
+/* One launch per level is a kernel boundary (~3 us) plus a batch of cold loads (~2.4 us) per level for ~1 us of dependent
+ * work.  Here every block below the root has its workgroup in ONE launch: it requests everything that does not depend on
+ * its parent (factor, CholUt, backward solution, residual), then waits for the parent's step, which travels as tagged words
+ * (st_tag / ld_tag of the persistent path: the consumer polls the payload itself until every word carries this launch's tag;
+ * relaxed agent-scope accesses, so nothing depends on one XCD's L2 seeing another's).  Workgroups are numbered in BFS order
+ * and the hardware starts them in order, so a waiting workgroup's parent is always running or done: no deadlock whatever
+ * part of the grid is resident.  Children of the root read the root's step from D.dlam (k_factor_w wrote it in an earlier
+ * launch).  A wait that never ends (it cannot) gives up after 0.5 s and ends the solve with UNKNOWN_ERROR. */
+__global__ void __launch_bounds__(WT) k_forward_all_w(Tree T, Data D, u64 *fw, unsigned tag, int h) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int ii = 1 + blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int e[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) e[i] = T.desc[(size_t)DESC_INTS * ii + i];
+    if (!phase_main(D.ctrl, h)) return;
+    const int d = e[0], nxi = e[1], ld = d | 1, dad = e[10];
+    double *L = lds;
+    double *zz = lds + (size_t)ld * d;
+    const int bo = e[7], xo = e[5];
+    const double *Lg = D.CholW + e[8];
+    const int lc = lane < d ? lane : 0;
+    double v[16], cu[16], dl[16];
+#pragma unroll
+    for (int m = 0; m < 16; m++) { const int j = wave + WW * m; const bool ok = lane < d && j < d && lane >= j; v[m] = Lg[ok ? lane + (size_t)j * d : 0]; }
+    const double *CUt = D.CholUt + e[9] + (size_t)lc * nxi;
+#pragma unroll
+    for (int m = 0; m < 16; m++) { const int i = wave + WW * m; cu[m] = CUt[i < nxi ? i : 0]; }
+    const double myinv = D.invd[bo + lc], yv = D.dlam[bo + lc], rv = D.res[bo + lc];
+    LOADS_DONE();
+#pragma unroll
+    for (int m = 0; m < 16; m++) { const int j = wave + WW * m; if (lane < d && j < d && lane >= j) L[lane + (size_t)j * ld] = v[m]; }
+    __syncthreads();
+    double Lc[64];                                        /* wave 0: its column of the factor, in registers before the wait */
+    if (wave == 0) wide_backsolve_load(L, ld, d, lane, Lc);
+    /* the parent's step: entries xo .. xo + nxi - 1 of the step vector (this wave's share: i = wave + 4 m) */
+    if (dad == 0) {
+#pragma unroll
+        for (int m = 0; m < 16; m++) { const int i = wave + WW * m; dl[m] = D.dlam[xo + (i < nxi ? i : 0)]; }
+    } else {
+        /* lane m (mod 16) fetches entry i = wave + 4 m: ONE tagged double per lane and round (a workgroup's poll is 2 x nxi words,
+         * not 32 per thread: hundreds of workgroups poll at once while the levels above them are still at work) */
+        const int i = wave + WW * (lane & 15);
+        const bool need = i < nxi;
+        const u64 *src = fw + (size_t)(xo + (need ? i : wave)) * 2;
+        double val = 0.0;
+        const u64 t0 = wall_clock64();
+        for (;;) {
+            bool ok = true;
+            val = ld_tag(src, tag, ok);
+            if (__all(ok || !need)) break;
+            if (wall_clock64() - t0 > 50000000ull) {                      /* 0.5 s at 100 MHz */
+                if (tid == 0) { D.ctrl->status = 3; __hip_atomic_store(&D.ctrl->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+#pragma unroll
+        for (int m = 0; m < 16; m++) dl[m] = rdlane(val, m);
+    }
+    {
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int m = 0; m < 16; m += 2) {
+            a0 = fma(wave + WW * m < nxi ? cu[m] : 0.0, dl[m], a0);
+            a1 = fma(wave + WW * (m + 1) < nxi ? cu[m + 1] : 0.0, dl[m + 1], a1);
+        }
+        zz[wave * 64 + lane] = a0 + a1;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    const double rhs = lane < d ? fma(-1.0, (zz[lane] + zz[64 + lane]) + (zz[128 + lane] + zz[192 + lane]), yv) : 0.0;
+    const double mine = wide_backsolve_chain(Lc, d, rhs, myinv);
+    double pd = 0.0;
+    if (lane < d) {
+        st_tag(fw + (size_t)(bo + lane) * 2, mine, tag);                  /* first: my children wait for it */
+        D.dlam[bo + lane] = mine; pd = rv * mine;
+    }
     pd = wave_sum(pd);
     if (lane == 0) D.part_dot[ii] = pd;
 }
