@@ -233,12 +233,32 @@ __global__ void __launch_bounds__(WAVE) k_dense_init(Tree T, Data D) {
     }
 }
 
+/* acc + sum_{i < n} a[i * sa] * b[i * sb], terms added in ascending order (the reference's order), but the loads go out EIGHT
+ * AT A TIME: a runtime-bounded `for (i) acc = fma(a[i], b[i], acc)` makes one memory round trip per trip of the loop (the
+ * compiler does not move loads across the back edge), which is what the node sweeps of wider nodes spent their time on
+ * (k_stage / k_grad at nx = 20, nu = 10: 15.6 / 13.3 us per launch).  Clamped addresses, masked use: nothing diverges. */
+__device__ __forceinline__ double dot_batched(const double *a, int sa, const double *b, int sb, int n, double acc, bool batch) {
+    if (!batch) {                                            /* operands in LDS (g_persist with its state mirrored): the plain loop is the shorter program */
+        for (int i = 0; i < n; i++) acc = fma(a[(size_t)i * sa], b[(size_t)i * sb], acc);
+        return acc;
+    }
+    for (int i0 = 0; i0 < n; i0 += 8) {
+        double va[8], vb[8];
+#pragma unroll
+        for (int m = 0; m < 8; m++) { const int i = i0 + m < n ? i0 + m : 0; va[m] = a[(size_t)i * sa]; vb[m] = b[(size_t)i * sb]; }
+        asm volatile("" ::: "memory");                       /* the batch stays a batch (see LOADS_DONE in tdunes_wide.hpp) */
+#pragma unroll
+        for (int m = 0; m < 8; m++) { const double t = fma(va[m], vb[m], acc); acc = i0 + m < n ? t : acc; }
+    }
+    return acc;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* k_stage: one wave per node.  mode 0: evaluate at lam[cur] (first sweep of a solve);         */
 /* mode 1: line-search trial, lam_next = lam_cur + (tau - tauPrev) * dlam, evaluate there.     */
 /* Produces qmod,rmod,x,u,xUnc,uUnc,QinvCal,RinvCal and the node's dual-function term.         */
 /* ------------------------------------------------------------------------------------------ */
-__device__ void stage_body(const Tree &T, const Data &D, int mode, int k, int lane, double *lds) {
+__device__ void stage_body(const Tree &T, const Data &D, int mode, int k, int lane, double *lds, bool batch = true) {
     const Ctrl *c = D.ctrl;
     const int nxk = T.nx[k], nuk = T.nu[k], xo = T.xoff[k], uo = T.uoff[k];
     const int nkid = T.nk[k], d = T.bdim[k];
@@ -279,7 +299,7 @@ __device__ void stage_body(const Tree &T, const Data &D, int mode, int k, int la
                 const int kid = T.kid0[k] + cc, nxc = T.nx[kid];
                 const double *col = isx ? D.A + T.aoff[kid] + (size_t)j * nxc : D.B + T.boff[kid] + (size_t)j * nxc;
                 double acc = 0.0;
-                for (int i = 0; i < nxc; i++) acc = fma(col[i], lk[rowoff + i], acc);
+                acc = dot_batched(col, 1, lk + rowoff, 1, nxc, acc, batch);
                 v = fma(-1.0, acc, v);
                 rowoff += nxc;
             }
@@ -319,7 +339,7 @@ __device__ void stage_body(const Tree &T, const Data &D, int mode, int k, int la
             const int kid = T.kid0[k] + cc, nxc = T.nx[kid];
             const double *col = isx ? D.A + T.aoff[kid] + (size_t)j * nxc : D.B + T.boff[kid] + (size_t)j * nxc;
             double acc = 0.0;
-            for (int i = 0; i < nxc; i++) acc = fma(col[i], lk[rowoff + i], acc);
+            acc = dot_batched(col, 1, lk + rowoff, 1, nxc, acc, batch);
             v = fma(-1.0, acc, v);
             rowoff += nxc;
         }
@@ -371,7 +391,14 @@ template <bool IS_MAX>
 __device__ double block_reduce(const double *v, int n, double *sh) {
     /* strided per-thread partials, wave shuffle tree, then the (<= 16) wave results in order */
     double acc = 0.0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) acc = IS_MAX ? nanmax(acc, v[i]) : acc + v[i];
+    for (int i0 = threadIdx.x; i0 < n; i0 += 8 * blockDim.x) {          /* eight loads in flight per thread, same order of the sums */
+        double t[8];
+#pragma unroll
+        for (int m = 0; m < 8; m++) { const int i = i0 + m * (int)blockDim.x; t[m] = v[i < n ? i : 0]; }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int m = 0; m < 8; m++) { const int i = i0 + m * (int)blockDim.x; if (i < n) acc = IS_MAX ? nanmax(acc, t[m]) : acc + t[m]; }
+    }
     acc = IS_MAX ? wave_max(acc) : wave_sum(acc);
     __syncthreads();                                   /* sh may still be read from a previous call */
     if ((threadIdx.x & (WAVE - 1)) == 0) sh[threadIdx.x >> 6] = acc;
@@ -392,7 +419,7 @@ __global__ void __launch_bounds__(256) k_fval_init(Tree T, Data D) {
 /* ------------------------------------------------------------------------------------------ */
 /* k_grad: one wave per node k >= 1:  res_k = b_k - x_k + A_k x_dad + B_k u_dad                */
 /* ------------------------------------------------------------------------------------------ */
-__device__ void grad_body(const Tree &T, const Data &D, int termCondition, int k, int lane) {
+__device__ void grad_body(const Tree &T, const Data &D, int termCondition, int k, int lane, bool batch = true) {
     const int p = T.dad[k], nxk = T.nx[k], nxp = T.nx[p], nup = T.nu[p];
     const int xo = T.xoff[k], xp = T.xoff[p], up = T.uoff[p];
     const double *A = D.A + T.aoff[k], *B = D.B + T.boff[k];
@@ -400,10 +427,10 @@ __device__ void grad_body(const Tree &T, const Data &D, int termCondition, int k
     for (int i = lane; i < nxk; i += WAVE) {
         double rv = fma(-1.0, D.x[xo + i], D.b[xo + i]);
         double acc = 0.0;
-        for (int j = 0; j < nxp; j++) acc = fma(A[i + (size_t)j * nxk], D.x[xp + j], acc);
+        acc = dot_batched(A + i, nxk, D.x + xp, 1, nxp, acc, batch);
         rv += acc;
         acc = 0.0;
-        for (int j = 0; j < nup; j++) acc = fma(B[i + (size_t)j * nxk], D.u[up + j], acc);
+        acc = dot_batched(B + i, nxk, D.u + up, 1, nup, acc, batch);
         rv += acc;
         D.res[xo + i] = rv;
         D.resMod[xo + i] = rv;
@@ -804,6 +831,10 @@ struct tqgpu_solver {
     unsigned long long *fw_words = nullptr;   /* wide path: the steps of a forward sweep as tagged words (k_forward_all_w), [sum_nx][2] */
     unsigned fw_epoch = 0;              /* tag of the last fused forward launch */
     bool fw_fused = true;               /* TREEQP_AMD_WIDE_FWD=levels: one launch per level instead */
+    unsigned long long *sch_words = nullptr;  /* wide path: Schur records of a fused backward sweep as tagged words (k_factor_all_w), [Nn][sch_rs][2] */
+    int sch_rs = 0;                     /* doubles per record: (max nx + 1)^2 */
+    unsigned bw_epoch = 0;
+    bool bw_fused = true;               /* TREEQP_AMD_WIDE_BWD=levels: one launch per level instead */
     bool dense = false, need_dense_init = false;   /* dense unconstrained stage solver selected (generic path only) */
     double *d_Hd = nullptr;      /* writable alias of Data.Hd */
     int *d_kind = nullptr;       /* writable alias of Data.kind */
@@ -1470,6 +1501,13 @@ void launch_generic_iteration(tqgpu_solver *s, const Opts &O, int h, int &launch
     else hipLaunchKernelGGL(k_hess, dim3(T.Np), dim3(WAVE), s->lds_hess, st, T, D, h);
     launches++;
     mark(1);
+    if (wide && s->sch_words && s->bw_fused && !phases) {
+        /* all levels in one launch, last block first: a block waits for its children's Schur records inside the kernel */
+        s->bw_epoch++;
+        if (s->bw_epoch == 0) s->bw_epoch = 1;
+        hipLaunchKernelGGL(k_factor_all_w, dim3(T.Np), dim3(WT), s->lds_factor_w, st, T, D, O, s->sch_words, s->sch_rs, s->bw_epoch, h);
+        launches++;
+    } else
     for (int lvl = T.Nh - 1; lvl >= 0; lvl--) {
         const int first = s->lvl_first[lvl], count = s->lvl_first[lvl + 1] - first;
         if (wide) hipLaunchKernelGGL(k_factor_w, dim3(count), dim3(WT), s->lds_factor_w, st, T, D, O, first, h);
@@ -1659,7 +1697,7 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
     if ((rc = allow_lds(k_stage, s->lds_stage)) || (rc = allow_lds(k_hess, s->lds_hess)) ||
         (rc = allow_lds(k_factor, s->lds_factor)) || (rc = allow_lds(k_forward, s->lds_forward)))
         return cleanup_fail(rc);
-    if (s->wide && ((rc = allow_lds(k_hess_w, s->lds_hess_w)) || (rc = allow_lds(k_factor_w, s->lds_factor_w)) || (rc = allow_lds(k_forward_w, s->lds_forward_w)) || (rc = allow_lds(k_forward_all_w, s->lds_forward_w))))
+    if (s->wide && ((rc = allow_lds(k_hess_w, s->lds_hess_w)) || (rc = allow_lds(k_factor_w, s->lds_factor_w)) || (rc = allow_lds(k_forward_w, s->lds_forward_w)) || (rc = allow_lds(k_forward_all_w, s->lds_forward_w)) || (rc = allow_lds(k_factor_all_w, s->lds_factor_w))))
         return cleanup_fail(rc);
     if (s->fast >= 0) {
         hipDeviceProp_t prop;
@@ -1672,6 +1710,14 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
             return cleanup_fail(fail(TQGPU_ENOMEM, "hipMalloc failed for the forward hand-over words"));
         const char *m = getenv("TREEQP_AMD_WIDE_FWD");
         s->fw_fused = !(m && strcmp(m, "levels") == 0);
+        int nxmax = 0;
+        for (int k = 0; k < s->Nn; k++) nxmax = std::max(nxmax, s->nx[k]);
+        s->sch_rs = (nxmax + 1) * (nxmax + 1);
+        const size_t sbytes = sizeof(unsigned long long) * 2 * (size_t)s->sch_rs * (size_t)s->Nn;
+        if (hipMalloc(&s->sch_words, sbytes) != hipSuccess || hipMemset(s->sch_words, 0, sbytes) != hipSuccess)
+            return cleanup_fail(fail(TQGPU_ENOMEM, "hipMalloc failed for the Schur hand-over words"));
+        m = getenv("TREEQP_AMD_WIDE_BWD");
+        s->bw_fused = !(m && strcmp(m, "levels") == 0);
     }
     if ((rc = setup_persist(s, device))) return cleanup_fail(rc);
     {
@@ -1734,6 +1780,7 @@ extern "C" void tqgpu_destroy(tqgpu_solver *s) {
     if (s->wg_map) (void)hipFree(s->wg_map);
     if (s->d_desc) (void)hipFree(s->d_desc);
     if (s->fw_words) (void)hipFree(s->fw_words);
+    if (s->sch_words) (void)hipFree(s->sch_words);
     if (s->d_gitems) (void)hipFree(s->d_gitems);
     if (s->h_gitems) (void)hipHostFree(s->h_gitems);
     if (s->batch_ev) (void)hipEventDestroy(s->batch_ev);

@@ -106,7 +106,7 @@ __device__ __forceinline__ void g_persist_body(Tree T_in, Data D_in, Opts O, GPa
     __syncthreads();
 
     /* first sweep at lambda0 (phase S of iteration 0) and fval0 */
-    for (int k = wave; k < Nn; k += GP_WAVES) stage_body(sT, sD, 0, k, lane, lds);
+    for (int k = wave; k < Nn; k += GP_WAVES) stage_body(sT, sD, 0, k, lane, lds, !G.const_in_lds);
     __syncthreads();
     {
         const double f = block_reduce<false>(sD.fval, Nn, sh);
@@ -117,7 +117,7 @@ __device__ __forceinline__ void g_persist_body(Tree T_in, Data D_in, Opts O, GPa
 
     for (;;) {
         /* ---- G: dual gradient + termination test (dual_Newton_tree.c:519-543) ---- */
-        for (int k = 1 + wave; k < Nn; k += GP_WAVES) grad_body(sT, sD, O.termCondition, k, lane);
+        for (int k = 1 + wave; k < Nn; k += GP_WAVES) grad_body(sT, sD, O.termCondition, k, lane, !G.const_in_lds);
         __syncthreads();
         {
             double err = (O.termCondition == 2) ? block_reduce<true>(sD.part_err + 1, Nn - 1, sh) : block_reduce<false>(sD.part_err + 1, Nn - 1, sh);
@@ -166,7 +166,7 @@ __device__ __forceinline__ void g_persist_body(Tree T_in, Data D_in, Opts O, GPa
         __syncthreads();
         if (flag) break;
         for (;;) {
-            for (int k = wave; k < Nn; k += GP_WAVES) stage_body(sT, sD, 1, k, lane, lds);
+            for (int k = wave; k < Nn; k += GP_WAVES) stage_body(sT, sD, 1, k, lane, lds, !G.const_in_lds);
             __syncthreads();
             const double f = block_reduce<false>(sD.fval, Nn, sh);
             if (threadIdx.x == 0) { ls_decide_tail(c, sD, O, f); flag = c->ls_pending; }

@@ -39,6 +39,17 @@
 
 __device__ __forceinline__ int up16(int v) { return (v + 15) & ~15; }
 __device__ __forceinline__ int wide_ld(int rows_padded) { return rows_padded | 16; }
+/* leading dimension of the tall matrix in k_factor_w: == 16 (mod 32) where that costs nothing, == 8 (mod 32) otherwise (the four
+ * k-groups of an operand fetch then still spread over all banks, two groups per bank like with 16; and 81 x 60 -- C4 -- takes
+ * 52 KB instead of 56: three workgroups per CU, i.e. the 729 blocks of C4's last level resident at once) */
+#ifdef TQ_WIDE_LD16
+__host__ __device__ __forceinline__ int wide_ldf(int rows_padded) { return rows_padded | 16; }
+#else
+#ifndef TQ_WIDE_PAD
+#define TQ_WIDE_PAD 8
+#endif
+__host__ __device__ __forceinline__ int wide_ldf(int rows_padded) { return (rows_padded & 16) ? rows_padded : rows_padded + TQ_WIDE_PAD; }
+#endif
 
 /* z <- L^-T z for one wave, entry j of z on lane j (d <= 64): the strictly-lower part of column `lane` of L is
  * fetched into registers in one go, then every step is two readlanes and one FMA -- no memory in the chain.
@@ -155,19 +166,28 @@ __global__ void __launch_bounds__(WT) k_hess_w(Tree T, Data D, int h) {
 /* ------------------------------------------------------------------------------------------ */
 /* F: tall Cholesky of [W ; resMod' ; Ut], Schur complement into the parent, root solve        */
 /* ------------------------------------------------------------------------------------------ */
-__global__ void __launch_bounds__(WT) k_factor_w(Tree T, Data D, Opts O, int first, int h) {
+/* FUSED: all levels of the backward sweep in ONE launch (k_factor_all_w).  A block's Schur complement then does not go into
+ * the parent's W / resMod in global memory (read-modify-write, visible to the parent only across a kernel boundary) but
+ * travels as a record of tagged words (st_tag / ld_tag of the persistent path): entry (gi, gj), 1 <= gi <= nx, 0 <= gj <= gi, of
+ * G = Xt Xt' at gi * (nx + 1) + gj of the block's record (rs doubles per node).  The parent loads its block -- which does not
+ * depend on its children -- and subtracts the records in LDS as they arrive.  Workgroups are numbered from the LAST block to
+ * the root and the hardware starts them in that order, so the children a workgroup waits for are running or done whatever
+ * part of the grid is resident. */
+template <bool FUSED>
+__device__ __forceinline__ void factor_w_body(const Tree &T, const Data &D, const Opts &O, int ii, int first, int h, u64 *sch, int rs, unsigned tag) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ int small_flag;
-    const int ii = first + blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    int e[14];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    constexpr int NE = FUSED ? 28 : 14;
+    int e[NE];
 #pragma unroll
-    for (int i = 0; i < 14; i++) e[i] = T.desc[(size_t)DESC_INTS * ii + i];      /* node record: requested together with the control block */
+    for (int i = 0; i < NE; i++) e[i] = T.desc[(size_t)DESC_INTS * ii + i];      /* node record: requested together with the control block */
     if (!phase_main(D.ctrl, h)) return;
     Ctrl *c = D.ctrl;
     const int d = e[0], nxi = ii > 0 ? e[1] : 0;
     /* rows in LDS: 0..d-1 the block, d..dp-1 identity padding (so that the padding columns stay inert), dp the right-hand
      * side, dp+1.. the Ut rows */
-    const int dp = up16(d), R = dp + 1 + nxi, Rp = up16(R), ld = wide_ld(Rp);
+    const int dp = up16(d), R = dp + 1 + nxi, Rp = up16(R), ld = wide_ldf(Rp);
     double *Tm = lds;                           /* ld x dp, column major */
     const double *W = D.W + e[8];
     const int bo = e[7];
@@ -209,6 +229,40 @@ __global__ void __launch_bounds__(WT) k_factor_w(Tree T, Data D, Opts O, int fir
             }
         }
         __syncthreads();
+        if (FUSED) {
+            /* children that own a block (kid < Np) have posted G = Xt Xt' of their tall factor: subtract G[gi][gj], gj >= 1, from the
+             * diagonal sub-block of W at the child's position, G[gi][0] from the right-hand side row.  Every thread polls its own
+             * entries (at most ceil((nx + 1)^2 / 256) per child); distinct entries, distinct LDS words. */
+            const int nkp = e[3], k0 = e[4];
+            int posc = 0;
+            bool dead = false;
+            for (int cc = 0; cc < nkp; cc++) {
+                const int kid = k0 + cc;
+                const int nxc = cc == 0 ? e[16] : cc == 1 ? e[19] : cc == 2 ? e[22] : cc == 3 ? e[25] : T.nx[kid];
+                if (kid < T.Np) {
+                    const int w = nxc + 1;
+                    const u64 *rec = sch + (size_t)kid * rs * 2;
+                    for (int f = tid; f < w * w; f += WT) {
+                        const int gi = f / w, gj = f - gi * w;
+                        if (gi < 1 || gj > gi) continue;
+                        double val = 0.0;
+                        const u64 t0 = wall_clock64();
+                        for (;;) {
+                            bool ok = true;
+                            val = ld_tag(rec + (size_t)f * 2, tag, ok);
+                            if (ok || dead) break;
+                            if (wall_clock64() - t0 > 50000000ull) { dead = true; val = 0.0; break; }      /* 0.5 s at 100 MHz: cannot happen (see above) */
+                            __builtin_amdgcn_s_sleep(4);
+                        }
+                        double *dst = gj == 0 ? Tm + dp + (size_t)(posc + gi - 1) * ld : Tm + (posc + gi - 1) + (size_t)(posc + gj - 1) * ld;
+                        *dst -= val;
+                    }
+                }
+                posc += nxc;
+            }
+            if (dead) { D.ctrl->status = 3; __hip_atomic_store(&D.ctrl->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            __syncthreads();
+        }
         WSTAMP(1);
         for (int kb = 0; kb < dp; kb += 16) {
             /* ---- panel kb: rows kb.. , columns kb..kb+15, one row per lane, in registers ---- */
@@ -269,17 +323,19 @@ __global__ void __launch_bounds__(WT) k_factor_w(Tree T, Data D, Opts O, int fir
      * lower tiles: 4 per wave).  (Requested at kernel start they cost 32 registers across the factorisation and
      * one workgroup per CU less.) */
     double pre[4][4];
+    if (!FUSED) {
 #pragma unroll
-    for (int mt = 0; mt < 4; mt++) {
-        int J = 0, rem = wave + WW * mt;
-        while (J < nt2 && rem >= nt2 - J) { rem -= nt2 - J; J++; }      /* tile number -> (I, J), lower tiles column by column */
-        const int gi = 16 * (J + rem) + r16;
+        for (int mt = 0; mt < 4; mt++) {
+            int J = 0, rem = wave + WW * mt;
+            while (J < nt2 && rem >= nt2 - J) { rem -= nt2 - J; J++; }      /* tile number -> (I, J), lower tiles column by column */
+            const int gi = 16 * (J + rem) + r16;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int gj = 16 * J + g + 4 * q;
-            const bool ok = J < nt2 && gi >= 1 && gi <= nxi && gj <= gi;
-            const double *src = !ok ? D.resMod + xo : (gj == 0 ? D.resMod + xo + gi - 1 : Wd + (pos + gi - 1) + (size_t)(pos + gj - 1) * ddim);
-            pre[mt][q] = *src;
+            for (int q = 0; q < 4; q++) {
+                const int gj = 16 * J + g + 4 * q;
+                const bool ok = J < nt2 && gi >= 1 && gi <= nxi && gj <= gi;
+                const double *src = !ok ? D.resMod + xo : (gj == 0 ? D.resMod + xo + gi - 1 : Wd + (pos + gi - 1) + (size_t)(pos + gj - 1) * ddim);
+                pre[mt][q] = *src;
+            }
         }
     }
     const double rv0 = D.res[bo + (lane < d ? lane : 0)];        /* root: residual for res' * dlam, requested early */
@@ -317,7 +373,8 @@ __global__ void __launch_bounds__(WT) k_factor_w(Tree T, Data D, Opts O, int fir
             for (int q = 0; q < 4; q++) {
                 const int gj = 16 * J + g + 4 * q;
                 if (gi >= 1 && gi <= nxi && gj <= gi) {
-                    if (gj == 0) D.resMod[xo + gi - 1] = pre[mt][q] - acc[q];
+                    if (FUSED) st_tag(sch + ((size_t)ii * rs + (size_t)gi * (nxi + 1) + gj) * 2, acc[q], tag);
+                    else if (gj == 0) D.resMod[xo + gi - 1] = pre[mt][q] - acc[q];
                     else Wd[(pos + gi - 1) + (size_t)(pos + gj - 1) * ddim] = pre[mt][q] - acc[q];
                 }
             }
@@ -341,6 +398,17 @@ __global__ void __launch_bounds__(WT) k_factor_w(Tree T, Data D, Opts O, int fir
         if (lane == 0) D.part_dot[0] = pd;
     }
     WSTAMP(15);
+}
+
+__global__ void __launch_bounds__(WT) k_factor_w(Tree T, Data D, Opts O, int first, int h) {
+    factor_w_body<false>(T, D, O, first + blockIdx.x, first, h, nullptr, 0, 0u);
+}
+/* the backward sweep of ALL levels as one launch: workgroup b takes block Np - 1 - b */
+#ifndef TQ_WIDE_WPS
+#define TQ_WIDE_WPS 2
+#endif
+__global__ void __launch_bounds__(WT, TQ_WIDE_WPS) k_factor_all_w(Tree T, Data D, Opts O, u64 *sch, int rs, unsigned tag, int h) {
+    factor_w_body<true>(T, D, O, T.Np - 1 - (int)blockIdx.x, T.Np - 1 - (int)blockIdx.x, h, sch, rs, tag);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -478,5 +546,5 @@ __global__ void __launch_bounds__(WT) k_forward_all_w(Tree T, Data D, u64 *fw, u
 /* LDS a block of dimension d (tall matrix of R rows, nz parent columns) needs in the wide kernels */
 static inline size_t wide_lds_hess(int d, int nz) { const int dp = (d + 15) & ~15, kz = (nz + 3) & ~3; return (size_t)2 * (dp | 16) * kz * sizeof(double); }
 static inline int wide_rows(int d, int nxi) { const int dp = (d + 15) & ~15; return (dp + 1 + nxi + 15) & ~15; }      /* padded rows of the tall matrix */
-static inline size_t wide_lds_factor(int d, int nxi) { const int dp = (d + 15) & ~15; return (size_t)(wide_rows(d, nxi) | 16) * dp * sizeof(double); }
+static inline size_t wide_lds_factor(int d, int nxi) { const int dp = (d + 15) & ~15; return (size_t)wide_ldf(wide_rows(d, nxi)) * dp * sizeof(double); }
 static inline size_t wide_lds_forward(int d) { return ((size_t)(d | 1) * d + WW * 64 + 2) * sizeof(double); }
