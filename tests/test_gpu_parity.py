@@ -453,7 +453,9 @@ def test_fused_path_matches_oracle_and_generic(gpu, orc, name, make):
         assert orc.max_kkt(flat, sol) < 1e-8
     assert_solution_close(sf, sg, TOL)
     assert_solution_close(stt, sg, TOL)
-    assert rf["n_launches"] <= rt["n_launches"] < rg["n_launches"]
+    # persistent: one launch per solve; the launch-per-tier and launch-per-phase paths need many (the latter fuses the levels of a
+    # sweep into one launch since round 2, so it is no longer necessarily above the tiered count)
+    assert rf["n_launches"] <= rt["n_launches"] and rf["n_launches"] < rg["n_launches"]
 
 
 @pytest.mark.parametrize("opts", [dict(regType=0), dict(regType=1, regValue=1e-8), dict(termCondition=0),

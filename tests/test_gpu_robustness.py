@@ -298,3 +298,53 @@ def test_factor_keeping_kernel_variant(gpu, orc, name, make, elim, scale, o):
         assert s.solve() == 0 and qp.info["iter"] == ref["iter"]
         assert_solution_close(qp.solution(), ref, TOL)
         s.destroy()
+
+
+@pytest.mark.gpu
+def test_event_timing_switch_and_fused_sweeps_agree_with_per_level_launches(gpu, monkeypatch):
+    """tqgpu_set_event_timing(0): a persistent solve is the bare launch (device_times -> NaN), same result; and the launch-per-phase
+    path gives the same solution whether a sweep is one launch (blocks wait for each other inside it) or one launch per level."""
+    import numpy as np
+    from treeqp_amd import problems as P
+    p = P.linear_chain(2, 5, 5)
+    nk = p.nk()
+    nx = np.full(p.Nn, p.nx, dtype=np.int32)
+    nu = np.where(nk > 0, p.nu, 0).astype(np.int32)
+    qp = gpu.TreeQp(nx, nu, nk).fill_lti(p)
+    g = gpu.TqGpu(nk, nx, nu).upload(qp.flat(), p.lambda0)
+    assert g.path == 2
+    r1 = g.solve()
+    t_on = g.device_times(1)
+    s1 = g.solution()
+    g.event_timing(False)
+    r2 = g.solve()
+    t_off = g.device_times(1)
+    s2 = g.solution()
+    g.event_timing(True)
+    assert np.isfinite(t_on).all() and np.isnan(t_off).all()
+    assert (r1["status"], r1["iter"], r1["ls_total"]) == (r2["status"], r2["iter"], r2["ls_total"])
+    assert r2["device_time"] > 0
+    for k in ("x", "u", "lam", "mu_x", "mu_u"):
+        assert np.array_equal(s1[k], s2[k])
+    g.close()
+    # fused sweeps against one launch per level, narrow (wave per block) and wide (workgroup per block) kernels
+    for f in (P.irregular_clipping_qp(), P.pruned_chain_qp(seed=11)):
+        sols = []
+        for mode in ("", "levels"):
+            monkeypatch.setenv("TREEQP_AMD_PATH", "generic")
+            if mode:
+                monkeypatch.setenv("TREEQP_AMD_FWD", mode)
+                monkeypatch.setenv("TREEQP_AMD_BWD", mode)
+            else:
+                monkeypatch.delenv("TREEQP_AMD_FWD", raising=False)
+                monkeypatch.delenv("TREEQP_AMD_BWD", raising=False)
+            m = gpu.TqGpu(f.nk, f.nx, f.nu).upload(f.as_dict(), f.lambda0)
+            assert m.path == 0
+            r = m.solve(**f.opts)
+            sols.append((r, m.solution()))
+            m.close()
+        (ra, sa), (rb, sb) = sols
+        assert (ra["status"], ra["iter"], ra["ls_total"]) == (rb["status"], rb["iter"], rb["ls_total"]) and ra["status"] == 0
+        assert ra["n_launches"] < rb["n_launches"]
+        for k in ("x", "u", "lam"):
+            assert np.max(np.abs(sa[k] - sb[k])) <= 1e-10 * max(1.0, np.max(np.abs(sb[k])))

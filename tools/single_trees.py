@@ -1,5 +1,5 @@
 """Single small / irregular trees: device time of one solve against the CPU oracle on one thread (same box).
-Usage: python tools/single_trees.py"""
+Usage: python tools/single_trees.py [substring of the case name]"""
 import sys
 import time
 from pathlib import Path
@@ -14,7 +14,10 @@ import oracle_py as orc
 
 cases = [("thesis example", P.thesis_example()), ("pruned chain (one C5 tree)", P.pruned_chain_qp()),
          ("irregular clipping", P.irregular_clipping_qp()), ("random shape seed 5", P.random_shape_qp(5))]
+only = sys.argv[1] if len(sys.argv) > 1 else ""
 for name, f in cases:
+    if only and only not in name:
+        continue
     g = capi.TqGpu(f.nk, f.nx, f.nu).upload(f.as_dict(), f.lambda0)
     g.event_timing(False)
     for _ in range(10):

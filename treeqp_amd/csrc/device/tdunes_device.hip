@@ -118,6 +118,34 @@ struct Opts {
     double tol, regTol, regValue, gamma, beta;
 };
 
+/* Tagged words: what crosses workgroups INSIDE a launch.  A double travels as two 64-bit relaxed agent-scope atomic stores,
+ * each (tag << 32) | 32-bit half; the consumer polls the payload itself until every word carries the tag it expects (see
+ * tdunes_persist.hpp).  Relaxed agent-scope accesses go to the memory side, so nothing depends on one XCD's L2 seeing another's. */
+#define RLX __ATOMIC_RELAXED
+#define AGENT __HIP_MEMORY_SCOPE_AGENT
+typedef unsigned long long u64;
+__device__ __forceinline__ void st_tag(u64 *p, double v, unsigned tag) {
+    const u64 t = (u64)tag << 32;
+    __hip_atomic_store(p, t | (unsigned)__double2loint(v), RLX, AGENT);
+    __hip_atomic_store(p + 1, t | (unsigned)__double2hiint(v), RLX, AGENT);
+}
+__device__ __forceinline__ double ld_tag(const u64 *p, unsigned tag, bool &ok) {
+    const u64 a = __hip_atomic_load(p, RLX, AGENT), b = __hip_atomic_load(p + 1, RLX, AGENT);
+    ok = ok && (unsigned)(a >> 32) == tag && (unsigned)(b >> 32) == tag;
+    return __hiloint2double((int)(unsigned)b, (int)(unsigned)a);
+}
+/* one tagged double, polled until it is there; gives up after 0.5 s (dead = true, value 0) */
+__device__ __forceinline__ double wait_tag(const u64 *p, unsigned tag, bool &dead) {
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        bool ok = true;
+        const double v = ld_tag(p, tag, ok);
+        if (ok) return v;
+        if (dead || wall_clock64() - t0 > 50000000ull) { dead = true; return 0.0; }      /* 100 MHz clock */
+        __builtin_amdgcn_s_sleep(4);
+    }
+}
+
 /* Phase guards.  The host enqueues kernels ahead of the device's decisions and tags every launch
  * with the Newton iteration `h` (and line-search trial `t`) it belongs to; a kernel whose tag does
  * not match the device state is a no-op.  This keeps the host out of the loop: it only reads the
@@ -559,7 +587,11 @@ __device__ __forceinline__ void tall_potrf(double *Tm, double *invd, int R, int 
     }
 }
 
-__device__ void factor_body(const Tree &T, const Data &D, const Opts &O, int ii, int lane, double *lds) {
+/* sch != nullptr: the backward sweep of all levels is ONE launch (k_factor_all): the Schur complement of a block does not go
+ * into the parent's W / resMod in global memory but travels as a record of tagged words -- entry (gi, gj), 1 <= gi <= nx,
+ * 0 <= gj <= gi, of [v | S] at gi * (nx + 1) + gj of the block's record (rs doubles per node) -- and the parent subtracts the
+ * records of its children from its tall matrix in LDS as they arrive (see factor_w_body in tdunes_wide.hpp). */
+__device__ void factor_body(const Tree &T, const Data &D, const Opts &O, int ii, int lane, double *lds, u64 *sch = nullptr, int rs = 0, unsigned tag = 0u) {
     Ctrl *c = D.ctrl;
     const int d = T.bdim[ii], nxi = ii > 0 ? T.nx[ii] : 0;
     const int R = d + 1 + nxi, ld = R | 1;
@@ -580,6 +612,27 @@ __device__ void factor_body(const Tree &T, const Data &D, const Opts &O, int ii,
         for (int e = lane; e < nxi * d; e += WAVE) {
             const int i = e % nxi, j = e / nxi;
             Tm[d + 1 + i + (size_t)j * ld] = Ut[i + (size_t)j * nxi];
+        }
+        if (sch) {
+            WSYNC();
+            const int k0 = T.kid0[ii];
+            bool dead = false;
+            for (int cc = 0, posc = 0; cc < T.nk[ii]; cc++) {
+                const int kid = k0 + cc, nxc = T.nx[kid];
+                if (kid < T.Np) {
+                    const int w = nxc + 1;
+                    const u64 *rec = sch + (size_t)kid * rs * 2;
+                    for (int f = lane; f < w * w; f += WAVE) {
+                        const int gi = f / w, gj = f - gi * w;
+                        if (gi < 1 || gj > gi) continue;
+                        const double val = wait_tag(rec + (size_t)f * 2, tag, dead);
+                        double *dst = gj == 0 ? Tm + d + (size_t)(posc + gi - 1) * ld : Tm + (posc + gi - 1) + (size_t)(posc + gj - 1) * ld;
+                        *dst -= val;
+                    }
+                }
+                posc += nxc;
+            }
+            if (dead) { c->status = 3; __hip_atomic_store(&c->done, 1, RLX, AGENT); }      /* cannot happen: the children were started first */
         }
         WSYNC();
         tall_potrf(Tm, invd, R, d, ld, lane);
@@ -615,13 +668,15 @@ __device__ void factor_body(const Tree &T, const Data &D, const Opts &O, int ii,
             if (i < j) continue;
             double acc = 0.0;
             for (int cidx = 0; cidx < d; cidx++) acc = fma(Tm[d + 1 + i + (size_t)cidx * ld], Tm[d + 1 + j + (size_t)cidx * ld], acc);
-            Wd[(pos + i) + (size_t)(pos + j) * ddim] -= acc;
+            if (sch) st_tag(sch + ((size_t)ii * rs + (size_t)(i + 1) * (nxi + 1) + (j + 1)) * 2, acc, tag);
+            else Wd[(pos + i) + (size_t)(pos + j) * ddim] -= acc;
         }
         const int xo = T.xoff[ii];
         for (int i = lane; i < nxi; i += WAVE) {
             double acc = 0.0;
             for (int cidx = 0; cidx < d; cidx++) acc = fma(Tm[d + 1 + i + (size_t)cidx * ld], Tm[d + (size_t)cidx * ld], acc);
-            D.resMod[xo + i] -= acc;
+            if (sch) st_tag(sch + ((size_t)ii * rs + (size_t)(i + 1) * (nxi + 1)) * 2, acc, tag);
+            else D.resMod[xo + i] -= acc;
         }
     } else {
         /* root: dlam_0 = L^-T (L^-1 resMod_0); column-oriented back substitution, k descending */
@@ -650,23 +705,40 @@ __global__ void __launch_bounds__(WAVE) k_factor(Tree T, Data D, Opts O, int fir
     if (!phase_main(D.ctrl, h)) return;
     factor_body(T, D, O, first + blockIdx.x, threadIdx.x, lds);
 }
+/* all levels in one launch: workgroup b takes block Np - 1 - b, so that the children a block waits for were started before it */
+__global__ void __launch_bounds__(WAVE) k_factor_all(Tree T, Data D, Opts O, u64 *sch, int rs, unsigned tag, int h) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    if (!phase_main(D.ctrl, h)) return;
+    factor_body(T, D, O, T.Np - 1 - (int)blockIdx.x, threadIdx.x, lds, sch, rs, tag);
+}
 
 /* ------------------------------------------------------------------------------------------ */
 /* k_forward: one wave per block of one level:                                                 */
 /*   dlam_ii = L^-T ( y_ii - CholUt_ii' * dlam_dad[pos..] )                                    */
 /* ------------------------------------------------------------------------------------------ */
-__device__ void forward_body(const Tree &T, const Data &D, int ii, int lane, double *lds) {
+/* fw != nullptr: the forward sweep of all levels is ONE launch (k_forward_all): the step of the parent block arrives as tagged
+ * words (children of the root read D.dlam, which k_factor wrote in an earlier launch), and the block's own step is posted the
+ * same way.  Everything that does not depend on the parent is fetched before the wait. */
+__device__ void forward_body(const Tree &T, const Data &D, int ii, int lane, double *lds, u64 *fw = nullptr, unsigned tag = 0u) {
     const int d = T.bdim[ii], nxi = T.nx[ii], ld = d | 1;
     double *L = lds;                      /* ld x d */
     double *z = lds + (size_t)ld * d;     /* d */
     double *dl = z + d;                   /* nxi : dlam of node ii (inside the parent's block) */
+    double *iv = dl + nxi;                /* d : reciprocal diagonal (from global memory it was one round trip per step of the chain below) */
     const int bo = T.xoff[T.kid0[ii]], xo = T.xoff[ii];
     const double *Lg = D.CholW + T.woff[ii];
     for (int e = lane; e < d * d; e += WAVE) {
         const int i = e % d, j = e / d;
         if (i >= j) L[i + (size_t)j * ld] = Lg[i + (size_t)j * d];
     }
-    for (int i = lane; i < nxi; i += WAVE) dl[i] = D.dlam[xo + i];
+    for (int j = lane; j < d; j += WAVE) iv[j] = D.invd[bo + j];
+    if (fw && T.dad[ii] != 0) {
+        bool dead = false;
+        for (int i = lane; i < nxi; i += WAVE) dl[i] = wait_tag(fw + (size_t)(xo + i) * 2, tag, dead);
+        if (dead) { D.ctrl->status = 3; __hip_atomic_store(&D.ctrl->done, 1, RLX, AGENT); }      /* cannot happen: the parent was started first */
+    } else {
+        for (int i = lane; i < nxi; i += WAVE) dl[i] = D.dlam[xo + i];
+    }
     WSYNC();
     const double *CUt = D.CholUt + T.utoff[ii];
     for (int j = lane; j < d; j += WAVE) {
@@ -674,10 +746,9 @@ __device__ void forward_body(const Tree &T, const Data &D, int ii, int lane, dou
         for (int i = 0; i < nxi; i++) acc = fma(CUt[i + (size_t)j * nxi], dl[i], acc);
         z[j] = fma(-1.0, acc, D.dlam[bo + j]);
     }
-    const double *invd = D.invd + bo;
     for (int k = d - 1; k >= 0; k--) {
         WSYNC();
-        const double zk = z[k] * invd[k];
+        const double zk = z[k] * iv[k];
         for (int i = lane; i < k; i += WAVE) z[i] = fma(-L[k + (size_t)i * ld], zk, z[i]);
         WSYNC();
         if (lane == 0) z[k] = zk;
@@ -685,6 +756,7 @@ __device__ void forward_body(const Tree &T, const Data &D, int ii, int lane, dou
     WSYNC();
     double pd = 0.0;
     for (int j = lane; j < d; j += WAVE) {
+        if (fw) st_tag(fw + (size_t)(bo + j) * 2, z[j], tag);       /* first: my children wait for it */
         D.dlam[bo + j] = z[j];
         pd = fma(D.res[bo + j], z[j], pd);
     }
@@ -696,6 +768,12 @@ __global__ void __launch_bounds__(WAVE) k_forward(Tree T, Data D, int first, int
     extern __shared__ __attribute__((aligned(16))) double lds[];
     if (!phase_main(D.ctrl, h)) return;
     forward_body(T, D, first + blockIdx.x, threadIdx.x, lds);
+}
+/* all levels below the root in one launch, blocks in BFS order: a block's parent was started before it */
+__global__ void __launch_bounds__(WAVE) k_forward_all(Tree T, Data D, u64 *fw, unsigned tag, int h) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    if (!phase_main(D.ctrl, h)) return;
+    forward_body(T, D, 1 + (int)blockIdx.x, threadIdx.x, lds, fw, tag);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -828,13 +906,13 @@ struct tqgpu_solver {
     size_t lds_stage = 0, lds_hess = 0, lds_factor = 0, lds_forward = 0, lds_dense = 0;
     bool wide = false;              /* larger blocks (16 < d <= 64): workgroup-per-block MFMA kernels (tdunes_wide.hpp) */
     size_t lds_hess_w = 0, lds_factor_w = 0, lds_forward_w = 0;
-    unsigned long long *fw_words = nullptr;   /* wide path: the steps of a forward sweep as tagged words (k_forward_all_w), [sum_nx][2] */
+    unsigned long long *fw_words = nullptr;   /* launch-per-phase path: the steps of a forward sweep as tagged words (k_forward_all_w), [sum_nx][2] */
     unsigned fw_epoch = 0;              /* tag of the last fused forward launch */
-    bool fw_fused = true;               /* TREEQP_AMD_WIDE_FWD=levels: one launch per level instead */
-    unsigned long long *sch_words = nullptr;  /* wide path: Schur records of a fused backward sweep as tagged words (k_factor_all_w), [Nn][sch_rs][2] */
+    bool fw_fused = true;               /* TREEQP_AMD_FWD=levels: one launch per level instead */
+    unsigned long long *sch_words = nullptr;  /* launch-per-phase path: Schur records of a fused backward sweep as tagged words (k_factor_all_w), [Nn][sch_rs][2] */
     int sch_rs = 0;                     /* doubles per record: (max nx + 1)^2 */
     unsigned bw_epoch = 0;
-    bool bw_fused = true;               /* TREEQP_AMD_WIDE_BWD=levels: one launch per level instead */
+    bool bw_fused = true;               /* TREEQP_AMD_BWD=levels: one launch per level instead */
     bool dense = false, need_dense_init = false;   /* dense unconstrained stage solver selected (generic path only) */
     double *d_Hd = nullptr;      /* writable alias of Data.Hd */
     int *d_kind = nullptr;       /* writable alias of Data.kind */
@@ -998,7 +1076,7 @@ int build_tables(tqgpu_solver *s) {
             s->lds_hess = std::max(s->lds_hess, (2 * d * nz + 2) * sizeof(double));
             const size_t R = d + 1 + (k > 0 ? s->nx[k] : 0), ld = R | 1;
             s->lds_factor = std::max(s->lds_factor, (ld * d + d + 2) * sizeof(double));
-            s->lds_forward = std::max(s->lds_forward, ((d | 1) * d + d + s->nx[k] + 2) * sizeof(double));
+            s->lds_forward = std::max(s->lds_forward, ((d | 1) * d + 2 * d + s->nx[k] + 2) * sizeof(double));
         }
     }
     {
@@ -1501,11 +1579,12 @@ void launch_generic_iteration(tqgpu_solver *s, const Opts &O, int h, int &launch
     else hipLaunchKernelGGL(k_hess, dim3(T.Np), dim3(WAVE), s->lds_hess, st, T, D, h);
     launches++;
     mark(1);
-    if (wide && s->sch_words && s->bw_fused && !phases) {
+    if (s->sch_words && s->bw_fused && !phases) {
         /* all levels in one launch, last block first: a block waits for its children's Schur records inside the kernel */
         s->bw_epoch++;
         if (s->bw_epoch == 0) s->bw_epoch = 1;
-        hipLaunchKernelGGL(k_factor_all_w, dim3(T.Np), dim3(WT), s->lds_factor_w, st, T, D, O, s->sch_words, s->sch_rs, s->bw_epoch, h);
+        if (wide) hipLaunchKernelGGL(k_factor_all_w, dim3(T.Np), dim3(WT), s->lds_factor_w, st, T, D, O, s->sch_words, s->sch_rs, s->bw_epoch, h);
+        else hipLaunchKernelGGL(k_factor_all, dim3(T.Np), dim3(WAVE), s->lds_factor, st, T, D, O, s->sch_words, s->sch_rs, s->bw_epoch, h);
         launches++;
     } else
     for (int lvl = T.Nh - 1; lvl >= 0; lvl--) {
@@ -1514,12 +1593,15 @@ void launch_generic_iteration(tqgpu_solver *s, const Opts &O, int h, int &launch
         else hipLaunchKernelGGL(k_factor, dim3(count), dim3(WAVE), s->lds_factor, st, T, D, O, first, h);
         launches++;
     }
-    if (wide && s->fw_words && s->fw_fused && T.Np > 1) {
+    if (s->fw_words && s->fw_fused && !phases) {
         /* all levels below the root in one launch: a block waits for its parent's step inside the kernel */
-        s->fw_epoch++;
-        if (s->fw_epoch == 0) s->fw_epoch = 1;
-        hipLaunchKernelGGL(k_forward_all_w, dim3(T.Np - 1), dim3(WT), s->lds_forward_w, st, T, D, s->fw_words, s->fw_epoch, h);
-        launches++;
+        if (T.Np > 1) {
+            s->fw_epoch++;
+            if (s->fw_epoch == 0) s->fw_epoch = 1;
+            if (wide) hipLaunchKernelGGL(k_forward_all_w, dim3(T.Np - 1), dim3(WT), s->lds_forward_w, st, T, D, s->fw_words, s->fw_epoch, h);
+            else hipLaunchKernelGGL(k_forward_all, dim3(T.Np - 1), dim3(WAVE), s->lds_forward, st, T, D, s->fw_words, s->fw_epoch, h);
+            launches++;
+        }
     } else
     for (int lvl = 1; lvl < T.Nh; lvl++) {
         const int first = s->lvl_first[lvl], count = s->lvl_first[lvl + 1] - first;
@@ -1695,7 +1777,8 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
     }
 
     if ((rc = allow_lds(k_stage, s->lds_stage)) || (rc = allow_lds(k_hess, s->lds_hess)) ||
-        (rc = allow_lds(k_factor, s->lds_factor)) || (rc = allow_lds(k_forward, s->lds_forward)))
+        (rc = allow_lds(k_factor, s->lds_factor)) || (rc = allow_lds(k_forward, s->lds_forward)) ||
+        (rc = allow_lds(k_factor_all, s->lds_factor)) || (rc = allow_lds(k_forward_all, s->lds_forward)))
         return cleanup_fail(rc);
     if (s->wide && ((rc = allow_lds(k_hess_w, s->lds_hess_w)) || (rc = allow_lds(k_factor_w, s->lds_factor_w)) || (rc = allow_lds(k_forward_w, s->lds_forward_w)) || (rc = allow_lds(k_forward_all_w, s->lds_forward_w)) || (rc = allow_lds(k_factor_all_w, s->lds_factor_w))))
         return cleanup_fail(rc);
@@ -1703,12 +1786,12 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) != hipSuccess || prop.maxThreadsPerBlock < FW * WAVE) s->fast = -1;
     }
-    if (s->wide) {
-        /* hand-over words of the fused forward sweep (zeroed once; every launch brings its own tag) */
+    {
+        /* hand-over words of the fused forward / backward sweeps of the launch-per-phase path (zeroed once; every launch brings its own tag) */
         const size_t bytes = sizeof(unsigned long long) * 2 * (size_t)std::max(s->sum_nx, 1);
         if (hipMalloc(&s->fw_words, bytes) != hipSuccess || hipMemset(s->fw_words, 0, bytes) != hipSuccess)
             return cleanup_fail(fail(TQGPU_ENOMEM, "hipMalloc failed for the forward hand-over words"));
-        const char *m = getenv("TREEQP_AMD_WIDE_FWD");
+        const char *m = getenv("TREEQP_AMD_FWD");              /* =levels: one launch per tree level (the round-1 protocol) */
         s->fw_fused = !(m && strcmp(m, "levels") == 0);
         int nxmax = 0;
         for (int k = 0; k < s->Nn; k++) nxmax = std::max(nxmax, s->nx[k]);
@@ -1716,7 +1799,7 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
         const size_t sbytes = sizeof(unsigned long long) * 2 * (size_t)s->sch_rs * (size_t)s->Nn;
         if (hipMalloc(&s->sch_words, sbytes) != hipSuccess || hipMemset(s->sch_words, 0, sbytes) != hipSuccess)
             return cleanup_fail(fail(TQGPU_ENOMEM, "hipMalloc failed for the Schur hand-over words"));
-        m = getenv("TREEQP_AMD_WIDE_BWD");
+        m = getenv("TREEQP_AMD_BWD");
         s->bw_fused = !(m && strcmp(m, "levels") == 0);
     }
     if ((rc = setup_persist(s, device))) return cleanup_fail(rc);

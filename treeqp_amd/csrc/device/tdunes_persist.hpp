@@ -53,11 +53,6 @@
  */
 #pragma once
 
-#define RLX __ATOMIC_RELAXED
-#define AGENT __HIP_MEMORY_SCOPE_AGENT
-
-typedef unsigned long long u64;
-
 /* what only the start and the end of a launch touch; lives in device memory so that the kernel
  * holds ONE pointer during the loop (scalar register pressure) */
 /* result block in pinned host memory: the top workgroup writes it the moment the launch is decided, the
@@ -114,16 +109,6 @@ struct PSync {
     unsigned trip;          /* tag of the pass the workgroup is in (kernel-local copy only)           */
 };
 
-__device__ __forceinline__ void st_tag(u64 *p, double v, unsigned tag) {
-    const u64 t = (u64)tag << 32;
-    __hip_atomic_store(p, t | (unsigned)__double2loint(v), RLX, AGENT);
-    __hip_atomic_store(p + 1, t | (unsigned)__double2hiint(v), RLX, AGENT);
-}
-__device__ __forceinline__ double ld_tag(const u64 *p, unsigned tag, bool &ok) {
-    const u64 a = __hip_atomic_load(p, RLX, AGENT), b = __hip_atomic_load(p + 1, RLX, AGENT);
-    ok = ok && (unsigned)(a >> 32) == tag && (unsigned)(b >> 32) == tag;
-    return __hiloint2double((int)(unsigned)b, (int)(unsigned)a);
-}
 /* Poll loops read the payload AND the two "launch is over" words in the same round trip (the loads are
  * independent, so they are in flight together); a poll iteration is then one memory latency long and needs
  * no sleep.  `over` = halt word == launch number or timeout word set; false = give up. */
