@@ -251,11 +251,16 @@ def main():
     iters = 0
     ls = 0
     launches = 0
-    for _ in range(args.steps):
-        it_, ls_, la_, r = solve_step()   # returns when the verdict (status, iteration count) of every tree is on the host
-        iters += it_
-        ls += ls_
-        launches += la_
+    if len(mirrors) == 1:
+        # the K steps as the reference's drivers run their NREP solves: a loop in C (tqgpu_solve_n), every solve waiting for its
+        # verdict (status, iteration count) before the next starts -- the solver is timed, not this interpreter
+        r, iters, ls, launches = g.solve_n(args.steps, **opts)
+    else:
+        for _ in range(args.steps):
+            it_, ls_, la_, r = solve_step()   # returns when the verdict of every tree is on the host
+            iters += it_
+            ls += ls_
+            launches += la_
     for m in mirrors:
         m.device_times(1)                 # synchronises: all K solves are complete (state written back)
     barrier()

@@ -146,6 +146,11 @@ int tqgpu_shard_gather_solution(tqgpu_solver *s);
 /* test / diagnostic: n virtual ranks of one tree in one process on one device, lock-step */
 int tqgpu_solve_virtual_ranks(tqgpu_solver **ranks, int n, const tqgpu_opts *opts, tqgpu_result *res);
 
+/* n solves of the same problem from the same starting duals, one after the other, each waiting for its verdict: the timing loop
+ * of the reference's drivers (examples/spring_mass_dual_newton_tree.c:135-140, `for (jj = 0; jj < NREP; jj++)
+ * treeqp_tdunes_solve(...)`) in C.  res: the last solve; sums over the solves in *iter_sum, *ls_sum, *launch_sum (each may be NULL). */
+int tqgpu_solve_n(tqgpu_solver *s, const tqgpu_opts *opts, int n, tqgpu_result *res, long *iter_sum, long *ls_sum, long *launch_sum);
+
 /* Batched multi-tree solve: n independent mirrors with the same options (examples/fault_tolerance.c:486-530
  * holds one tree_qp_in / workspace pair per configuration and solves them one after the other).  Mirrors whose
  * solve is a single persistent launch run concurrently, as many as fit on the device at once. */

@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(FW * WAVE) sg_bench(PConst C, Opts O, PSync Sy
     long long t0 = clock64();
     for (int r = 0; r < reps; r++) {
         if (WHAT == 0) {
-            acc += p_stage_owned<NX, NU, MD>(C, Sy, L, l0, nown, s, wave, lane, 1.0, r & 1, false, false, 0u, PChain{1, 1.0, 0.6}, false);
+            acc += p_stage_owned<NX, NU, MD, false>(C, Sy, L, l0, nown, s, wave, lane, 1.0, r & 1, false, false, 0u, PChain{1, 1.0, 0.6}, false);
             __syncthreads();
         } else {
             for (int loc0 = wave; loc0 < nbt; loc0 += 2 * FW) {

@@ -538,6 +538,24 @@ class TqGpu:
         self._chk(lib().tqgpu_solve(self.h, C.byref(o), C.byref(r)))
         return {f: getattr(r, f) for f, _ in GpuResult._fields_}
 
+    def solve_n(self, n: int, profile=0, **kw):
+        """n solves back to back (the reference drivers' NREP loop, in C) -> (last result, sum of iterations, of trials, of launches)."""
+        key = (profile, tuple(sorted(kw.items())))
+        cache = self.__dict__.setdefault("_opts_cache", {})
+        o = cache.get(key)
+        if o is None:
+            o = GpuOpts(maxIter=100, termCondition=2, stationarityTolerance=1e-8, regType=2, regTol=1e-6, regValue=1e-6,
+                        lineSearchMaxIter=50, lineSearchGamma=0.1, lineSearchBeta=0.6, lineSearchRestartTrigger=-1, profile=profile, checkLastActiveSet=1)
+            for k, v in kw.items():
+                if not hasattr(o, k):
+                    raise KeyError(k)
+                setattr(o, k, v)
+            cache[key] = o
+        r = GpuResult()
+        it, ls, la = C.c_long(0), C.c_long(0), C.c_long(0)
+        self._chk(lib().tqgpu_solve_n(self.h, C.byref(o), int(n), C.byref(r), C.byref(it), C.byref(ls), C.byref(la)))
+        return {f: getattr(r, f) for f, _ in GpuResult._fields_}, it.value, ls.value, la.value
+
     def solution(self) -> dict:
         out = dict(x=np.zeros(self.sum_nx), u=np.zeros(self.sum_nu), lam=np.zeros(self.sum_lam),
                    mu_x=np.zeros(self.sum_nx), mu_u=np.zeros(self.sum_nu), dlam=np.zeros(self.sum_lam))

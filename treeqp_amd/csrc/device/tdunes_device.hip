@@ -261,22 +261,25 @@ __global__ void __launch_bounds__(WAVE) k_dense_init(Tree T, Data D) {
     }
 }
 
-/* acc + sum_{i < n} a[i * sa] * b[i * sb], terms added in ascending order (the reference's order), but the loads go out EIGHT
+/* acc + sum_{i < n} a[i * sa] * b[i * sb], terms added in ascending order (the reference's order), but the loads go out DOT_BATCH
  * AT A TIME: a runtime-bounded `for (i) acc = fma(a[i], b[i], acc)` makes one memory round trip per trip of the loop (the
  * compiler does not move loads across the back edge), which is what the node sweeps of wider nodes spent their time on
  * (k_stage / k_grad at nx = 20, nu = 10: 15.6 / 13.3 us per launch).  Clamped addresses, masked use: nothing diverges. */
+#ifndef DOT_BATCH
+#define DOT_BATCH 8       /* loads in flight per lane and batch (16 and 24 measured slower: registers; tools/ab.py db8 / db16 / db24) */
+#endif
 __device__ __forceinline__ double dot_batched(const double *a, int sa, const double *b, int sb, int n, double acc, bool batch) {
     if (!batch) {                                            /* operands in LDS (g_persist with its state mirrored): the plain loop is the shorter program */
         for (int i = 0; i < n; i++) acc = fma(a[(size_t)i * sa], b[(size_t)i * sb], acc);
         return acc;
     }
-    for (int i0 = 0; i0 < n; i0 += 8) {
-        double va[8], vb[8];
+    for (int i0 = 0; i0 < n; i0 += DOT_BATCH) {
+        double va[DOT_BATCH], vb[DOT_BATCH];
 #pragma unroll
-        for (int m = 0; m < 8; m++) { const int i = i0 + m < n ? i0 + m : 0; va[m] = a[(size_t)i * sa]; vb[m] = b[(size_t)i * sb]; }
+        for (int m = 0; m < DOT_BATCH; m++) { const int i = i0 + m < n ? i0 + m : 0; va[m] = a[(size_t)i * sa]; vb[m] = b[(size_t)i * sb]; }
         asm volatile("" ::: "memory");                       /* the batch stays a batch (see LOADS_DONE in tdunes_wide.hpp) */
 #pragma unroll
-        for (int m = 0; m < 8; m++) { const double t = fma(va[m], vb[m], acc); acc = i0 + m < n ? t : acc; }
+        for (int m = 0; m < DOT_BATCH; m++) { const double t = fma(va[m], vb[m], acc); acc = i0 + m < n ? t : acc; }
     }
     return acc;
 }
@@ -2349,6 +2352,28 @@ extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *r
     rc = solve_end(s, o, cx, res);
     if (rc == TQGPU_ETIMEOUT) rc = solve_after_timeout(s, o, res);
     return rc;
+}
+
+/* n solves of the same problem from the same starting duals, one after the other (each waits for its verdict), as the reference's
+ * drivers time the solver (`for (jj = 0; jj < NREP; jj++) treeqp_tdunes_solve(...)`, examples/spring_mass_dual_newton_tree.c:135-140):
+ * the loop is in C, so what is timed is the solver and not the caller's interpreter.  res = the last solve's result; sums over
+ * the n solves in iter_sum / ls_sum / launch_sum.  Stops at the first solve that does not end with status 0 or 1. */
+extern "C" int tqgpu_solve_n(tqgpu_solver *s, const tqgpu_opts *o, int n, tqgpu_result *res, long *iter_sum, long *ls_sum, long *launch_sum) {
+    if (!s || !o || !res || n < 1) return fail(TQGPU_EINVAL, "tqgpu_solve_n: bad arguments");
+    long it = 0, ls = 0, la = 0;
+    static const int pace = getenv("TREEQP_AMD_PACE") ? atoi(getenv("TREEQP_AMD_PACE")) : 0;      /* experiment: 1 = wait for the stream to drain before the next launch */
+    for (int i = 0; i < n; i++) {
+        const int rc = tqgpu_solve(s, o, res);
+        if (rc != TQGPU_OK) return rc;
+        if (pace == 1) HIP_TRY(hipStreamSynchronize(s->stream));
+        else if (pace > 1) { const auto t0 = std::chrono::steady_clock::now(); while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(pace)) __builtin_ia32_pause(); }
+        it += res->iter; ls += res->ls_total; la += res->n_launches;
+        if (res->status != 0 && res->status != 1) break;
+    }
+    if (iter_sum) *iter_sum = it;
+    if (ls_sum) *ls_sum = ls;
+    if (launch_sum) *launch_sum = la;
+    return TQGPU_OK;
 }
 
 /* diagnostic / test support: a foreign kernel that holds compute units.  `blocks` workgroups of 256 threads, each claiming `lds_kb`
