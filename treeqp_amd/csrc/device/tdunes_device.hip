@@ -266,7 +266,11 @@ __global__ void __launch_bounds__(WAVE) k_dense_init(Tree T, Data D) {
  * compiler does not move loads across the back edge), which is what the node sweeps of wider nodes spent their time on
  * (k_stage / k_grad at nx = 20, nu = 10: 15.6 / 13.3 us per launch).  Clamped addresses, masked use: nothing diverges. */
 #ifndef DOT_BATCH
-#define DOT_BATCH 8       /* loads in flight per lane and batch (16 and 24 measured slower: registers; tools/ab.py db8 / db16 / db24) */
+#define DOT_BATCH 8       /* loads in flight per lane and batch (16 and 24 measured slower inside the single-workgroup kernel: registers).
+                             Also tried, none faster: 24 in flight in the standalone sweeps at nx = 20, the node's dimensions from its one
+                             128-byte record instead of the index tables, the children's [A | B] fetched coalesced into LDS and read back
+                             with typed LDS pointers, the staging loops of the block bodies batched the same way (slower).  k_stage /
+                             k_grad at nx = 20 stream 16 MB in 12 us behind a ~4.5 us launch floor. */
 #endif
 __device__ __forceinline__ double dot_batched(const double *a, int sa, const double *b, int sb, int n, double acc, bool batch) {
     if (!batch) {                                            /* operands in LDS (g_persist with its state mirrored): the plain loop is the shorter program */
@@ -1083,15 +1087,15 @@ int build_tables(tqgpu_solver *s) {
         }
     }
     {
-        int dmax = 0, rmax = 0;
+        int dmax = 0, rmax = 0, nzmax = 0;
         for (int k = 0; k < s->Np; k++) {
             const int d = s->bdim[k], nxi = k > 0 ? s->nx[k] : 0, nz = s->nx[k] + s->nu[k];
-            dmax = std::max(dmax, d); rmax = std::max(rmax, wide_rows(d, nxi));
+            dmax = std::max(dmax, d); rmax = std::max(rmax, wide_rows(d, nxi)); nzmax = std::max(nzmax, nz);
             s->lds_hess_w = std::max(s->lds_hess_w, wide_lds_hess(d, nz));
             s->lds_factor_w = std::max(s->lds_factor_w, wide_lds_factor(d, nxi));
             s->lds_forward_w = std::max(s->lds_forward_w, wide_lds_forward(d));
         }
-        s->wide = dmax > 16 && dmax <= 64 && rmax <= 128;
+        s->wide = dmax > 16 && dmax <= 64 && rmax <= 128 && nzmax <= 32;      /* k_hess_w keeps a parent's entries of P for 8 k-steps of 4 in registers */
     }
     const size_t lim = 160 * 1024;
     if (s->lds_factor > lim || s->lds_hess > lim)
@@ -2361,12 +2365,10 @@ extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *r
 extern "C" int tqgpu_solve_n(tqgpu_solver *s, const tqgpu_opts *o, int n, tqgpu_result *res, long *iter_sum, long *ls_sum, long *launch_sum) {
     if (!s || !o || !res || n < 1) return fail(TQGPU_EINVAL, "tqgpu_solve_n: bad arguments");
     long it = 0, ls = 0, la = 0;
-    static const int pace = getenv("TREEQP_AMD_PACE") ? atoi(getenv("TREEQP_AMD_PACE")) : 0;      /* experiment: 1 = wait for the stream to drain before the next launch */
+    /* (waiting for the stream to drain, or a few microseconds, before the next launch measured slower than launching at once) */
     for (int i = 0; i < n; i++) {
         const int rc = tqgpu_solve(s, o, res);
         if (rc != TQGPU_OK) return rc;
-        if (pace == 1) HIP_TRY(hipStreamSynchronize(s->stream));
-        else if (pace > 1) { const auto t0 = std::chrono::steady_clock::now(); while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(pace)) __builtin_ia32_pause(); }
         it += res->iter; ls += res->ls_total; la += res->n_launches;
         if (res->status != 0 && res->status != 1) break;
     }

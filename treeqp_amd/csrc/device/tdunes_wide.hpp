@@ -91,10 +91,16 @@ __global__ void __launch_bounds__(WT) k_hess_w(Tree T, Data D, int h) {
     if (!phase_main(D.ctrl, h)) return;
     const int d = e[0], nxp = e[1], nup = e[2], nz = nxp + nup;
     const int dp = up16(d), kz = (nz + 3) & ~3, ldc = wide_ld(dp);
-    double *Cs = lds, *CP = lds + (size_t)ldc * kz;
+    double *Cs = lds;             /* C only: C P is formed when an operand is fetched (one multiply per MFMA) -- half the LDS, so that all
+                                     parents of C4 (1093) are resident at once instead of in two rounds */
     const int k0 = e[4], ko = e[7];
     const double *Qc = D.QinvCal + e[5], *Rc = D.RinvCal + e[6];
-    for (int e = tid; e < 2 * ldc * kz; e += WT) lds[e] = 0.0;
+    for (int e = tid; e < ldc * kz; e += WT) lds[e] = 0.0;
+    /* this lane's entries of P for the k-steps of the product below: column s + g, s = 0, 4, .. (requested before the staging) */
+    const int g_ = lane >> 4;
+    double pcs[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) { const int col = 4 * m + g_; const int cs = col < nz ? col : 0; pcs[m] = cs < nxp ? Qc[cs] : Rc[cs - nxp]; }
     __syncthreads();
     /* children's [A B] rows: rows on the lanes, columns dealt over the waves; branch-free (clamped) loads with 32-bit
      * offsets, eight in flight per thread and child (more in flight costs registers, i.e. workgroups per CU, and this
@@ -112,20 +118,19 @@ __global__ void __launch_bounds__(WT) k_hess_w(Tree T, Data D, int h) {
         const bool rowok = lane < nxc;
         const int i = rowok ? lane : 0;
         for (int c0 = 0; c0 < nz; c0 += 8 * WW) {
-            double a[8], pc[8];
+            double a[8];
 #pragma unroll
             for (int m = 0; m < 8; m++) {
                 const int col = c0 + wave + WW * m;
                 const int cs = (rowok && col < nz) ? col : 0;
                 const bool st = cs < nxp;
                 a[m] = (st ? A : B)[i + (st ? cs : cs - nxp) * nxc];
-                pc[m] = (st ? Qc : Rc)[st ? cs : cs - nxp];
             }
             LOADS_DONE();
 #pragma unroll
             for (int m = 0; m < 8; m++) {
                 const int col = c0 + wave + WW * m;
-                if (rowok && col < nz) { Cs[rowoff + i + col * ldc] = a[m]; CP[rowoff + i + col * ldc] = a[m] * pc[m]; }
+                if (rowok && col < nz) Cs[rowoff + i + col * ldc] = a[m];
             }
         }
         rowoff += nxc;
@@ -142,10 +147,14 @@ __global__ void __launch_bounds__(WT) k_hess_w(Tree T, Data D, int h) {
             const int i = 16 * I + r;
             const double qd = D.QinvCal[ko + (i < d ? i : 0)];          /* diagonal term, in flight during the MFMAs */
             f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-            for (int s = 0; s < kz; s += 4) {
-                const double a = CP[16 * J + r + (size_t)(s + g) * ldc];
-                const double b = Cs[16 * I + r + (size_t)(s + g) * ldc];
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 8; m++) {                            /* kz <= 32 (checked at create time) */
+                const int s = 4 * m;
+                if (s < kz) {
+                    const double a = Cs[16 * J + r + (size_t)(s + g) * ldc] * pcs[m];
+                    const double b = Cs[16 * I + r + (size_t)(s + g) * ldc];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -158,7 +167,7 @@ __global__ void __launch_bounds__(WT) k_hess_w(Tree T, Data D, int h) {
         double *Ut = D.Ut + e[9];
         for (int f = tid; f < nxp * d; f += WT) {
             const int i = f % nxp, rr = f / nxp;
-            Ut[i + (size_t)rr * nxp] = -1.0 * CP[rr + (size_t)i * ldc];
+            Ut[i + (size_t)rr * nxp] = -1.0 * (Cs[rr + (size_t)i * ldc] * Qc[i]);
         }
     }
 }
@@ -341,15 +350,18 @@ __device__ __forceinline__ void factor_w_body(const Tree &T, const Data &D, cons
     const double rv0 = D.res[bo + (lane < d ? lane : 0)];        /* root: residual for res' * dlam, requested early */
     LOADS_DONE();
     /* outputs: factor (rows on the lanes, columns dealt over the waves), reciprocal diagonal, backward solution, CholUt */
-    for (int j = wave; j < d; j += WW) {
-        if (lane < d && lane >= j) Lout[lane + j * d] = Tm[lane + j * ld];
-        if (ii > 0 && lane >= 1 && lane <= nxi) CUt[(lane - 1) + j * nxi] = Tm[dp + lane + j * ld];
-    }
-    for (int j = tid; j < d; j += WT) {
-        const double l = Tm[j + j * ld];
-        D.invd[bo + j] = l > 0.0 ? 1.0 / l : 0.0;
-        if (ii > 0) D.dlam[bo + j] = Tm[dp + j * ld];
-    }
+    auto write_outputs = [&]() {
+        for (int j = wave; j < d; j += WW) {
+            if (lane < d && lane >= j) Lout[lane + j * d] = Tm[lane + j * ld];
+            if (ii > 0 && lane >= 1 && lane <= nxi) CUt[(lane - 1) + j * nxi] = Tm[dp + lane + j * ld];
+        }
+        for (int j = tid; j < d; j += WT) {
+            const double l = Tm[j + j * ld];
+            D.invd[bo + j] = l > 0.0 ? 1.0 / l : 0.0;
+            if (ii > 0) D.dlam[bo + j] = Tm[dp + j * ld];
+        }
+    };
+    if (!FUSED || ii == 0) write_outputs();      /* fused sweep: the Schur record first -- the parent is waiting for it, nobody in this launch for the rest */
 
     if (ii > 0) {
         /* Schur complement into the parent's diagonal sub-block and right-hand side: G = Xt Xt', Xt = rows dp .. R-1
@@ -379,6 +391,7 @@ __device__ __forceinline__ void factor_w_body(const Tree &T, const Data &D, cons
                 }
             }
         }
+        if (FUSED) write_outputs();
     } else if (wave == 0) {
         /* root: dlam_0 = L^-T (L^-1 resMod_0), the vector in registers (entry j on lane j) */
         const int lc = lane < d ? lane : 0;
@@ -544,7 +557,7 @@ __global__ void __launch_bounds__(WT) k_forward_all_w(Tree T, Data D, u64 *fw, u
 }
 
 /* LDS a block of dimension d (tall matrix of R rows, nz parent columns) needs in the wide kernels */
-static inline size_t wide_lds_hess(int d, int nz) { const int dp = (d + 15) & ~15, kz = (nz + 3) & ~3; return (size_t)2 * (dp | 16) * kz * sizeof(double); }
+static inline size_t wide_lds_hess(int d, int nz) { const int dp = (d + 15) & ~15, kz = (nz + 3) & ~3; return (size_t)(dp | 16) * kz * sizeof(double); }
 static inline int wide_rows(int d, int nxi) { const int dp = (d + 15) & ~15; return (dp + 1 + nxi + 15) & ~15; }      /* padded rows of the tall matrix */
 static inline size_t wide_lds_factor(int d, int nxi) { const int dp = (d + 15) & ~15; return (size_t)wide_ldf(wide_rows(d, nxi)) * dp * sizeof(double); }
 static inline size_t wide_lds_forward(int d) { return ((size_t)(d | 1) * d + WW * 64 + 2) * sizeof(double); }
