@@ -348,3 +348,23 @@ def test_event_timing_switch_and_fused_sweeps_agree_with_per_level_launches(gpu,
         assert ra["n_launches"] < rb["n_launches"]
         for k in ("x", "u", "lam"):
             assert np.max(np.abs(sa[k] - sb[k])) <= 1e-10 * max(1.0, np.max(np.abs(sb[k])))
+
+
+@pytest.mark.gpu
+def test_solve_n_is_n_solves(gpu):
+    """tqgpu_solve_n (the reference drivers' NREP loop in C, what bench.py times): same verdicts and sums as n calls of tqgpu_solve."""
+    p = P.spring_mass()
+    nk = p.nk()
+    nx = np.full(p.Nn, p.nx, dtype=np.int32)
+    nu = np.where(nk > 0, p.nu, 0).astype(np.int32)
+    qp = gpu.TreeQp(nx, nu, nk).fill_lti(p)
+    g = gpu.TqGpu(nk, nx, nu).upload(qp.flat(), p.lambda0)
+    r1 = g.solve()
+    s1 = g.solution()
+    rn, it, ls, la = g.solve_n(7)
+    sn = g.solution()
+    assert (rn["status"], rn["iter"], rn["ls_total"]) == (r1["status"], r1["iter"], r1["ls_total"]) == (0, 3, 3)
+    assert it == 7 * r1["iter"] and ls == 7 * r1["ls_total"] and la >= 7
+    for k in ("x", "u", "lam", "mu_x", "mu_u"):
+        assert np.array_equal(s1[k], sn[k])
+    g.close()

@@ -54,12 +54,12 @@ __host__ __device__ __forceinline__ int wide_ldf(int rows_padded) { return (rows
 /* z <- L^-T z for one wave, entry j of z on lane j (d <= 64): the strictly-lower part of column `lane` of L is
  * fetched into registers in one go, then every step is two readlanes and one FMA -- no memory in the chain.
  * L column major in LDS with leading dimension ld; myinv = 1 / L[lane][lane].  Returns the solution entry. */
-__device__ __forceinline__ void wide_backsolve_load(const double *L, int ld, int d, int lane, double (&Lc)[64]) {
+__device__ __forceinline__ void wide_backsolve_load(lds_cptr L, int ld, int d, int lane, double (&Lc)[64]) {
     const int lc = lane < d ? lane : 0;
 #pragma unroll
     for (int k = 1; k < 64; k++) {
         const bool use = k < d && k > lane;
-        const double v = L[(use ? k : 0) + (size_t)lc * ld];
+        const double v = L[(use ? k : 0) + lc * ld];
         Lc[k] = use ? -v : 0.0;
     }
 }
@@ -73,7 +73,7 @@ __device__ __forceinline__ double wide_backsolve_chain(const double (&Lc)[64], i
     }
     return z * myinv;
 }
-__device__ __forceinline__ double wide_backsolve(const double *L, int ld, int d, int lane, double z, double myinv) {
+__device__ __forceinline__ double wide_backsolve(lds_cptr L, int ld, int d, int lane, double z, double myinv) {
     double Lc[64];
     wide_backsolve_load(L, ld, d, lane, Lc);
     return wide_backsolve_chain(Lc, d, z, myinv);
@@ -91,11 +91,11 @@ __global__ void __launch_bounds__(WT) k_hess_w(Tree T, Data D, int h) {
     if (!phase_main(D.ctrl, h)) return;
     const int d = e[0], nxp = e[1], nup = e[2], nz = nxp + nup;
     const int dp = up16(d), kz = (nz + 3) & ~3, ldc = wide_ld(dp);
-    double *Cs = lds;             /* C only: C P is formed when an operand is fetched (one multiply per MFMA) -- half the LDS, so that all
+    lds_ptr Cs = to_lds(lds);     /* C only: C P is formed when an operand is fetched (one multiply per MFMA) -- half the LDS, so that all
                                      parents of C4 (1093) are resident at once instead of in two rounds */
     const int k0 = e[4], ko = e[7];
     const double *Qc = D.QinvCal + e[5], *Rc = D.RinvCal + e[6];
-    for (int e = tid; e < ldc * kz; e += WT) lds[e] = 0.0;
+    for (int e = tid; e < ldc * kz; e += WT) Cs[e] = 0.0;
     /* this lane's entries of P for the k-steps of the product below: column s + g, s = 0, 4, .. (requested before the staging) */
     const int g_ = lane >> 4;
     double pcs[8];
@@ -151,8 +151,8 @@ __global__ void __launch_bounds__(WT) k_hess_w(Tree T, Data D, int h) {
             for (int m = 0; m < 8; m++) {                            /* kz <= 32 (checked at create time) */
                 const int s = 4 * m;
                 if (s < kz) {
-                    const double a = Cs[16 * J + r + (size_t)(s + g) * ldc] * pcs[m];
-                    const double b = Cs[16 * I + r + (size_t)(s + g) * ldc];
+                    const double a = Cs[16 * J + r + (s + g) * ldc] * pcs[m];
+                    const double b = Cs[16 * I + r + (s + g) * ldc];
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
                 }
             }
@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(WT) k_hess_w(Tree T, Data D, int h) {
         double *Ut = D.Ut + e[9];
         for (int f = tid; f < nxp * d; f += WT) {
             const int i = f % nxp, rr = f / nxp;
-            Ut[i + (size_t)rr * nxp] = -1.0 * (Cs[rr + (size_t)i * ldc] * Qc[i]);
+            Ut[i + (size_t)rr * nxp] = -1.0 * (Cs[rr + i * ldc] * Qc[i]);
         }
     }
 }
@@ -197,7 +197,8 @@ __device__ __forceinline__ void factor_w_body(const Tree &T, const Data &D, cons
     /* rows in LDS: 0..d-1 the block, d..dp-1 identity padding (so that the padding columns stay inert), dp the right-hand
      * side, dp+1.. the Ut rows */
     const int dp = up16(d), R = dp + 1 + nxi, Rp = up16(R), ld = wide_ldf(Rp);
-    double *Tm = lds;                           /* ld x dp, column major */
+    lds_ptr Tm = to_lds(lds);                   /* ld x dp, column major; typed LDS pointer and 32-bit index arithmetic: ds_read / ds_write with
+                                                   immediate offsets instead of flat_* with 64-bit address arithmetic per access */
     const double *W = D.W + e[8];
     const int bo = e[7];
     const double *Ut = D.Ut + e[9];
@@ -263,7 +264,7 @@ __device__ __forceinline__ void factor_w_body(const Tree &T, const Data &D, cons
                             if (wall_clock64() - t0 > 50000000ull) { dead = true; val = 0.0; break; }      /* 0.5 s at 100 MHz: cannot happen (see above) */
                             __builtin_amdgcn_s_sleep(4);
                         }
-                        double *dst = gj == 0 ? Tm + dp + (size_t)(posc + gi - 1) * ld : Tm + (posc + gi - 1) + (size_t)(posc + gj - 1) * ld;
+                        lds_ptr dst = gj == 0 ? Tm + dp + (posc + gi - 1) * ld : Tm + (posc + gi - 1) + (posc + gj - 1) * ld;
                         *dst -= val;
                     }
                 }
@@ -283,7 +284,7 @@ __device__ __forceinline__ void factor_w_body(const Tree &T, const Data &D, cons
             double Tr[16];
             if (mine) {
 #pragma unroll
-                for (int j = 0; j < 16; j++) { const double v = Tm[row + (size_t)(kb + j) * ld]; Tr[j] = valid ? v : 0.0; }
+                for (int j = 0; j < 16; j++) { const double v = Tm[row + (kb + j) * ld]; Tr[j] = valid ? v : 0.0; }
             }
             __syncthreads();                       /* every wave holds its copy of the diagonal tile before wave 0 overwrites it */
             WSTAMP(2 + 3 * (kb >> 4));
@@ -291,7 +292,7 @@ __device__ __forceinline__ void factor_w_body(const Tree &T, const Data &D, cons
                 const double pmin = p_potrf_rows<16>(Tr, lane);
                 if (valid && (wave == 0 || !diag)) {
 #pragma unroll
-                    for (int j = 0; j < 16; j++) Tm[row + (size_t)(kb + j) * ld] = Tr[j];
+                    for (int j = 0; j < 16; j++) Tm[row + (kb + j) * ld] = Tr[j];
                 }
                 if (wave == 0 && lane == 0 && pmin <= O.regTol * O.regTol) small_flag = 1;   /* sqrt(pivot) <= regTol, incl. non-positive pivots */
             }
@@ -306,15 +307,15 @@ __device__ __forceinline__ void factor_w_body(const Tree &T, const Data &D, cons
                     if ((t & (WW - 1)) != wave) continue;
                     f64x4 acc;
 #pragma unroll
-                    for (int q = 0; q < 4; q++) acc[q] = Tm[16 * I + r16 + (size_t)(16 * J + g + 4 * q) * ld];
+                    for (int q = 0; q < 4; q++) acc[q] = Tm[16 * I + r16 + (16 * J + g + 4 * q) * ld];
 #pragma unroll
                     for (int s = 0; s < 16; s += 4) {
-                        const double a = -1.0 * Tm[16 * J + r16 + (size_t)(kb + s + g) * ld];
-                        const double b = Tm[16 * I + r16 + (size_t)(kb + s + g) * ld];
+                        const double a = -1.0 * Tm[16 * J + r16 + (kb + s + g) * ld];
+                        const double b = Tm[16 * I + r16 + (kb + s + g) * ld];
                         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
                     }
 #pragma unroll
-                    for (int q = 0; q < 4; q++) Tm[16 * I + r16 + (size_t)(16 * J + g + 4 * q) * ld] = acc[q];
+                    for (int q = 0; q < 4; q++) Tm[16 * I + r16 + (16 * J + g + 4 * q) * ld] = acc[q];
                 }
             }
             __syncthreads();
@@ -377,7 +378,7 @@ __device__ __forceinline__ void factor_w_body(const Tree &T, const Data &D, cons
             const int ra = dp + 16 * J + r16, rb = dp + 16 * I + r16;
             const bool oka = ra < R, okb = rb < R;
             for (int k = 0; k < dp; k += 4) {
-                const double a = Tm[(oka ? ra : 0) + (size_t)(k + g) * ld], b = Tm[(okb ? rb : 0) + (size_t)(k + g) * ld];
+                const double a = Tm[(oka ? ra : 0) + (k + g) * ld], b = Tm[(okb ? rb : 0) + (k + g) * ld];
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(oka ? a : 0.0, okb ? b : 0.0, acc, 0, 0, 0);
             }
             const int gi = 16 * I + r16;
@@ -395,12 +396,12 @@ __device__ __forceinline__ void factor_w_body(const Tree &T, const Data &D, cons
     } else if (wave == 0) {
         /* root: dlam_0 = L^-T (L^-1 resMod_0), the vector in registers (entry j on lane j) */
         const int lc = lane < d ? lane : 0;
-        const double l = Tm[lc + (size_t)lc * ld];
+        const double l = Tm[lc + lc * ld];
         const double myinv = l > 0.0 ? 1.0 / l : 0.0;
         /* (one block per solve: the plain loop, not wide_backsolve's 64-register column) */
-        double z = lane < d ? Tm[dp + (size_t)lc * ld] : 0.0;
+        double z = lane < d ? Tm[dp + lc * ld] : 0.0;
         for (int k = d - 1; k >= 1; k--) {
-            const double lk = Tm[k + (size_t)lc * ld];
+            const double lk = Tm[k + lc * ld];
             const double zk = rdlane(z * myinv, k);
             z = fma(lane < k ? -lk : 0.0, zk, z);
         }
@@ -435,8 +436,8 @@ __global__ void __launch_bounds__(WT) k_forward_w(Tree T, Data D, int first, int
     for (int i = 0; i < 10; i++) e[i] = T.desc[(size_t)DESC_INTS * ii + i];      /* node record: requested together with the control block */
     if (!phase_main(D.ctrl, h)) return;
     const int d = e[0], nxi = e[1], ld = d | 1;
-    double *L = lds;                      /* ld x d, lower part */
-    double *zz = lds + (size_t)ld * d;    /* WW x 64 : per-wave partials of CholUt' * dlam_dad */
+    lds_ptr L = to_lds(lds);              /* ld x d, lower part */
+    lds_ptr zz = L + ld * d;              /* WW x 64 : per-wave partials of CholUt' * dlam_dad */
     const int bo = e[7], xo = e[5];
     const double *Lg = D.CholW + e[8];
     const int lc = lane < d ? lane : 0;
@@ -452,7 +453,7 @@ __global__ void __launch_bounds__(WT) k_forward_w(Tree T, Data D, int first, int
     const double myinv = D.invd[bo + lc], yv = D.dlam[bo + lc], rv = D.res[bo + lc];
     LOADS_DONE();
 #pragma unroll
-    for (int m = 0; m < 16; m++) { const int j = wave + WW * m; if (lane < d && j < d && lane >= j) L[lane + (size_t)j * ld] = v[m]; }
+    for (int m = 0; m < 16; m++) { const int j = wave + WW * m; if (lane < d && j < d && lane >= j) L[lane + j * ld] = v[m]; }
     {
         double a0 = 0.0, a1 = 0.0;
 #pragma unroll
@@ -491,8 +492,8 @@ __global__ void __launch_bounds__(WT) k_forward_all_w(Tree T, Data D, u64 *fw, u
     for (int i = 0; i < 12; i++) e[i] = T.desc[(size_t)DESC_INTS * ii + i];
     if (!phase_main(D.ctrl, h)) return;
     const int d = e[0], nxi = e[1], ld = d | 1, dad = e[10];
-    double *L = lds;
-    double *zz = lds + (size_t)ld * d;
+    lds_ptr L = to_lds(lds);
+    lds_ptr zz = L + ld * d;
     const int bo = e[7], xo = e[5];
     const double *Lg = D.CholW + e[8];
     const int lc = lane < d ? lane : 0;
@@ -505,7 +506,7 @@ __global__ void __launch_bounds__(WT) k_forward_all_w(Tree T, Data D, u64 *fw, u
     const double myinv = D.invd[bo + lc], yv = D.dlam[bo + lc], rv = D.res[bo + lc];
     LOADS_DONE();
 #pragma unroll
-    for (int m = 0; m < 16; m++) { const int j = wave + WW * m; if (lane < d && j < d && lane >= j) L[lane + (size_t)j * ld] = v[m]; }
+    for (int m = 0; m < 16; m++) { const int j = wave + WW * m; if (lane < d && j < d && lane >= j) L[lane + j * ld] = v[m]; }
     __syncthreads();
     double Lc[64];                                        /* wave 0: its column of the factor, in registers before the wait */
     if (wave == 0) wide_backsolve_load(L, ld, d, lane, Lc);
