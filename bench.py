@@ -408,14 +408,14 @@ def main():
                 tb = time.perf_counter() - tb0
                 sweep.append({"trees_per_gpu": nb, "value": nit / tb, "ms_per_step": 1e3 * tb / ksteps})
                 nxt = nb + 1 if nb < 4 else nb + max(1, nb // 3)
-                if nxt * cap["workgroups_per_tree"] > cap["capacity"] or nxt > 24:
+                if nxt * cap["workgroups_per_tree"] > cap["capacity"] or nxt > 40:
                     break
                 nb = nxt
             best = max(sweep, key=lambda e: e["value"])
             out["batched"] = {"trees_per_gpu": best["trees_per_gpu"], "value": best["value"], "unit": "newton_iter/s", "ms_per_step": best["ms_per_step"],
                               "roofline_frac": best["value"] * bytes_it / 1e9 / HBM_PEAK_GBS, "sweep": sweep,
-                              "capacity": cap, "note": "independent trees per GPU, one persistent launch each, concurrently resident (every workgroup of every launch must be "
-                                                       "resident: trees_per_gpu x workgroups_per_tree <= capacity); throughput, not the latency metric"}
+                              "capacity": cap, "note": "independent trees per GPU solved by one tqgpu_solve_batch call per step: ONE launch carries all trees of a shape that has a batch kernel "
+                                                       "(every workgroup of it must be resident: trees_per_gpu x workgroups_per_tree <= capacity); throughput, not the latency metric"}
             for m in more:
                 m.close()
         if world == 1 and not args.no_cpu_baseline:

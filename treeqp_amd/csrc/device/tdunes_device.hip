@@ -992,6 +992,10 @@ struct tqgpu_solver {
     void *sync_slab = nullptr; size_t sync_bytes = 0;
     int *d_desc = nullptr;
     GItem *d_gitems = nullptr, *h_gitems = nullptr; int gitems_cap = 0;   /* batched single-workgroup launches (first mirror of a batch owns the array) */
+    PItem *d_pitems = nullptr, *h_pitems = nullptr; int pitems_cap = 0;   /* batched persistent launches: one descriptor per tree (first mirror of a batch owns the array) */
+    std::vector<unsigned long> pitems_key;                                /* the mirrors (by uid) the device copy of the array describes */
+    unsigned long uid = 0;                                                /* unique per mirror of this process (an address can come back) */
+    bool stream_pending = false;                                          /* something was enqueued on `stream` without a synchronisation after it (asynchronous uploads, constant packing): a batch launch on ANOTHER stream waits for it first */
     hipEvent_t batch_ev = nullptr;
     size_t sync_words_bytes = 0, lds_persist = 0;
     /* sharded mode */
@@ -1533,21 +1537,26 @@ int setup_persist(tqgpu_solver *s, int device) {
 
 /* one persistent launch (prologue = first sweep of the solve + control block reset): no memset, the
  * hand-over words are told apart by the launch number in their tags */
-int launch_persist(tqgpu_solver *s, const Opts &O, int &launches, int prologue) {
+int launch_persist(tqgpu_solver *s, const Opts &O, int &launches, int prologue, unsigned batch_seq = 0) {
     const Data &D = s->D; hipStream_t st = s->stream;
-    s->launch_no = (s->launch_no + 1) & 0xFFFFu;
-    if (s->launch_no == 0) {
-        /* the 16-bit launch number wraps: words that are not rewritten by every launch (the line-search command / verdict /
-         * batch partials) could still carry a tag of 65535 launches ago -- wipe the hand-over buffers (stream-ordered) */
-        s->launch_no = 1;
-        HIP_TRY(hipMemsetAsync(s->sync_slab, 0, s->sync_bytes, st));
+    if (batch_seq) s->launch_no = batch_seq >> 16;          /* part of a batch launch: the caller chose the number (and wiped the buffers if it wrapped) */
+    else {
+        s->launch_no = (s->launch_no + 1) & 0xFFFFu;
+        if (s->launch_no == 0) {
+            /* the 16-bit launch number wraps: words that are not rewritten by every launch (the line-search command / verdict /
+             * batch partials) could still carry a tag of 65535 launches ago -- wipe the hand-over buffers (stream-ordered) */
+            s->launch_no = 1;
+            HIP_TRY(hipMemsetAsync(s->sync_slab, 0, s->sync_bytes, st));
+        }
     }
     s->psync.seq = s->launch_no << 16;
     if (s->need_pack) {
         const int n = std::max(s->Nn * 16, (s->Nn - 1) * s->nx[0] * (s->nx[0] + s->nu[0]));
         hipLaunchKernelGGL(k_pack_persist, dim3((n + 255) / 256), dim3(256), 0, st, s->Nn, s->Np, s->nx[0], s->nu[0], D, s->pab, s->pcst); launches++;
         s->need_pack = false;
+        s->stream_pending = true;
     }
+    if (batch_seq) { launches++; return TQGPU_OK; }          /* the caller launches the batch */
     if (!s->mstage) {
         switch (s->fast) {
 #define X(idx, nx, nu, md) case idx: if (O.reuse) hipLaunchKernelGGL((f_persist<nx, nu, md, true>), dim3(s->geom.G), dim3(FW * WAVE), s->lds_persist, st, s->pconst, O, s->geom, s->psync, prologue); \
@@ -1653,6 +1662,7 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
     HIP_TRY(hipSetDevice(device));
 
     tqgpu_solver *s = new tqgpu_solver();
+    { static std::atomic<unsigned long> next_uid{1}; s->uid = next_uid.fetch_add(1); }
     s->device = device; s->Nn = Nn;
     s->nk.assign(nk, nk + Nn); s->nx.assign(nx, nx + Nn); s->nu.assign(nu, nu + Nn);
     int rc = build_tables(s);
@@ -1869,6 +1879,8 @@ extern "C" void tqgpu_destroy(tqgpu_solver *s) {
     if (s->pconst_slab) (void)hipFree(s->pconst_slab);
     if (s->wg_map) (void)hipFree(s->wg_map);
     if (s->d_desc) (void)hipFree(s->d_desc);
+    if (s->d_pitems) (void)hipFree(s->d_pitems);
+    if (s->h_pitems) (void)hipHostFree(s->h_pitems);
     if (s->fw_words) (void)hipFree(s->fw_words);
     if (s->sch_words) (void)hipFree(s->sch_words);
     if (s->d_gitems) (void)hipFree(s->d_gitems);
@@ -2049,6 +2061,7 @@ extern "C" int tqgpu_set_problem(tqgpu_solver *s, const double *A, const double 
         if (s->in_valid && memcmp(mir, src, bytes) == 0) return TQGPU_OK;
         memcpy(mir, src, bytes);
         HIP_TRY(hipMemcpyAsync(dev, mir, bytes, hipMemcpyHostToDevice, s->stream));
+        s->stream_pending = true;
         any_pack |= pack; any_init |= init;
         return TQGPU_OK;
     };
@@ -2069,6 +2082,7 @@ extern "C" int tqgpu_set_problem(tqgpu_solver *s, const double *A, const double 
         if (!s->lam_valid || memcmp(s->h_lam, lambda, bytes) != 0) {
             memcpy(s->h_lam, lambda, bytes);
             HIP_TRY(hipMemcpyAsync(s->d_lam_init + s->nx0, s->h_lam, bytes, hipMemcpyHostToDevice, s->stream));
+            s->stream_pending = true;
             s->lam_valid = true;
         }
     }
@@ -2121,6 +2135,7 @@ struct SolveCtx {
     int launches = 0, ring = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool fast = false, persist = false, first_launch = true, prelaunched = false, gpersist = false, phases = false, events = true;
+    unsigned batch_seq = 0;          /* != 0: this solve's persistent launch is part of a batch launch the caller makes with this launch number */
 #ifdef TQ_HOSTPROF
     std::chrono::steady_clock::time_point hp0, hp1, hp2;
 #endif
@@ -2168,13 +2183,14 @@ int solve_begin(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, GItem *defer
     s->solve_no++;
     /* the event pair costs two more packets on the queue per solve; a single persistent launch reports its own clock (launch
      * start to verdict) anyway, so there the pair is optional */
-    cx.events = s->ev_timing || !cx.persist;
+    cx.events = (s->ev_timing || !cx.persist) && !cx.batch_seq;
     s->ring_ok[(size_t)cx.ring] = cx.events ? 1 : 0;
     if (cx.events) HIP_TRY(hipEventRecord(cx.ev0, st));
     if (!cx.persist) HIP_TRY(hipMemsetAsync(D.ctrl, 0, sizeof(Ctrl), st));     /* persistent path: reset by the launch's prologue */
     if (s->need_init && !cx.gpersist) {     /* g_persist recomputes the reciprocal weights itself; dense nodes never read theirs */
         hipLaunchKernelGGL(k_init, dim3((nxu + 255) / 256), dim3(256), 0, st, s->sum_nx, s->sum_nu, D); cx.launches++;
         s->need_init = false;
+        s->stream_pending = true;
     }
     if (s->dense && s->need_dense_init) {
         hipLaunchKernelGGL(k_dense_init, dim3(T.Nn), dim3(WAVE), s->lds_dense, st, T, D); cx.launches++;
@@ -2204,7 +2220,7 @@ int solve_begin(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, GItem *defer
             if (defer) { defer->T = T; defer->D = D; defer->G = gp; }           /* launched by the caller, together with the rest of its batch */
             else hipLaunchKernelGGL(g_persist, dim3(1), dim3(GP_WAVES * WAVE), s->lds_gp_total, st, T, D, O, gp);
             cx.launches++;
-        } else rcx = launch_persist(s, O, cx.launches, 1);
+        } else rcx = launch_persist(s, O, cx.launches, 1, cx.batch_seq);
         if (rcx != TQGPU_OK) return rcx;
         cx.first_launch = false; cx.prelaunched = true;
         /* the launch normally ends the solve: close the timing here */
@@ -2421,6 +2437,30 @@ extern "C" int tqgpu_geometry(const tqgpu_solver *s, int *levels, int *tiers, in
 /* diagnostic: how often a persistent launch of this mirror timed out and the solve was redone on another path */
 extern "C" int tqgpu_timeouts(const tqgpu_solver *s) { return s ? s->n_timeouts : 0; }
 
+/* shapes with a batch kernel (f_persist_batch: one launch for a batch of trees of one shape); the BASELINE shapes -- any other
+ * (nx, nu, md) of FAST_TABLE / MSTAGE_TABLE is one line away and costs its compile time; without a line the members of a batch
+ * are launched one by one as before */
+#define BATCH_TABLE(X) X(0, 8, 3, 2, false) X(1, 4, 1, 3, true)
+static int batch_kernel_index(const tqgpu_solver *s) {
+#define X(idx, nx, nu, md, ms) if (s->fNX == nx && s->fNU == nu && s->fMD == md && s->mstage == ms) return idx;
+    BATCH_TABLE(X)
+#undef X
+    return -1;
+}
+static int launch_persist_batch(tqgpu_solver *lead, int kidx, const PItem *items, const Opts &O, int n_trees, unsigned seq) {
+    const int G = lead->geom.G;
+    static size_t lds_allowed[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    switch (kidx) {
+#define X(idx, nx, nu, md, ms) case idx: { \
+        if (lds_allowed[idx] < lead->lds_persist) { int rc = allow_lds(f_persist_batch<nx, nu, md, ms>, lead->lds_persist); if (rc != TQGPU_OK) return rc; lds_allowed[idx] = lead->lds_persist; } \
+        hipLaunchKernelGGL((f_persist_batch<nx, nu, md, ms>), dim3((unsigned)(G * n_trees)), dim3(FW * WAVE), lead->lds_persist, lead->stream, items, O, G, seq); break; }
+        BATCH_TABLE(X)
+#undef X
+        default: return fail(TQGPU_EINVAL, "no batch kernel for this shape");
+    }
+    return TQGPU_OK;
+}
+
 /* Batched multi-tree solve (the usage pattern of examples/fault_tolerance.c:486-530, one QP per
  * configuration): n independent mirrors, same options.  Mirrors on the persistent path have their launches in
  * flight together, as many at a time as fit on the device at once (every workgroup of a persistent launch must
@@ -2444,7 +2484,12 @@ extern "C" int tqgpu_solve_batch(tqgpu_solver **solvers, int n, const tqgpu_opts
             /* single-workgroup mirrors do not wait for each other: any number per launch; launch-per-level mirrors go alone */
             const int need = persist_like ? s->geom.G : (gp_like ? 0 : s->co_capacity + 1);
             /* two workgroups on one CU run at half speed each: a batch fills the CUs once, not twice, unless a member needs more */
-            const int cap = (s->n_cu > 0 && need <= s->n_cu) ? std::min(s->co_capacity, s->n_cu) : s->co_capacity;
+            /* separate launches: two workgroups on one CU run at half speed each, so a batch fills the CUs once, not twice, unless a
+             * member needs more.  Members that go out together as ONE launch (batch kernel) fill the device up to what is co-resident:
+             * a tree's waves are parked at barriers and waits two thirds of the time, and trees that share CUs fill those gaps
+             * (C2: 3 trees 72 k it/s, 5 trees 98 k; C1: 22 trees 656 k, 38 trees 922 k). */
+            const bool one_launch = persist_like && batch_kernel_index(s) >= 0 && o->checkLastActiveSet != 2 && !getenv("TREEQP_AMD_BATCH_LAUNCHES");
+            const int cap = (!one_launch && s->n_cu > 0 && need <= s->n_cu) ? std::min(s->co_capacity, s->n_cu) : s->co_capacity;
             if (j > i && (s->device != dev || used + need > cap)) break;
             used += need;
         }
@@ -2466,9 +2511,33 @@ extern "C" int tqgpu_solve_batch(tqgpu_solver **solvers, int n, const tqgpu_opts
                 return fail(TQGPU_ENOMEM, "allocation of the batch descriptors failed");
             lead->gitems_cap = (int)cap;
         }
-        size_t gi = 0, lds_batch = 0;
+        /* persistent mirrors of this wave that share a shape with a batch kernel go out as ONE launch as well */
+        std::vector<int> pm;
+        {
+            const tqgpu_solver *f = nullptr;
+            for (int k = begun_from; k < begun_to; k++) {
+                const tqgpu_solver *s = solvers[k];
+                if (!(persist_capable(s) && !o->profile && o->maxIter > 0 && o->checkLastActiveSet != 2 && batch_kernel_index(s) >= 0)) continue;
+                if (!f) f = s;
+                if (batch_kernel_index(s) == batch_kernel_index(f) && s->geom.G == f->geom.G && s->lds_persist == f->lds_persist && s->Nn == f->Nn) pm.push_back(k);
+            }
+            if (pm.size() < 2 || getenv("TREEQP_AMD_BATCH_LAUNCHES")) pm.clear();      /* (=1: one launch per tree, the round-1 protocol) */
+        }
+        unsigned pseq = 0;
+        if (!pm.empty()) {
+            unsigned mx = 0;
+            for (int k : pm) mx = std::max(mx, solvers[k]->launch_no);
+            unsigned nn = mx + 1;
+            if (nn > 0xFFFFu) {          /* the 16-bit launch number wraps: see launch_persist */
+                for (int k : pm) HIP_TRY(hipMemsetAsync(solvers[k]->sync_slab, 0, solvers[k]->sync_bytes, solvers[k]->stream));
+                nn = 1;
+            }
+            pseq = nn << 16;
+        }
+        size_t gi = 0, lds_batch = 0, pi = 0;
         for (int k = begun_from; k < begun_to; k++) {
             const bool in_group = lead && gi < gp_members.size() && gp_members[gi] == k;
+            if (pi < pm.size() && pm[pi] == k) { cx[(size_t)k].batch_seq = pseq; pi++; }
             int rc = solve_begin(solvers[k], o, cx[(size_t)k], in_group ? &lead->h_gitems[gi] : nullptr);
             if (rc != TQGPU_OK) { if (first_err == TQGPU_OK) { first_err = rc; first_msg = g_err; } break; }
             if (in_group) { gi++; lds_batch = std::max(lds_batch, solvers[k]->lds_gp_total); }
@@ -2491,11 +2560,47 @@ extern "C" int tqgpu_solve_batch(tqgpu_solver **solvers, int n, const tqgpu_opts
             HIP_TRY(hipEventRecord(lead->batch_ev, st0));
             for (size_t m = 1; m < gi; m++) HIP_TRY(hipStreamWaitEvent(solvers[gp_members[m]]->stream, lead->batch_ev, 0));
         }
+        if (!pm.empty() && ok_to == begun_to) {
+            tqgpu_solver *pl = solvers[pm[0]];
+            const size_t np = pm.size();
+            if (pl->pitems_cap < (int)np) {
+                if (pl->d_pitems) (void)hipFree(pl->d_pitems);
+                if (pl->h_pitems) (void)hipHostFree(pl->h_pitems);
+                pl->d_pitems = nullptr; pl->h_pitems = nullptr; pl->pitems_cap = 0; pl->pitems_key.clear();
+                const size_t cap = np * 2;
+                if (hipMalloc(&pl->d_pitems, cap * sizeof(PItem)) != hipSuccess || hipHostMalloc((void **)&pl->h_pitems, cap * sizeof(PItem), hipHostMallocDefault) != hipSuccess)
+                    return fail(TQGPU_ENOMEM, "allocation of the batch descriptors failed");
+                pl->pitems_cap = (int)cap;
+            }
+            std::vector<unsigned long> key;
+            for (int k : pm) key.push_back(solvers[k]->uid);
+            hipStream_t st0 = pl->stream;
+            if (key != pl->pitems_key) {
+                /* the descriptors are what the single launches pass as kernel arguments; they do not change from solve to solve, so
+                 * the device copy is refreshed only when the batch is composed of other mirrors than last time */
+                HIP_TRY(hipStreamSynchronize(st0));                 /* a previous batch launch may still read the array */
+                for (size_t m = 0; m < np; m++) { const tqgpu_solver *sm = solvers[pm[m]]; pl->h_pitems[m].C = sm->pconst; pl->h_pitems[m].Gm = sm->geom; pl->h_pitems[m].Sy = sm->psync; }
+                HIP_TRY(hipMemcpyAsync(pl->d_pitems, pl->h_pitems, np * sizeof(PItem), hipMemcpyHostToDevice, st0));
+                pl->pitems_key = key;
+            }
+            /* what the other members enqueued on their own streams since their last synchronisation (asynchronous uploads, constant
+             * packing: first solves and changed data only) comes before the launch.  No per-member event traffic in the steady state:
+             * a pair of calls per member and step was most of a step with 22 small trees. */
+            for (size_t m = 1; m < np; m++) {
+                tqgpu_solver *sm = solvers[pm[m]];
+                if (sm->stream_pending) { HIP_TRY(hipStreamSynchronize(sm->stream)); sm->stream_pending = false; }
+            }
+            int rcb = launch_persist_batch(pl, batch_kernel_index(pl), pl->d_pitems, cx[(size_t)pm[0]].O, (int)np, pseq);
+            if (rcb != TQGPU_OK) return rcb;
+        }
         for (int k = begun_from; k < ok_to; k++) {
             int rc = solve_end(solvers[k], o, cx[(size_t)k], &results[k]);
             if (rc == TQGPU_ETIMEOUT) rc = solve_after_timeout(solvers[k], o, &results[k]);     /* device shared: redone on its own, see tqgpu_solve */
             if (rc != TQGPU_OK && first_err == TQGPU_OK) { first_err = rc; first_msg = g_err; }
         }
+        /* the members' later work (solution export, the next solve) runs on their own streams: it has to find the batch launch
+         * complete -- every verdict is in, so this waits for the write-back of the last workgroups only, once per batch */
+        if (!pm.empty() && ok_to == begun_to) HIP_TRY(hipStreamSynchronize(solvers[pm[0]]->stream));
         if (first_err != TQGPU_OK) break;
         i = j;
     }

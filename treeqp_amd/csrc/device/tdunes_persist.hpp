@@ -1504,10 +1504,10 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
 #ifndef TQ_WPS
 #define TQ_WPS 2
 #endif
+/* the workgroup `b` (position in the launch's own numbering) of one tree: finds its tier and role and runs its life */
 template <int NX, int NU, int MD, bool RU>
-__global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_persist(PConst C, Opts O, PGeom Gm, PSync Sy, int prologue) {
-    extern __shared__ __attribute__((aligned(16))) double lds_all[];
-    const int wg = Gm.wg_of_block[blockIdx.x];
+__device__ __forceinline__ void persist_entry(const PConst &C, const Opts &O, const PGeom &Gm, const PSync &Sy, int prologue, int b, double *lds_all) {
+    const int wg = Gm.wg_of_block[b];
     int tier = 0;
     for (int i = 0; i < Gm.n_tiers; i++) if (wg >= Gm.wg0[i]) tier = i;
     /* one instantiation of the pass loop per ROLE: each carries only its own branches and live state (the common one was at the
@@ -1515,17 +1515,17 @@ __global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_persist(PConst C, Opts O,
      * always have Uni::TH levels. */
     if (!RU && Gm.n_tiers > 1) {
         if (tier == 0) p_run<NX, NU, MD, RU, 1, true>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
-        else if (tier == Gm.n_tiers - 1) {
-#ifdef TQ_TOP_FULLTH
-            if (Gm.l1[tier] - Gm.l0[tier] == Uni<NX, NU, MD>::TH) p_run<NX, NU, MD, RU, 3, true>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
-            else
-#endif
-            p_run<NX, NU, MD, RU, 3>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
-        }
+        else if (tier == Gm.n_tiers - 1) p_run<NX, NU, MD, RU, 3>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
         else p_run<NX, NU, MD, RU, 2, true>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
         return;
     }
     p_run<NX, NU, MD, RU>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
+}
+
+template <int NX, int NU, int MD, bool RU>
+__global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_persist(PConst C, Opts O, PGeom Gm, PSync Sy, int prologue) {
+    extern __shared__ __attribute__((aligned(16))) double lds_all[];
+    persist_entry<NX, NU, MD, RU>(C, O, Gm, Sy, prologue, (int)blockIdx.x, lds_all);
 }
 
 /* multistage trees (branching for Nr stages, then one child per node -- the reference's setup_multistage_tree
@@ -1534,12 +1534,11 @@ __global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_persist(PConst C, Opts O,
  * chain workgroup spreads G + H and the stage sweep over its four waves; its backward / forward sweeps are one
  * wave walking down the chain, which is what a chain is. */
 template <int NX, int NU, int MD, bool RU>
-__global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_mpersist(PConst C, Opts O, PGeom Gm, PSync Sy, int prologue) {
-    extern __shared__ __attribute__((aligned(16))) double lds_all[];
-    const int wg = Gm.wg_of_block[blockIdx.x];
+__device__ __forceinline__ void mpersist_entry(const PConst &C, const Opts &O, const PGeom &Gm, const PSync &Sy, int prologue, int b, double *lds_all) {
+    const int wg = Gm.wg_of_block[b];
     int tier = 0;
     for (int i = 0; i < Gm.n_tiers; i++) if (wg >= Gm.wg0[i]) tier = i;
-    if (!RU) {             /* per role as in f_persist; a multistage tree has two tiers or more (chains below the branching part) */
+    if (!RU) {             /* per role as in persist_entry; a multistage tree has two tiers or more (chains below the branching part) */
         if (Gm.chain[tier]) {
             if (tier == 0) p_run<NX, NU, 1, RU, 1>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
             else p_run<NX, NU, 1, RU, 2>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
@@ -1549,6 +1548,31 @@ __global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_mpersist(PConst C, Opts O
     }
     if (Gm.chain[tier]) p_run<NX, NU, 1, RU>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
     else p_run<NX, NU, MD, RU>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
+}
+
+template <int NX, int NU, int MD, bool RU>
+__global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_mpersist(PConst C, Opts O, PGeom Gm, PSync Sy, int prologue) {
+    extern __shared__ __attribute__((aligned(16))) double lds_all[];
+    mpersist_entry<NX, NU, MD, RU>(C, O, Gm, Sy, prologue, (int)blockIdx.x, lds_all);
+}
+
+/* A BATCH of independent trees of one shape as ONE launch (tqgpu_solve_batch): workgroups [t G, (t + 1) G) are tree t's, which
+ * works from its own descriptors (constants, geometry, hand-over buffers, result block) in device memory and never looks at
+ * another tree.  One launch per tree on a stream of its own only overlaps as many trees as the runtime has hardware queues
+ * (C1: 22 trees reached 3.4 x one tree); one launch carries them all.  Every tree of the launch takes the same launch number
+ * (its tags only have to be unique in the tree's own buffers).  Fresh solves only (prologue). */
+struct PItem { PConst C; PGeom Gm; PSync Sy; };
+template <int NX, int NU, int MD, bool MSTAGE>
+__global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_persist_batch(const PItem *items, Opts O, int G, unsigned seq) {
+    extern __shared__ __attribute__((aligned(16))) double lds_all[];
+    const int tree = (int)blockIdx.x / G, b = (int)blockIdx.x - tree * G;
+    const PItem *it = items + tree;
+    const PConst C = it->C;
+    const PGeom Gm = it->Gm;
+    PSync Sy = it->Sy;
+    Sy.seq = seq;
+    if (MSTAGE) mpersist_entry<NX, NU, MD, false>(C, O, Gm, Sy, 1, b, lds_all);
+    else persist_entry<NX, NU, MD, false>(C, O, Gm, Sy, 1, b, lds_all);
 }
 
 /* packed constants of the persistent path (run whenever the QP data changed): [A | B] per edge and
