@@ -368,3 +368,47 @@ def test_solve_n_is_n_solves(gpu):
     for k in ("x", "u", "lam", "mu_x", "mu_u"):
         assert np.array_equal(s1[k], sn[k])
     g.close()
+
+
+@pytest.mark.gpu
+def test_batch_of_one_shape_is_one_launch_and_survives_changes(gpu, orc):
+    """Trees of one shape with a batch kernel go out as ONE launch (f_persist_batch): bit-identical to single solves; a member whose
+    data changed between two batch calls (asynchronous upload on its own stream) is picked up; the batch may be composed of other
+    mirrors the next time (descriptor cache); more trees than one workgroup per CU (filled to the co-residency capacity)."""
+    def make(ub):
+        p = P.spring_mass()
+        nk = p.nk()
+        nx = np.full(p.Nn, p.nx, dtype=np.int32)
+        nu = np.where(nk > 0, p.nu, 0).astype(np.int32)
+        qp = gpu.TreeQp(nx, nu, nk).fill_lti(p)
+        f = qp.flat()
+        f["umin"] = np.full_like(f["umin"], -ub); f["umax"] = np.full_like(f["umax"], ub)
+        return p, f, (nk, nx, nu)
+    ubs = [0.5, 0.4, 0.3, 0.45, 0.35, 0.25]
+    built = [make(ub) for ub in ubs]
+    singles = []
+    for p, f, (nk, nx, nu) in built:
+        g = gpu.TqGpu(nk, nx, nu).upload(f, p.lambda0)
+        singles.append((g.solve(), g.solution()))
+        g.close()
+    ms = [gpu.TqGpu(nk, nx, nu).upload(f, p.lambda0) for p, f, (nk, nx, nu) in built]
+    assert all(m.path == 2 for m in ms)
+    def check(mirrors, refs):
+        res = gpu.solve_batch(mirrors)
+        for m, r, (r1, s1) in zip(mirrors, res, refs):
+            assert (r["status"], r["iter"], r["ls_total"]) == (r1["status"], r1["iter"], r1["ls_total"])
+            sol = m.solution()
+            for k in ("x", "u", "lam", "mu_x", "mu_u"):
+                assert np.array_equal(sol[k], s1[k])
+    check(ms, singles)
+    check(ms, singles)                                            # same composition: cached descriptors, next launch number
+    check(ms[1:4], singles[1:4])                                  # another composition
+    # member 2 gets member 5's bounds (asynchronous upload on its own stream), then the full batch again
+    p5, f5, _ = built[5]
+    ms[2].upload(f5, p5.lambda0)
+    check(ms, singles[:2] + [singles[5]] + singles[3:])
+    # 30 trees of 10 workgroups: more than one workgroup per CU on some CUs
+    many = [gpu.TqGpu(*built[i % 6][2]).upload(built[i % 6][1], built[i % 6][0].lambda0) for i in range(30)]
+    check(many, [singles[i % 6] for i in range(30)])
+    for m in ms + many:
+        m.close()
