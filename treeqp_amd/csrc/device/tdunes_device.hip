@@ -2437,10 +2437,10 @@ extern "C" int tqgpu_geometry(const tqgpu_solver *s, int *levels, int *tiers, in
 /* diagnostic: how often a persistent launch of this mirror timed out and the solve was redone on another path */
 extern "C" int tqgpu_timeouts(const tqgpu_solver *s) { return s ? s->n_timeouts : 0; }
 
-/* shapes with a batch kernel (f_persist_batch: one launch for a batch of trees of one shape); the BASELINE shapes -- any other
+/* shapes with a batch kernel (f_persist_batch: one launch for a batch of trees of one shape); the BASELINE shapes and a few neighbours -- any other
  * (nx, nu, md) of FAST_TABLE / MSTAGE_TABLE is one line away and costs its compile time; without a line the members of a batch
  * are launched one by one as before */
-#define BATCH_TABLE(X) X(0, 8, 3, 2, false) X(1, 4, 1, 3, true)
+#define BATCH_TABLE(X) X(0, 8, 3, 2, false) X(1, 4, 1, 3, true) X(2, 8, 3, 2, true) X(3, 4, 1, 2, false) X(4, 4, 1, 2, true) X(5, 8, 2, 2, false)
 static int batch_kernel_index(const tqgpu_solver *s) {
 #define X(idx, nx, nu, md, ms) if (s->fNX == nx && s->fNU == nu && s->fMD == md && s->mstage == ms) return idx;
     BATCH_TABLE(X)
