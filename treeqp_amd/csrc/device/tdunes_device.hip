@@ -577,6 +577,10 @@ __global__ void __launch_bounds__(WAVE) k_hess(Tree T, Data D, int h) {
 /* one lane per row:  rows 0..d-1 -> L,  row d -> (L^-1 resMod)',  rows d+1.. -> Ut L^-T.       */
 /* Root block (ii == 0): no Ut rows; followed by the backward solve L^-T.                       */
 /* ------------------------------------------------------------------------------------------ */
+/* (Tried in round 2 and dropped: the tall matrix in registers, row per lane with readlane broadcasts as in the persistent kernels,
+ * for R <= 64 and d <= 32: the factor phase of the single-workgroup kernel gained 6 %, the rest of that kernel lost more to the
+ * code it added -- a block step there is bound by its global round trips, not by this loop; batching the k loop eight LDS reads
+ * at a time: slower.) */
 __device__ __forceinline__ void tall_potrf(double *Tm, double *invd, int R, int d, int ld, int lane) {
     for (int j = 0; j < d; j++) {
         /* every row i >= j : s_i = T[i,j] - sum_{k<j} T[i,k] T[j,k] */
@@ -941,7 +945,7 @@ struct tqgpu_solver {
     int *d_lvl_first = nullptr;
     size_t lds_gp_wave = 0;         /* doubles of LDS per wave of g_persist */
     size_t lds_gp_total = 0;        /* bytes of dynamic LDS of g_persist (windows + state mirror) */
-    bool gp_in_lds = false, gp_const_in_lds = false;
+    bool gp_in_lds = false, gp_const_in_lds = false, gp_tab_in_lds = false, gp_small16 = false, gp_small8 = false;
     double *pab = nullptr, *pcst = nullptr;
     bool need_pack = true;          /* QP data changed since the constants were packed */
     /* writable aliases of the const inputs */
@@ -1827,6 +1831,16 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
         for (int l = 0; l <= s->Nh; l++) widest = std::max(widest, s->lvl_first[l + 1] - s->lvl_first[l]);
         const size_t per_wave = (std::max(std::max(s->lds_stage, s->lds_hess), std::max(s->lds_factor, s->lds_forward)) + 7) / 8 + 2;
         s->lds_gp_wave = per_wave;
+        {
+            /* four nodes per wave in the stage sweep: nx + nu <= 16 everywhere, clipping nodes only, and a quarter of the wave's window
+             * holds a node's duals (bdim + nx doubles) */
+            bool ok16 = !s->dense && !getenv("TREEQP_AMD_NO_STAGE16");
+            for (int k = 0; k < Nn && ok16; k++) ok16 = s->nx[k] + s->nu[k] <= 16 && (size_t)(s->bdim[k] + s->nx[k]) <= per_wave / 4;
+            s->gp_small16 = ok16;
+            bool ok8 = !getenv("TREEQP_AMD_NO_STAGE16");          /* eight nodes per wave in the gradient sweep: nx <= 8 everywhere */
+            for (int k = 0; k < Nn && ok8; k++) ok8 = s->nx[k] <= 8;
+            s->gp_small8 = ok8;
+        }
         s->gpersist_ok = widest <= 6 * GP_WAVES && per_wave * 8 * GP_WAVES <= 150 * 1024;
         /* LDS mirror of the mutable state (tdunes_gpersist.hpp): 16 node-sized vectors (rounded up to even), 4 block arrays */
         {
@@ -1839,11 +1853,15 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
             const size_t consts = (ev((size_t)s->sum_A) + ev((size_t)s->sum_B) + 5 * ev(sx) + 4 * ev(su)) * 8;
             s->gp_const_in_lds = s->gp_in_lds && s->lds_gp_total + consts <= 150 * 1024;
             if (s->gp_const_in_lds) s->lds_gp_total += consts;
-            if (!s->gp_in_lds) s->lds_gp_total = per_wave * GP_WAVES * 8;
+            if (!s->gp_in_lds) {
+                /* the state does not fit: the index tables alone, next to the per-wave windows, if THEY fit */
+                s->gp_tab_in_lds = s->gpersist_ok && (per_wave * GP_WAVES + tables + 8) * 8 <= 150 * 1024;
+                s->lds_gp_total = (per_wave * GP_WAVES + (s->gp_tab_in_lds ? tables + 8 : 0)) * 8;
+            }
             else if (s->lds_gp_total > 64 * 1024 &&
                      hipFuncSetAttribute(reinterpret_cast<const void *>(g_persist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_gp_total) != hipSuccess) {
                 (void)hipGetLastError();
-                s->gp_in_lds = false; s->lds_gp_total = per_wave * GP_WAVES * 8;
+                s->gp_in_lds = false; s->gp_tab_in_lds = false; s->lds_gp_total = per_wave * GP_WAVES * 8;
             }
             if (s->gpersist_ok && !s->gp_in_lds && s->lds_gp_total > 64 * 1024 &&
                 hipFuncSetAttribute(reinterpret_cast<const void *>(g_persist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_gp_total) != hipSuccess) {
@@ -2215,7 +2233,7 @@ int solve_begin(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, GItem *defer
             s->psync.seq = s->launch_no << 16;
             GParams gp;
             gp.lvl_first = s->d_lvl_first; gp.lam_init = s->d_lam_init; gp.hres = s->h_res; gp.seq = s->psync.seq; gp.lds_wave = (int)s->lds_gp_wave;
-            gp.in_lds = s->gp_in_lds ? 1 : 0; gp.sum_nx = s->sum_nx; gp.sum_nu = s->sum_nu; gp.sum_W = s->sum_W; gp.sum_Ut = s->sum_Ut;
+            gp.in_lds = s->gp_in_lds ? 1 : 0; gp.tab_in_lds = (!s->gp_in_lds && s->gp_tab_in_lds) ? 1 : 0; gp.small16 = s->gp_small16 ? 1 : 0; gp.small8 = s->gp_small8 ? 1 : 0; gp.sum_nx = s->sum_nx; gp.sum_nu = s->sum_nu; gp.sum_W = s->sum_W; gp.sum_Ut = s->sum_Ut;
             gp.const_in_lds = s->gp_const_in_lds ? 1 : 0; gp.sum_A = s->sum_A; gp.sum_B = s->sum_B;
             if (defer) { defer->T = T; defer->D = D; defer->G = gp; }           /* launched by the caller, together with the rest of its batch */
             else hipLaunchKernelGGL(g_persist, dim3(1), dim3(GP_WAVES * WAVE), s->lds_gp_total, st, T, D, O, gp);

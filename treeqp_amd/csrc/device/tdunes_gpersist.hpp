@@ -25,6 +25,9 @@ struct GParams {
     unsigned seq;                /* launch number (completion word of the result block) */
     int lds_wave;                /* doubles of LDS window per wave */
     int in_lds;                  /* 1: the mutable state of the solve is mirrored in LDS for the whole launch */
+    int small8;                  /* 1: every node has nx <= 8: the gradient sweep takes eight nodes per wave (grad_body8) */
+    int small16;                 /* 1: every node has nx + nu <= 16 and is a clipping node: the stage sweep takes four nodes per wave (stage_body16) */
+    int tab_in_lds;              /* 1 (in_lds == 0): at least the index tables are -- every node or block step starts with a chain of dependent look-ups */
     int const_in_lds;            /* 1: ... and so are the constants (A, B, b, weights, linear terms, bounds) */
     int sum_nx, sum_nu, sum_W, sum_Ut, sum_A, sum_B;
 };
@@ -34,6 +37,119 @@ struct GParams {
  * generic bodies address it through ordinary (generic address space) pointers, so pointing those at an LDS
  * mirror turns every dependent global round trip (~1 us each, several per block step) into an LDS access.
  * Constants (A, B, b, weights, bounds, index tables) stay in global memory: read-only, cached. */
+/* The stage sweep for SMALL nodes: four nodes per wave, one per row of 16 lanes (lane t of a row: entry t of [x | u] of its
+ * node), instead of one node per wave with 64 - (nx + nu) lanes idle.  A sweep over the nodes of a tree is then a quarter of the
+ * rounds -- and a line-search trial IS a sweep: the stragglers of a batch of C5-class trees (the launch ends with the slowest
+ * tree) are the trees with many trials (one with 95 trials spent 14 of its 18 ms in them).  Same arithmetic as stage_body's
+ * clipping branch; the sums of a node are taken over its row (row16_sum) instead of over the wave.  Needs nx + nu <= 16 for
+ * every node of the group, clipping nodes only; `win` doubles of the wave's LDS window per row. */
+__device__ void stage_body16(const Tree &T, const Data &D, int mode, int k0, int count, int lane, double *lds, int win, bool batch) {
+    const Ctrl *c = D.ctrl;
+    const int g = lane >> 4, t = lane & 15;
+    const bool act = g < count;
+    const int k = act ? k0 + g : k0;
+    const int nxk = T.nx[k], nuk = T.nu[k], xo = T.xoff[k], uo = T.uoff[k];
+    const int nkid = T.nk[k], d = T.bdim[k];
+    const double *lamc = c->cur ? D.lam1 : D.lam0;
+    double *lamn = c->cur ? D.lam0 : D.lam1;
+    const double step = c->tau - c->tauPrev;
+    const bool save_s = mode == 1 && c->ls_iter == 1;
+    double *lk = lds + (size_t)g * win;         /* d doubles */
+    double *lown = lk + d;                      /* nxk doubles */
+    const int kid0k = nkid > 0 ? T.kid0[k] : 0;
+    const int ko = nkid > 0 ? T.xoff[kid0k] : 0;
+    if (act) {
+        for (int tt = t; tt < d; tt += 16) {
+            double v = lamc[ko + tt];
+            if (mode == 1) v = fma(step, D.dlam[ko + tt], v);
+            lk[tt] = v;
+        }
+        for (int tt = t; tt < nxk; tt += 16) {
+            double v = 0.0;
+            if (k > 0) {
+                v = lamc[xo + tt];
+                if (mode == 1) { v = fma(step, D.dlam[xo + tt], v); lamn[xo + tt] = v; }
+            }
+            lown[tt] = v;
+        }
+    }
+    WSYNC();
+    double p_qx = 0.0, p_hx = 0.0, p_ru = 0.0, p_hu = 0.0, p_c = 0.0;
+    if (act && t < nxk + nuk) {
+        const bool isx = t < nxk;
+        const int j = isx ? t : t - nxk;
+        double v = isx ? fma(-1.0, D.q[xo + j], lown[j]) : -1.0 * D.r[uo + j];
+        int rowoff = 0;
+        for (int cc = 0; cc < nkid; cc++) {
+            const int kid = kid0k + cc, nxc = T.nx[kid];
+            const double *col = isx ? D.A + T.aoff[kid] + (size_t)j * nxc : D.B + T.boff[kid] + (size_t)j * nxc;
+            double acc = 0.0;
+            acc = dot_batched(col, 1, lk + rowoff, 1, nxc, acc, batch);
+            v = fma(-1.0, acc, v);
+            rowoff += nxc;
+        }
+        if (isx) {
+            D.qmod[xo + j] = v;
+            const double qi = D.Qinv[xo + j];
+            const double unc = qi * v, lo = D.xmin[xo + j], hi = D.xmax[xo + j];
+            double xv, cal;
+            if (unc >= hi) { xv = hi; cal = 0.0; } else if (unc <= lo) { xv = lo; cal = 0.0; } else { xv = unc; cal = qi; }
+            if (save_s) D.xUncS[xo + j] = D.xUnc[xo + j];
+            D.xUnc[xo + j] = unc; D.x[xo + j] = xv; D.QinvCal[xo + j] = cal;
+            p_qx = (D.Qd[xo + j] * xv) * xv;
+            p_hx = v * xv;
+        } else {
+            D.rmod[uo + j] = v;
+            const double ri = D.Rinv[uo + j];
+            const double unc = ri * v, lo = D.umin[uo + j], hi = D.umax[uo + j];
+            double uv, cal;
+            if (unc >= hi) { uv = hi; cal = 0.0; } else if (unc <= lo) { uv = lo; cal = 0.0; } else { uv = unc; cal = ri; }
+            if (save_s) D.uUncS[uo + j] = D.uUnc[uo + j];
+            D.uUnc[uo + j] = unc; D.u[uo + j] = uv; D.RinvCal[uo + j] = cal;
+            p_ru = (D.Rd[uo + j] * uv) * uv;
+            p_hu = v * uv;
+        }
+    }
+    if (act) for (int tt = t; tt < d; tt += 16) p_c = fma(D.b[ko + tt], lk[tt], p_c);
+    p_qx = row16_sum(p_qx); p_hx = row16_sum(p_hx); p_ru = row16_sum(p_ru); p_hu = row16_sum(p_hu); p_c = row16_sum(p_c);
+    if (act && t == 0) {
+        double f = -0.5 * p_qx - p_c;       /* clipping.c:375 */
+        f += p_hx;                          /* :376 */
+        f -= 0.5 * p_ru;                    /* :380 */
+        f += p_hu;                          /* :381 */
+        D.fval[k] = f;
+    }
+    WSYNC();
+}
+
+/* The gradient sweep for nodes with nx <= 8: eight nodes per wave, one per group of 8 lanes (grad_body keeps nx lanes of 64 busy).
+ * The node's termination partial is taken over its group: after row_ror 4, 2, 1 the LAST lane of a group holds the group's
+ * sum / maximum.  Same arithmetic and order of the sums per entry as grad_body. */
+__device__ void grad_body8(const Tree &T, const Data &D, int termCondition, int k0, int count, int lane, bool batch) {
+    const int g = lane >> 3, i = lane & 7;
+    const bool act = g < count;
+    const int k = act ? k0 + g : k0;
+    const int p = T.dad[k], nxk = T.nx[k], nxp = T.nx[p], nup = T.nu[p];
+    const int xo = T.xoff[k], xp = T.xoff[p], up = T.uoff[p];
+    const double *A = D.A + T.aoff[k], *B = D.B + T.boff[k];
+    double part = 0.0;
+    if (act && i < nxk) {
+        double rv = fma(-1.0, D.x[xo + i], D.b[xo + i]);
+        double acc = 0.0;
+        acc = dot_batched(A + i, nxk, D.x + xp, 1, nxp, acc, batch);
+        rv += acc;
+        acc = 0.0;
+        acc = dot_batched(B + i, nxk, D.u + up, 1, nup, acc, batch);
+        rv += acc;
+        D.res[xo + i] = rv;
+        D.resMod[xo + i] = rv;
+        part = (termCondition == 2) ? fabs(rv) : rv * rv;
+    }
+    if (termCondition == 2) { part = nanmax(part, dpp_mov<0x124>(part)); part = nanmax(part, dpp_mov<0x122>(part)); part = nanmax(part, dpp_mov<0x121>(part)); }
+    else { part += dpp_mov<0x124>(part); part += dpp_mov<0x122>(part); part += dpp_mov<0x121>(part); }
+    if (act && i == 7) D.part_err[k] = part;
+}
+
 __device__ __forceinline__ double *gp_take(double *&cursor, int n) { double *p = cursor; cursor += (n + 1) & ~1; return p; }
 
 /* The two descriptor structs hold ~60 pointers.  As kernel arguments (or locals) they would have to live in
@@ -50,6 +166,7 @@ __device__ __forceinline__ void g_persist_body(Tree T_in, Data D_in, Opts O, GPa
     Ctrl *c = D.ctrl;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double *lds = lds_all + (size_t)wave * G.lds_wave;
+    double *cur_tab = lds_all + (size_t)GP_WAVES * G.lds_wave;      /* where the LDS copy of the index tables goes (behind the state mirror, if there is one) */
     if (G.in_lds) {
         double *cur_p = lds_all + (size_t)GP_WAVES * G.lds_wave;
         const int sx = G.sum_nx, su = G.sum_nu, Nn_ = T.Nn;
@@ -72,9 +189,14 @@ __device__ __forceinline__ void g_persist_body(Tree T_in, Data D_in, Opts O, GPa
             for (int i = threadIdx.x; i < su; i += GP_WAVES * WAVE) { cRd[i] = D_in.Rd[i]; cr[i] = D_in.r[i]; cul[i] = D_in.umin[i]; cuu[i] = D_in.umax[i]; }
             D.A = cA; D.B = cB; D.b = cb; D.Qd = cQd; D.q = cq; D.xmin = cxl; D.xmax = cxu; D.Rd = cRd; D.r = cr; D.umin = cul; D.umax = cuu;
         }
-        /* the index tables too: every block step starts with a chain of dependent table look-ups */
-        int *ip = reinterpret_cast<int *>(cur_p);
-        const int n1 = Nn_ + 1;
+        cur_tab = cur_p;
+    }
+    if (G.in_lds || G.tab_in_lds) {
+        /* the index tables: every node or block step starts with a chain of dependent table look-ups -- from global memory that is
+         * a round trip per hop, whatever else the step reads.  (They fit next to the per-wave windows even when the state does not:
+         * the members of a batch of C5-class trees.) */
+        int *ip = reinterpret_cast<int *>(cur_tab);
+        const int Nn_ = T.Nn, n1 = Nn_ + 1;
         const int *src[13] = {T_in.dad, T_in.nk, T_in.kid0, T_in.nx, T_in.nu, T_in.xoff, T_in.uoff, T_in.aoff, T_in.boff, T_in.pos, T_in.bdim, T_in.woff, T_in.utoff};
         const int len[13] = {Nn_, Nn_, Nn_, Nn_, Nn_, n1, n1, n1, n1, Nn_, Nn_, n1, n1};
         int *dst[13];
@@ -106,7 +228,12 @@ __device__ __forceinline__ void g_persist_body(Tree T_in, Data D_in, Opts O, GPa
     __syncthreads();
 
     /* first sweep at lambda0 (phase S of iteration 0) and fval0 */
-    for (int k = wave; k < Nn; k += GP_WAVES) stage_body(sT, sD, 0, k, lane, lds, !G.const_in_lds);
+    const int win16 = G.lds_wave / 4;           /* LDS per row of 16 lanes in stage_body16 */
+    auto stage_sweep = [&](int mode) {
+        if (G.small16) { for (int k0 = 4 * wave; k0 < Nn; k0 += 4 * GP_WAVES) stage_body16(sT, sD, mode, k0, min(4, Nn - k0), lane, lds, win16, !G.const_in_lds); }
+        else for (int k = wave; k < Nn; k += GP_WAVES) stage_body(sT, sD, mode, k, lane, lds, !G.const_in_lds);
+    };
+    stage_sweep(0);
     __syncthreads();
     {
         const double f = block_reduce<false>(sD.fval, Nn, sh);
@@ -117,7 +244,8 @@ __device__ __forceinline__ void g_persist_body(Tree T_in, Data D_in, Opts O, GPa
 
     for (;;) {
         /* ---- G: dual gradient + termination test (dual_Newton_tree.c:519-543) ---- */
-        for (int k = 1 + wave; k < Nn; k += GP_WAVES) grad_body(sT, sD, O.termCondition, k, lane, !G.const_in_lds);
+        if (G.small8) { for (int k0 = 1 + 8 * wave; k0 < Nn; k0 += 8 * GP_WAVES) grad_body8(sT, sD, O.termCondition, k0, min(8, Nn - k0), lane, !G.const_in_lds); }
+        else for (int k = 1 + wave; k < Nn; k += GP_WAVES) grad_body(sT, sD, O.termCondition, k, lane, !G.const_in_lds);
         __syncthreads();
         {
             double err = (O.termCondition == 2) ? block_reduce<true>(sD.part_err + 1, Nn - 1, sh) : block_reduce<false>(sD.part_err + 1, Nn - 1, sh);
@@ -166,7 +294,7 @@ __device__ __forceinline__ void g_persist_body(Tree T_in, Data D_in, Opts O, GPa
         __syncthreads();
         if (flag) break;
         for (;;) {
-            for (int k = wave; k < Nn; k += GP_WAVES) stage_body(sT, sD, 1, k, lane, lds, !G.const_in_lds);
+            stage_sweep(1);
             __syncthreads();
             const double f = block_reduce<false>(sD.fval, Nn, sh);
             if (threadIdx.x == 0) { ls_decide_tail(c, sD, O, f); flag = c->ls_pending; }
