@@ -452,6 +452,60 @@ __global__ void __launch_bounds__(256) k_fval_init(Tree T, Data D) {
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* The small reductions as the TAIL of the sweep that produces their input (trees of <= FUSE_MAX nodes).  A reduction kernel of
+ * its own (k_check, k_fval_init, k_ls_begin, k_ls_decide) is a launch of one workgroup: ~5 us for a few hundred additions, and a
+ * single tree of a few hundred nodes is bound by its launch count.  Instead every workgroup of the sweep posts its partial as a
+ * tagged word and counts itself off; the workgroup that finds it is the last takes the reduction -- in the order block_reduce
+ * takes it with 256 threads, so the result is bit-identical to the separate kernel's -- and the decision.  (The partials
+ * travel as tagged words and are polled, so nothing depends on the order in which plain stores of other XCDs become visible.) */
+#define FUSE_MAX 512
+struct Fuse { u64 *red; int *cnt; unsigned tag; int on; };
+
+__device__ __forceinline__ bool fuse_last(const Fuse &F, int total, int lane) {
+    int old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add(F.cnt, 1, RLX, AGENT);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old == total - 1 && lane == 0) __hip_atomic_store(F.cnt, 0, RLX, AGENT);      /* the next launch counts from zero */
+    return old == total - 1;
+}
+/* sum / maximum of entries first .. first + n - 1 (n <= FUSE_MAX) of the tagged partials, by ONE wave, as block_reduce<IS_MAX> with
+ * 256 threads: lane l stands in for threads l, l + 64, l + 128, l + 192; `extra0` (with_extra) is entry 0 of the reduced vector,
+ * known to this wave already (the root's part_dot), the tagged words then hold entries 1 .. */
+template <bool IS_MAX>
+__device__ double fuse_reduce(const u64 *red, int first, int n, unsigned tag, int lane, bool with_extra = false, double extra0 = 0.0) {
+    double v[4][2];
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int w = 0; w < 4; w++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int i = w * WAVE + lane + 256 * j;                    /* index into the reduced vector */
+                const bool in = i < n;
+                bool okk = true;
+                double val = 0.0;
+                if (with_extra && i == 0) val = extra0;
+                else { val = ld_tag(red + (size_t)(first + (in ? i - (with_extra ? 1 : 0) : 0)) * 2, tag, okk); ok = ok && (okk || !in); }
+                v[w][j] = in ? val : 0.0;
+            }
+        if (__all(ok)) break;
+        if (wall_clock64() - t0 > 20000000ull) return __builtin_nan("");      /* 0.2 s: cannot happen (every workgroup posted before it counted itself off); a NaN ends the solve */
+        __builtin_amdgcn_s_sleep(2);
+    }
+    double r = 0.0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < 2; j++) { const int i = w * WAVE + lane + 256 * j; if (i < n) acc = IS_MAX ? nanmax(acc, v[w][j]) : acc + v[w][j]; }
+        acc = IS_MAX ? wave_max(acc) : wave_sum(acc);
+        r = IS_MAX ? nanmax(r, acc) : r + acc;
+    }
+    return r;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* k_grad: one wave per node k >= 1:  res_k = b_k - x_k + A_k x_dad + B_k u_dad                */
 /* ------------------------------------------------------------------------------------------ */
 __device__ void grad_body(const Tree &T, const Data &D, int termCondition, int k, int lane, bool batch = true) {
@@ -488,6 +542,22 @@ __global__ void __launch_bounds__(256) k_check(Tree T, Data D, Opts O, int h) {
     double err = (O.termCondition == 2) ? block_reduce<true>(D.part_err + 1, T.Nn - 1, sh)
                                         : block_reduce<false>(D.part_err + 1, T.Nn - 1, sh);
     if (threadIdx.x == 0) {
+        if (O.termCondition == 1) err = sqrt(err);
+        c->err = err;
+        if (err < O.tol) { c->done = 1; c->status = 0; }      /* TREEQP_OPTIMAL_SOLUTION_FOUND */
+    }
+}
+
+/* k_grad with k_check as its tail (small trees) */
+__global__ void __launch_bounds__(WAVE) k_grad_f(Tree T, Data D, Opts O, Fuse F, int h) {
+    Ctrl *c = D.ctrl;
+    if (!phase_main(c, h)) return;
+    const int k = blockIdx.x + 1, lane = threadIdx.x;
+    grad_body(T, D, O.termCondition, k, lane);
+    if (lane == 0) st_tag(F.red + (size_t)(k - 1) * 2, D.part_err[k], F.tag);
+    if (!fuse_last(F, T.Nn - 1, lane)) return;
+    double err = (O.termCondition == 2) ? fuse_reduce<true>(F.red, 0, T.Nn - 1, F.tag, lane) : fuse_reduce<false>(F.red, 0, T.Nn - 1, F.tag, lane);
+    if (lane == 0) {
         if (O.termCondition == 1) err = sqrt(err);
         c->err = err;
         if (err < O.tol) { c->done = 1; c->status = 0; }      /* TREEQP_OPTIMAL_SOLUTION_FOUND */
@@ -781,10 +851,24 @@ __global__ void __launch_bounds__(WAVE) k_forward(Tree T, Data D, int first, int
     forward_body(T, D, first + blockIdx.x, threadIdx.x, lds);
 }
 /* all levels below the root in one launch, blocks in BFS order: a block's parent was started before it */
-__global__ void __launch_bounds__(WAVE) k_forward_all(Tree T, Data D, u64 *fw, unsigned tag, int h) {
+/* the tail of a fused forward sweep (small trees): the direction test and the start of the line search (k_ls_begin) */
+__device__ __forceinline__ void fuse_ls_begin(const Tree &T, const Data &D, const Fuse &F, int ii, int lane) {
+    if (lane == 0) st_tag(F.red + (size_t)(ii - 1) * 2, D.part_dot[ii], F.tag);
+    if (!fuse_last(F, T.Np - 1, lane)) return;
+    const double s = fuse_reduce<false>(F.red, 0, T.Np, F.tag, lane, true, D.part_dot[0]);      /* entry 0: the root's, from k_factor */
+    if (lane == 0) {
+        Ctrl *c = D.ctrl;
+        const double dotp = -s;                                     /* :819 */
+        c->dot = dotp;
+        if (dotp > 1e-10 || !((dotp > 1e-10) || (dotp < 1e-10))) { c->done = 1; c->status = 2; }      /* :951, NaN included */
+        else { c->tau = 1.0; c->tauPrev = 0.0; c->ls_iter = 1; c->ls_pending = 1; }
+    }
+}
+__global__ void __launch_bounds__(WAVE) k_forward_all(Tree T, Data D, u64 *fw, unsigned tag, int h, Fuse F) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     if (!phase_main(D.ctrl, h)) return;
     forward_body(T, D, 1 + (int)blockIdx.x, threadIdx.x, lds, fw, tag);
+    if (F.on) fuse_ls_begin(T, D, F, 1 + (int)blockIdx.x, threadIdx.x);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -857,6 +941,22 @@ __global__ void __launch_bounds__(256) k_ls_decide(Tree T, Data D, Opts O, int h
     if (threadIdx.x == 0) ls_decide_tail(c, D, O, f);
 }
 
+/* k_stage with k_fval_init (mode 0) or k_ls_decide (mode 1) as its tail (small trees) */
+__global__ void __launch_bounds__(WAVE) k_stage_f(Tree T, Data D, Opts O, Fuse F, int mode, int h, int t) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    Ctrl *c = D.ctrl;
+    if (mode == 1 && !phase_trial(c, h, t)) return;
+    const int k = blockIdx.x, lane = threadIdx.x;
+    stage_body(T, D, mode, k, lane, lds);
+    if (lane == 0) st_tag(F.red + (size_t)k * 2, D.fval[k], F.tag);
+    if (!fuse_last(F, T.Nn, lane)) return;
+    const double f = fuse_reduce<false>(F.red, 0, T.Nn, F.tag, lane);
+    if (lane == 0) {
+        if (mode == 0) { c->fval0 = f; c->fval = f; }
+        else ls_decide_tail(c, D, O, f);
+    }
+}
+
 /* ---- sharded mode (one tree over several devices): rank-local partials and the decision from the
  * gathered per-rank records; sums run in rank order so that every rank takes the same decision ---- */
 __global__ void __launch_bounds__(256) k_shard_pack1(Data D, int nlocal, double *xerr, int rank, int termCondition, int h) {
@@ -924,6 +1024,10 @@ struct tqgpu_solver {
     int sch_rs = 0;                     /* doubles per record: (max nx + 1)^2 */
     unsigned bw_epoch = 0;
     bool bw_fused = true;               /* TREEQP_AMD_BWD=levels: one launch per level instead */
+    unsigned long long *fuse_red = nullptr;   /* small trees: partials of the reductions that run as the tail of a sweep (Fuse), [Nn][2] tagged words */
+    int *fuse_cnt = nullptr;            /* ... and the counter of the workgroups that have posted theirs */
+    unsigned fuse_epoch = 0;
+    bool fuse_ok = false, fuse_now = false;       /* fuse_now: this solve uses them (not while phases are timed one by one) */
     bool dense = false, need_dense_init = false;   /* dense unconstrained stage solver selected (generic path only) */
     double *d_Hd = nullptr;      /* writable alias of Data.Hd */
     int *d_kind = nullptr;       /* writable alias of Data.kind */
@@ -970,6 +1074,7 @@ struct tqgpu_solver {
     double first_sweep_time = NAN;        /* phase S of iteration 0 (the later ones are the accepted trial sweeps of the line searches) */
     hipEvent_t sweep_ev0 = nullptr, sweep_ev1 = nullptr;
     int last_iter = 0;
+    int last_ls_extra = 0;          /* the previous solve needed line-search trials beyond the first of an iteration */
     bool need_init = true;
     /* fused path for uniform complete trees */
     int fast = -1;            /* index into the instantiation table, -1: generic path only */
@@ -1381,6 +1486,15 @@ int launch_fast_iteration(tqgpu_solver *s, const Opts &O, int h, int &launches) 
 }
 
 /* one more line-search trial of iteration `it`; phase 0: sweep (+ pack), phase 1: decide */
+static Fuse next_fuse(tqgpu_solver *s) {
+    Fuse F; F.red = s->fuse_red; F.cnt = s->fuse_cnt; F.on = 1;
+    s->fuse_epoch++;
+    if (s->fuse_epoch == 0) s->fuse_epoch = 1;
+    F.tag = s->fuse_epoch;
+    return F;
+}
+static Fuse no_fuse() { Fuse F; F.red = nullptr; F.cnt = nullptr; F.tag = 0; F.on = 0; return F; }
+
 void launch_trial_phase(tqgpu_solver *s, const Opts &O, bool fast, int it, int t, int phase, int &launches) {
     const Tree &T = s->T; const Data &D = s->D; hipStream_t st = s->stream;
     const bool sharded = s->sharded;
@@ -1395,13 +1509,15 @@ void launch_trial_phase(tqgpu_solver *s, const Opts &O, bool fast, int it, int t
                 default: break;
             }
         }
-        if (!done) hipLaunchKernelGGL(k_stage, dim3(T.Nn), dim3(WAVE), s->lds_stage, st, T, D, 1, it, t);
+        if (!done) {
+            if (s->fuse_now && !sharded) hipLaunchKernelGGL(k_stage_f, dim3(T.Nn), dim3(WAVE), s->lds_stage, st, T, D, O, next_fuse(s), 1, it, t);      /* with k_ls_decide as its tail */
+            else hipLaunchKernelGGL(k_stage, dim3(T.Nn), dim3(WAVE), s->lds_stage, st, T, D, 1, it, t);
+        }
         launches++;
         if (sharded) { hipLaunchKernelGGL(k_shard_pack2, dim3(1), dim3(WAVE), 0, st, D, s->d_node_cnt_list, s->n_nodes_counted, s->d_blk_list, s->n_blk_counted, s->d_xs, s->rank, s->bnd_b0, s->bnd_bn, s->bnd_own0, s->bnd_ownn, it, t); launches++; }
     } else {
-        if (sharded) hipLaunchKernelGGL(k_ls_decide_parts, dim3(1), dim3(WAVE), 0, st, D, O, s->d_xs, s->nranks, it, t, 0);
-        else hipLaunchKernelGGL(k_ls_decide, dim3(1), dim3(256), 0, st, T, D, O, it, t, 0);
-        launches++;
+        if (sharded) { hipLaunchKernelGGL(k_ls_decide_parts, dim3(1), dim3(WAVE), 0, st, D, O, s->d_xs, s->nranks, it, t, 0); launches++; }
+        else if (!(s->fuse_now && !fast)) { hipLaunchKernelGGL(k_ls_decide, dim3(1), dim3(256), 0, st, T, D, O, it, t, 0); launches++; }
     }
 }
 
@@ -1590,11 +1706,15 @@ void launch_generic_iteration(tqgpu_solver *s, const Opts &O, int h, int &launch
     auto mark = [&](int i) { if (phases && (size_t)(4 * h + i) < s->phase_ev.size()) (void)hipEventRecord(s->phase_ev[(size_t)(4 * h + i)], st); };
     mark(0);
     if (parts & 1) {
-        hipLaunchKernelGGL(k_grad, dim3(T.Nn - 1), dim3(WAVE), 0, st, T, D, O.termCondition, h); launches++;
-        hipLaunchKernelGGL(k_check, dim3(1), dim3(256), 0, st, T, D, O, h); launches++;
+        if (s->fuse_now) { hipLaunchKernelGGL(k_grad_f, dim3(T.Nn - 1), dim3(WAVE), 0, st, T, D, O, next_fuse(s), h); launches++; }      /* with k_check as its tail */
+        else {
+            hipLaunchKernelGGL(k_grad, dim3(T.Nn - 1), dim3(WAVE), 0, st, T, D, O.termCondition, h); launches++;
+            hipLaunchKernelGGL(k_check, dim3(1), dim3(256), 0, st, T, D, O, h); launches++;
+        }
     }
     if (!(parts & 2)) return;
     const bool wide = s->wide && !s->dense;
+    bool ls_begun = false;           /* the forward sweep's last workgroup has done k_ls_begin's work */
     if (wide) hipLaunchKernelGGL(k_hess_w, dim3(T.Np), dim3(WT), s->lds_hess_w, st, T, D, h);
     else hipLaunchKernelGGL(k_hess, dim3(T.Np), dim3(WAVE), s->lds_hess, st, T, D, h);
     launches++;
@@ -1618,8 +1738,10 @@ void launch_generic_iteration(tqgpu_solver *s, const Opts &O, int h, int &launch
         if (T.Np > 1) {
             s->fw_epoch++;
             if (s->fw_epoch == 0) s->fw_epoch = 1;
-            if (wide) hipLaunchKernelGGL(k_forward_all_w, dim3(T.Np - 1), dim3(WT), s->lds_forward_w, st, T, D, s->fw_words, s->fw_epoch, h);
-            else hipLaunchKernelGGL(k_forward_all, dim3(T.Np - 1), dim3(WAVE), s->lds_forward, st, T, D, s->fw_words, s->fw_epoch, h);
+            const Fuse F = s->fuse_now ? next_fuse(s) : no_fuse();          /* with k_ls_begin as its tail */
+            ls_begun = s->fuse_now;
+            if (wide) hipLaunchKernelGGL(k_forward_all_w, dim3(T.Np - 1), dim3(WT), s->lds_forward_w, st, T, D, s->fw_words, s->fw_epoch, h, F);
+            else hipLaunchKernelGGL(k_forward_all, dim3(T.Np - 1), dim3(WAVE), s->lds_forward, st, T, D, s->fw_words, s->fw_epoch, h, F);
             launches++;
         }
     } else
@@ -1630,9 +1752,12 @@ void launch_generic_iteration(tqgpu_solver *s, const Opts &O, int h, int &launch
         launches++;
     }
     mark(2);
-    hipLaunchKernelGGL(k_ls_begin, dim3(1), dim3(256), 0, st, T, D, h); launches++;
-    hipLaunchKernelGGL(k_stage, dim3(T.Nn), dim3(WAVE), s->lds_stage, st, T, D, 1, h, 1); launches++;
-    hipLaunchKernelGGL(k_ls_decide, dim3(1), dim3(256), 0, st, T, D, O, h, 1, 0); launches++;
+    if (!ls_begun) { hipLaunchKernelGGL(k_ls_begin, dim3(1), dim3(256), 0, st, T, D, h); launches++; }
+    if (s->fuse_now) { hipLaunchKernelGGL(k_stage_f, dim3(T.Nn), dim3(WAVE), s->lds_stage, st, T, D, O, next_fuse(s), 1, h, 1); launches++; }      /* with k_ls_decide as its tail */
+    else {
+        hipLaunchKernelGGL(k_stage, dim3(T.Nn), dim3(WAVE), s->lds_stage, st, T, D, 1, h, 1); launches++;
+        hipLaunchKernelGGL(k_ls_decide, dim3(1), dim3(256), 0, st, T, D, O, h, 1, 0); launches++;
+    }
     mark(3);
 }
 
@@ -1799,7 +1924,7 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
 
     if ((rc = allow_lds(k_stage, s->lds_stage)) || (rc = allow_lds(k_hess, s->lds_hess)) ||
         (rc = allow_lds(k_factor, s->lds_factor)) || (rc = allow_lds(k_forward, s->lds_forward)) ||
-        (rc = allow_lds(k_factor_all, s->lds_factor)) || (rc = allow_lds(k_forward_all, s->lds_forward)))
+        (rc = allow_lds(k_factor_all, s->lds_factor)) || (rc = allow_lds(k_forward_all, s->lds_forward)) || (rc = allow_lds(k_stage_f, s->lds_stage)))
         return cleanup_fail(rc);
     if (s->wide && ((rc = allow_lds(k_hess_w, s->lds_hess_w)) || (rc = allow_lds(k_factor_w, s->lds_factor_w)) || (rc = allow_lds(k_forward_w, s->lds_forward_w)) || (rc = allow_lds(k_forward_all_w, s->lds_forward_w)) || (rc = allow_lds(k_factor_all_w, s->lds_factor_w))))
         return cleanup_fail(rc);
@@ -1822,6 +1947,13 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
             return cleanup_fail(fail(TQGPU_ENOMEM, "hipMalloc failed for the Schur hand-over words"));
         m = getenv("TREEQP_AMD_BWD");
         s->bw_fused = !(m && strcmp(m, "levels") == 0);
+        if (s->Nn <= FUSE_MAX && s->Nn >= 2 && !getenv("TREEQP_AMD_NO_FUSE")) {
+            const size_t rb = sizeof(unsigned long long) * 2 * (size_t)s->Nn;
+            if (hipMalloc(&s->fuse_red, rb) != hipSuccess || hipMemset(s->fuse_red, 0, rb) != hipSuccess ||
+                hipMalloc(&s->fuse_cnt, 4 * sizeof(int)) != hipSuccess || hipMemset(s->fuse_cnt, 0, 4 * sizeof(int)) != hipSuccess)
+                return cleanup_fail(fail(TQGPU_ENOMEM, "hipMalloc failed for the fused reductions"));
+            s->fuse_ok = true;
+        }
     }
     if ((rc = setup_persist(s, device))) return cleanup_fail(rc);
     {
@@ -1899,6 +2031,8 @@ extern "C" void tqgpu_destroy(tqgpu_solver *s) {
     if (s->d_desc) (void)hipFree(s->d_desc);
     if (s->d_pitems) (void)hipFree(s->d_pitems);
     if (s->h_pitems) (void)hipHostFree(s->h_pitems);
+    if (s->fuse_red) (void)hipFree(s->fuse_red);
+    if (s->fuse_cnt) (void)hipFree(s->fuse_cnt);
     if (s->fw_words) (void)hipFree(s->fw_words);
     if (s->sch_words) (void)hipFree(s->sch_words);
     if (s->d_gitems) (void)hipFree(s->d_gitems);
@@ -2219,8 +2353,12 @@ int solve_begin(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, GItem *defer
         HIP_TRY(hipMemcpyAsync(D.lam0, s->d_lam_init, sizeof(double) * (size_t)s->sum_nx, hipMemcpyDeviceToDevice, st));
         /* first sweep at lambda0 (phase S of iteration 0 + fval0); the persistent launch does it as its prologue */
         if (cx.phases) HIP_TRY(hipEventRecord(s->sweep_ev0, st));
-        hipLaunchKernelGGL(k_stage, dim3(T.Nn), dim3(WAVE), s->lds_stage, st, T, D, 0, 0, 0); cx.launches++;
-        hipLaunchKernelGGL(k_fval_init, dim3(1), dim3(256), 0, st, T, D); cx.launches++;
+        s->fuse_now = s->fuse_ok && !cx.phases && !cx.fast && !s->sharded;
+        if (s->fuse_now) { hipLaunchKernelGGL(k_stage_f, dim3(T.Nn), dim3(WAVE), s->lds_stage, st, T, D, cx.O, next_fuse(s), 0, 0, 0); cx.launches++; }      /* with k_fval_init as its tail */
+        else {
+            hipLaunchKernelGGL(k_stage, dim3(T.Nn), dim3(WAVE), s->lds_stage, st, T, D, 0, 0, 0); cx.launches++;
+            hipLaunchKernelGGL(k_fval_init, dim3(1), dim3(256), 0, st, T, D); cx.launches++;
+        }
         if (cx.phases) HIP_TRY(hipEventRecord(s->sweep_ev1, st));
     } else {
 #ifdef TQ_HOSTPROF
@@ -2267,6 +2405,11 @@ int solve_end(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, tqgpu_result *
     if (o->profile) HIP_TRY(hipEventRecord(s->iter_ev[0], st));
     int chunk = s->last_iter > 0 ? std::min(s->last_iter + 1, 16) : s->chunk;
     bool predicted = s->last_iter > 0 && !fast && !persist;     /* the chunk is a prediction: its last iteration should only find convergence */
+    /* a line search that wants a second trial turns everything enqueued behind it into no-ops (~3 us a launch): a problem that
+     * backtracked last time is fed two iterations at a time (TREEQP_AMD_LS_CHUNK; one C5-class tree: 1.15 ms with chunks of 8, 1.04 / 1.01 / 1.06 ms with 4 / 2 / 1),
+     * a read-back per chunk instead */
+    static const int ls_chunk = getenv("TREEQP_AMD_LS_CHUNK") ? std::max(1, atoi(getenv("TREEQP_AMD_LS_CHUNK"))) : 2;
+    if (s->last_ls_extra && !fast && !persist && chunk > ls_chunk) { chunk = ls_chunk; predicted = false; }
     if (cx.phases) { chunk = 1; predicted = false; }            /* phase timing: one iteration per read-back, so that every recorded event belongs to work that ran */
     int rest_due = -1;                                          /* iteration whose termination test ran, whose step did not */
     while (!finished) {
@@ -2301,12 +2444,19 @@ int solve_end(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, tqgpu_result *
 #endif
         tail_done = persist;
         bool extra_trials = false;
+        /* trials beyond the first go out in batches: 3, then 6, 12, 16, .. per read-back of the control block.  A trial that is
+         * accepted turns the rest of its batch into no-ops (~6 us each), so short searches -- the usual case: one or two more
+         * trials -- want small batches (one C5-class tree: 1.09 ms with batches of 8, 0.99 ms with 3), long ones few read-backs. */
+        static const int trial_batch0 = getenv("TREEQP_AMD_TRIAL_BATCH") ? std::max(1, atoi(getenv("TREEQP_AMD_TRIAL_BATCH"))) : 3;
+        int trial_batch = trial_batch0, ls_of = -1;
         while (!s->h_ctrl->done && s->h_ctrl->ls_pending) {
             tail_done = false;
             extra_trials = true;
-            /* the line search of iteration `iter` wants more trials (rare): a batch of them */
+            /* the line search of iteration `iter` wants more trials: a batch of them */
             const int it = s->h_ctrl->iter, t0 = s->h_ctrl->ls_iter;
-            for (int t = t0; t < t0 + 8 && t <= O.lsMaxIter; t++) { int rcx = launch_trial(s, O, fast, it, t, launches); if (rcx != TQGPU_OK) return rcx; }
+            if (it != ls_of) { ls_of = it; trial_batch = trial_batch0; }
+            for (int t = t0; t < t0 + trial_batch && t <= O.lsMaxIter; t++) { int rcx = launch_trial(s, O, fast, it, t, launches); if (rcx != TQGPU_OK) return rcx; }
+            trial_batch = std::min(2 * trial_batch, 16);
             if ((rc = read_ctrl(s)) != TQGPU_OK) return rc;
         }
         h = s->h_ctrl->iter;
@@ -2356,6 +2506,7 @@ int solve_end(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, tqgpu_result *
     res->status = c.status; res->iter = c.iter; res->ls_total = c.ls_total; res->ls_last = c.ls_last;
     res->n_launches = launches; res->device_time = 1e-3 * ms; res->last_error_norm = c.err; res->last_fval = c.fval;
     s->last_iter = c.iter;
+    s->last_ls_extra = c.ls_total > c.iter ? 1 : 0;
     return TQGPU_OK;
 }
 

@@ -484,7 +484,7 @@ __global__ void __launch_bounds__(WT) k_forward_w(Tree T, Data D, int first, int
  * and the hardware starts them in order, so a waiting workgroup's parent is always running or done: no deadlock whatever
  * part of the grid is resident.  Children of the root read the root's step from D.dlam (k_factor_w wrote it in an earlier
  * launch).  A wait that never ends (it cannot) gives up after 0.5 s and ends the solve with UNKNOWN_ERROR. */
-__global__ void __launch_bounds__(WT) k_forward_all_w(Tree T, Data D, u64 *fw, unsigned tag, int h) {
+__global__ void __launch_bounds__(WT) k_forward_all_w(Tree T, Data D, u64 *fw, unsigned tag, int h, Fuse F) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int ii = 1 + blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int e[12];
@@ -555,6 +555,7 @@ __global__ void __launch_bounds__(WT) k_forward_all_w(Tree T, Data D, u64 *fw, u
     }
     pd = wave_sum(pd);
     if (lane == 0) D.part_dot[ii] = pd;
+    if (F.on) fuse_ls_begin(T, D, F, ii, lane);          /* small trees: k_ls_begin as the tail of the sweep (wave 0 is the one left here) */
 }
 
 /* LDS a block of dimension d (tall matrix of R rows, nz parent columns) needs in the wide kernels */
