@@ -412,3 +412,27 @@ def test_batch_of_one_shape_is_one_launch_and_survives_changes(gpu, orc):
     check(many, [singles[i % 6] for i in range(30)])
     for m in ms + many:
         m.close()
+
+
+@pytest.mark.gpu
+def test_fused_sweeps_on_a_crowded_device(gpu, orc, monkeypatch):
+    """A sweep of all tree levels as ONE launch, blocks waiting for each other inside it, must not depend on how much of its grid is
+    resident: workgroups are started in dependency order, so whatever one waits for is running or done.  Here a foreign kernel holds
+    250 of the 256 compute units (a CU's whole LDS each) while a pruned tree is solved on the launch-per-phase path: same verdict,
+    same solution as on the free device, no in-kernel wait gives up (that would end the solve with UNKNOWN_ERROR)."""
+    L = gpu.lib()
+    monkeypatch.setenv("TREEQP_AMD_PATH", "generic")
+    f = P.pruned_chain_qp(seed=9)
+    ref = orc.solve(f.as_dict(), orc.default_opts(**f.opts), lambda0=f.lambda0)
+    g = gpu.TqGpu(f.nk, f.nx, f.nu).upload(f.as_dict(), f.lambda0)
+    assert g.path == 0
+    r0 = g.solve(**f.opts)
+    s0 = g.solution()
+    assert L.tqgpu_debug_occupy(-1, 250, 160, 400) == 0
+    r1 = g.solve(**f.opts)
+    s1 = g.solution()
+    assert L.tqgpu_debug_occupy_wait() == 0
+    assert (r1["status"], r1["iter"], r1["ls_total"]) == (r0["status"], r0["iter"], r0["ls_total"]) == (0, ref["iter"], ref["ls_total"])
+    for k in ("x", "u", "lam"):
+        assert np.array_equal(s0[k], s1[k])
+    g.close()
