@@ -1266,17 +1266,25 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
         int prep_next = nbt - 1;                          /* blocks >= prep_next + 1 have their forward step prepared (descending order) */
         if (verdict != 2) {
             double Tc[D];
+#ifdef TQ_CHAIN_BARRIERS
+            constexpr bool CHAIN = false;
+#else
+            /* a chain tier (MD == 1) has ONE block per level: wave 0 walks down the chain on its own -- no workgroup barrier between
+             * the levels (330 cycles of a ~2 400-cycle level) -- and the forward preparation of all its blocks is done by the four
+             * waves after the sweep (it is needed only when the parent's step arrives) */
+            constexpr bool CHAIN = MD == 1 && !RU;
+#endif
             for (int t = th - 1; t >= 0; t--) {
                 const int nb = U::width(t);
                 /* waves without a block on this level prepare the forward steps of the levels below (at most two each) */
                 const int idle = FW - nb, lo = U::first(t + 1);
-                if (wave >= nb && build) {
+                if (!CHAIN && wave >= nb && build) {
                     for (int r = 0; r < 2; r++) {
                         const int loc = prep_next - (r * idle + (wave - nb));
                         if (loc >= lo) p_prep_forward<NX, NU, MD>(L, loc, lane);
                     }
                 }
-                { const int avail = prep_next - lo + 1, take = avail < 2 * idle ? avail : 2 * idle; prep_next -= take > 0 ? take : 0; }
+                if (!CHAIN) { const int avail = prep_next - lo + 1, take = avail < 2 * idle ? avail : 2 * idle; prep_next -= take > 0 ? take : 0; }
                 if (RU && wave < nb && !build) {
                     const int loc = U::first(t) + wave;
                     const double pd = p_reuse_block<NX, NU, MD>(C, Sy, L, loc, p_slot_node<NX, NU, MD>(loc, l0, s, C), t, th, is_bottom, is_top && t == 0, tag_e, lane, L.wave);
@@ -1334,10 +1342,11 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
                         lds_fence();
                     }
                 }
-                lds_barrier();
+                if (CHAIN && t < th - 1) lds_fence(); else lds_barrier();
                 if (t == th - 1 && !is_bottom && *L.abort) { gone = true; break; }    /* a child never delivered: the launch is over, or the pass is dropped */
                 pstamp(C, O, e, tier, s, sl++);                           /* 3.. : one per backward level */
             }
+            if (CHAIN) lds_barrier();                                     /* the chain is factorised: the other waves may read it */
         }
         if (gone) { if (*L.abort == 2) { verdict = 2; gone = false; } else break; }
         pstamp(C, O, e, tier, s, sl++);                                   /* backward done */
