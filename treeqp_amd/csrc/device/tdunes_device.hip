@@ -1530,6 +1530,11 @@ int launch_trial(tqgpu_solver *s, const Opts &O, bool fast, int it, int t, int &
 
 
 /* persistent launch: geometry, sync words, co-residency test */
+/* poll naps by launch size (PollGuard::go_on) */
+static int nap_for_grid(int workgroups) {
+    static const int t1 = getenv("TREEQP_AMD_NAP_T1") ? atoi(getenv("TREEQP_AMD_NAP_T1")) : 128, t2 = getenv("TREEQP_AMD_NAP_T2") ? atoi(getenv("TREEQP_AMD_NAP_T2")) : 256;
+    return workgroups > t2 ? 2 : (workgroups > t1 ? 1 : 0);
+}
 int setup_persist(tqgpu_solver *s, int device) {
     s->persist_ok = false;
     if (s->fast < 0 || s->n_tiers > 8) return TQGPU_OK;
@@ -1605,6 +1610,10 @@ int setup_persist(tqgpu_solver *s, int device) {
     s->psync.bparts = s->psync.errs + n_errs + 32;
     s->psync.sgt = s->psync.bparts + n_bparts; s->psync.rfl = s->psync.sgt + n_sgt;
     s->psync.seq = 0; s->psync.trip = 0;
+    {
+        const char *e = getenv("TREEQP_AMD_NAP");
+        s->psync.nap = e ? atoi(e) : nap_for_grid(G.G);
+    }
     /* XCD-aware placement: the hardware deals workgroups round-robin over the 8 XCDs (workgroup b -> XCD b % 8)
      * and every XCD has its own L2.  A tier subtree talks to its parent and its children only, so whole
      * families go to one XCD: each subtree of the lowest tier with at most 8 subtrees picks an XCD, everything
@@ -2622,7 +2631,7 @@ static int launch_persist_batch(tqgpu_solver *lead, int kidx, const PItem *items
     switch (kidx) {
 #define X(idx, nx, nu, md, ms) case idx: { \
         if (lds_allowed[idx] < lead->lds_persist) { int rc = allow_lds(f_persist_batch<nx, nu, md, ms>, lead->lds_persist); if (rc != TQGPU_OK) return rc; lds_allowed[idx] = lead->lds_persist; } \
-        hipLaunchKernelGGL((f_persist_batch<nx, nu, md, ms>), dim3((unsigned)(G * n_trees)), dim3(FW * WAVE), lead->lds_persist, lead->stream, items, O, G, seq); break; }
+        hipLaunchKernelGGL((f_persist_batch<nx, nu, md, ms>), dim3((unsigned)(G * n_trees)), dim3(FW * WAVE), lead->lds_persist, lead->stream, items, O, G, seq, nap_for_grid(G)); break; }
         BATCH_TABLE(X)
 #undef X
         default: return fail(TQGPU_EINVAL, "no batch kernel for this shape");

@@ -107,6 +107,7 @@ struct PSync {
     unsigned *timeout;      /* sticky: a bounded spin gave up                                         */
     unsigned seq;           /* launch number << 16 (low 16 bits of the number are never 0)            */
     unsigned trip;          /* tag of the pass the workgroup is in (kernel-local copy only)           */
+    int nap;                /* how long a poll loop sleeps between two looks: 0 short (small launches), 1, 2 long (several hundred workgroups) */
 };
 
 /* Poll loops read the payload AND the two "launch is over" words in the same round trip (the loads are
@@ -126,6 +127,13 @@ struct PollGuard {
     __device__ __forceinline__ bool go_on(const PSync &Sy, u64 t0) const {
         if (h == Sy.seq || tmo || cm == Sy.trip) return false;
         if (wall_clock64() - t0 > 50000000ull) { __hip_atomic_store(Sy.timeout, 1u, RLX, AGENT); return false; }   /* 0.5 s at 100 MHz */
+        /* a nap between two looks: every look is 3 - 35 loads per lane that go to the memory side, and with a few hundred workgroups
+         * polling they are in each other's (and the producers') way -- C3 (293 workgroups): 153 us per solve without naps, 141 with
+         * 4 x 64 cycles, 137 with 16 x 64; a launch of 73 workgroups (C2) is best with 1 x 64 and 4 us slower with 16 x 64 (the nap
+         * is on the hand-over's critical path).  The host sets the length by the size of the launch. */
+        if (Sy.nap >= 2) __builtin_amdgcn_s_sleep(16);
+        else if (Sy.nap == 1) __builtin_amdgcn_s_sleep(4);
+        else __builtin_amdgcn_s_sleep(1);
         return true;
     }
 };
@@ -1572,7 +1580,7 @@ __global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_mpersist(PConst C, Opts O
  * (its tags only have to be unique in the tree's own buffers).  Fresh solves only (prologue). */
 struct PItem { PConst C; PGeom Gm; PSync Sy; };
 template <int NX, int NU, int MD, bool MSTAGE>
-__global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_persist_batch(const PItem *items, Opts O, int G, unsigned seq) {
+__global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_persist_batch(const PItem *items, Opts O, int G, unsigned seq, int nap) {
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     const int tree = (int)blockIdx.x / G, b = (int)blockIdx.x - tree * G;
     const PItem *it = items + tree;
@@ -1580,6 +1588,8 @@ __global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_persist_batch(const PItem
     const PGeom Gm = it->Gm;
     PSync Sy = it->Sy;
     Sy.seq = seq;
+    Sy.nap = nap;                 /* by the size of one tree (its hand-overs are what a nap delays; with several hundred workgroups of many small trees
+                                     in one launch no nap length measured clearly better than another) */
     if (MSTAGE) mpersist_entry<NX, NU, MD, false>(C, O, Gm, Sy, 1, b, lds_all);
     else persist_entry<NX, NU, MD, false>(C, O, Gm, Sy, 1, b, lds_all);
 }
