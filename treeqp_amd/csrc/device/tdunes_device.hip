@@ -121,6 +121,9 @@ struct Opts {
 /* Tagged words: what crosses workgroups INSIDE a launch.  A double travels as two 64-bit relaxed agent-scope atomic stores,
  * each (tag << 32) | 32-bit half; the consumer polls the payload itself until every word carries the tag it expects (see
  * tdunes_persist.hpp).  Relaxed agent-scope accesses go to the memory side, so nothing depends on one XCD's L2 seeing another's. */
+#ifndef TQ_WIDE_NAP
+#define TQ_WIDE_NAP 1        /* s_sleep between two looks of a wait inside a fused sweep (x 64 cycles): 1 / 2 / 4 give 0.94 / 0.97 / 0.99 ms for one C5-class tree, no difference on C4; 16 and 32 are slower on both */
+#endif
 #define RLX __ATOMIC_RELAXED
 #define AGENT __HIP_MEMORY_SCOPE_AGENT
 typedef unsigned long long u64;
@@ -142,7 +145,7 @@ __device__ __forceinline__ double wait_tag(const u64 *p, unsigned tag, bool &dea
         const double v = ld_tag(p, tag, ok);
         if (ok) return v;
         if (dead || wall_clock64() - t0 > 50000000ull) { dead = true; return 0.0; }      /* 100 MHz clock */
-        __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_s_sleep(TQ_WIDE_NAP);
     }
 }
 

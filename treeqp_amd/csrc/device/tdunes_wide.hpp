@@ -262,7 +262,7 @@ __device__ __forceinline__ void factor_w_body(const Tree &T, const Data &D, cons
                             val = ld_tag(rec + (size_t)f * 2, tag, ok);
                             if (ok || dead) break;
                             if (wall_clock64() - t0 > 50000000ull) { dead = true; val = 0.0; break; }      /* 0.5 s at 100 MHz: cannot happen (see above) */
-                            __builtin_amdgcn_s_sleep(4);
+                            __builtin_amdgcn_s_sleep(TQ_WIDE_NAP);
                         }
                         lds_ptr dst = gj == 0 ? Tm + dp + (posc + gi - 1) * ld : Tm + (posc + gi - 1) + (posc + gj - 1) * ld;
                         *dst -= val;
@@ -530,7 +530,7 @@ __global__ void __launch_bounds__(WT) k_forward_all_w(Tree T, Data D, u64 *fw, u
                 if (tid == 0) { D.ctrl->status = 3; __hip_atomic_store(&D.ctrl->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
                 break;
             }
-            __builtin_amdgcn_s_sleep(4);
+            __builtin_amdgcn_s_sleep(TQ_WIDE_NAP);
         }
 #pragma unroll
         for (int m = 0; m < 16; m++) dl[m] = rdlane(val, m);
