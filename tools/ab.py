@@ -9,10 +9,11 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 args = sys.argv[1:]
-workload, steps = "C2", "300"
+workload, steps, trees = "C2", "300", "1"
 while args and args[0].startswith("--"):
     if args[0] == "--workload": workload = args[1]
     if args[0] == "--steps": steps = args[1]
+    if args[0] == "--trees": trees = args[1]
     args = args[2:]
 for rnd in range(2):
     for name in args:
@@ -28,7 +29,7 @@ for rnd in range(2):
         else:
             env.pop("TREEQP_AMD_LIB", None)
         r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", steps, "--warmup", "30", "--workload", workload,
-                            "--no-cpu-baseline", "--no-batched"], env=env, capture_output=True, text=True, timeout=300)
+                            "--no-cpu-baseline", "--no-batched", "--trees", trees], env=env, capture_output=True, text=True, timeout=300)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if not line:
             print(f"{label:16s} FAILED rc={r.returncode} {r.stderr[-400:]}", flush=True)

@@ -1535,8 +1535,8 @@ int launch_trial(tqgpu_solver *s, const Opts &O, bool fast, int it, int t, int &
 /* persistent launch: geometry, sync words, co-residency test */
 /* poll naps by launch size (PollGuard::go_on) */
 static int nap_for_grid(int workgroups) {
-    static const int t1 = getenv("TREEQP_AMD_NAP_T1") ? atoi(getenv("TREEQP_AMD_NAP_T1")) : 128, t2 = getenv("TREEQP_AMD_NAP_T2") ? atoi(getenv("TREEQP_AMD_NAP_T2")) : 256;
-    return workgroups > t2 ? 2 : (workgroups > t1 ? 1 : 0);
+    static const int t1 = getenv("TREEQP_AMD_NAP_T1") ? atoi(getenv("TREEQP_AMD_NAP_T1")) : 128;
+    return workgroups > t1 ? 1 : 0;
 }
 int setup_persist(tqgpu_solver *s, int device) {
     s->persist_ok = false;
@@ -2630,11 +2630,13 @@ static int batch_kernel_index(const tqgpu_solver *s) {
 }
 static int launch_persist_batch(tqgpu_solver *lead, int kidx, const PItem *items, const Opts &O, int n_trees, unsigned seq) {
     const int G = lead->geom.G;
+    static const char *nap_env = getenv("TREEQP_AMD_NAP");
+    const int batch_nap = nap_env ? atoi(nap_env) : nap_for_grid(G * n_trees);     /* the whole launch polls the same memory system */
     static size_t lds_allowed[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     switch (kidx) {
 #define X(idx, nx, nu, md, ms) case idx: { \
         if (lds_allowed[idx] < lead->lds_persist) { int rc = allow_lds(f_persist_batch<nx, nu, md, ms>, lead->lds_persist); if (rc != TQGPU_OK) return rc; lds_allowed[idx] = lead->lds_persist; } \
-        hipLaunchKernelGGL((f_persist_batch<nx, nu, md, ms>), dim3((unsigned)(G * n_trees)), dim3(FW * WAVE), lead->lds_persist, lead->stream, items, O, G, seq, nap_for_grid(G)); break; }
+        hipLaunchKernelGGL((f_persist_batch<nx, nu, md, ms>), dim3((unsigned)(G * n_trees)), dim3(FW * WAVE), lead->lds_persist, lead->stream, items, O, G, seq, batch_nap); break; }
         BATCH_TABLE(X)
 #undef X
         default: return fail(TQGPU_EINVAL, "no batch kernel for this shape");

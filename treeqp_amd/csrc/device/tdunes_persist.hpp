@@ -107,7 +107,7 @@ struct PSync {
     unsigned *timeout;      /* sticky: a bounded spin gave up                                         */
     unsigned seq;           /* launch number << 16 (low 16 bits of the number are never 0)            */
     unsigned trip;          /* tag of the pass the workgroup is in (kernel-local copy only)           */
-    int nap;                /* how long a poll loop sleeps between two looks: 0 short (small launches), 1, 2 long (several hundred workgroups) */
+    int nap;                /* > 0: a launch of several hundred workgroups -- the bottom tier's wait for its parent's step naps long (p_forward_tier) */
 };
 
 /* Poll loops read the payload AND the two "launch is over" words in the same round trip (the loads are
@@ -128,12 +128,9 @@ struct PollGuard {
         if (h == Sy.seq || tmo || cm == Sy.trip) return false;
         if (wall_clock64() - t0 > 50000000ull) { __hip_atomic_store(Sy.timeout, 1u, RLX, AGENT); return false; }   /* 0.5 s at 100 MHz */
         /* a nap between two looks: every look is 3 - 35 loads per lane that go to the memory side, and with a few hundred workgroups
-         * polling they are in each other's (and the producers') way -- C3 (293 workgroups): 153 us per solve without naps, 141 with
-         * 4 x 64 cycles, 137 with 16 x 64; a launch of 73 workgroups (C2) is best with 1 x 64 and 4 us slower with 16 x 64 (the nap
-         * is on the hand-over's critical path).  The host sets the length by the size of the launch. */
-        if (Sy.nap >= 2) __builtin_amdgcn_s_sleep(16);
-        else if (Sy.nap == 1) __builtin_amdgcn_s_sleep(4);
-        else __builtin_amdgcn_s_sleep(1);
+         * polling they are in each other's (and the producers') way.  Short (64 cycles) here: this is on every hand-over's critical
+         * path.  The one long wait of a pass naps longer in large launches (p_forward_tier). */
+        __builtin_amdgcn_s_sleep(1);
         return true;
     }
 };
@@ -579,14 +576,32 @@ __device__ __forceinline__ double p_forward_tier(const PConst &C, const PSync &S
     if (from_parent) {
         const int ii = p_slot_node<NX, NU, MD>(0, l0, s, C);
         const u64 *src = Sy.dlt + (size_t)NX * ii * 2;
+        /* This wait is most of a pass for the lower tiers (the step comes down only after the whole backward sweep above), and every
+         * look of every waiting workgroup is memory traffic in the way of the ones at work.  In a launch of more than ~128
+         * workgroups (Sy.nap, set by the host) the bottom tier -- most of the workgroups, and the last link of the downward chain --
+         * naps 16 x 64 cycles more between two looks: C3 (256 of 293 workgroups) 145 -> 136 us per solve; on C2's 64 it would
+         * cost 0.6 us.  Two loops, not one with the choice inside: ANY extra instruction in the short loop -- even a never-taken
+         * scalar branch -- measured 1.4 us per C2 solve (profiles/r02_v2_nap_policy.txt). */
         const u64 t0c = wall_clock64();
-        for (;;) {
-            PollGuard pg;
-            ok = true;
+        if (!to_children && Sy.nap > 0) {
+            for (;;) {
+                PollGuard pg;
+                ok = true;
 #pragma unroll
-            for (int r = 0; r < NX; r++) dv[r] = ld_tag(src + 2 * r, tag, ok);
-            pg.load(Sy);
-            if (ok || !pg.go_on(Sy, t0c)) { pg.settle(); break; }
+                for (int r = 0; r < NX; r++) dv[r] = ld_tag(src + 2 * r, tag, ok);
+                pg.load(Sy);
+                if (ok || !pg.go_on(Sy, t0c)) { pg.settle(); break; }
+                __builtin_amdgcn_s_sleep(15);
+            }
+        } else {
+            for (;;) {
+                PollGuard pg;
+                ok = true;
+#pragma unroll
+                for (int r = 0; r < NX; r++) dv[r] = ld_tag(src + 2 * r, tag, ok);
+                pg.load(Sy);
+                if (ok || !pg.go_on(Sy, t0c)) { pg.settle(); break; }
+            }
         }
         ok = __all(ok);
         if (!ok) { if (lane == 0) *L.abort = p_abort_code(Sy); }      /* the launch is over or the pass is dropped: nothing below may leave the workgroup */
@@ -1588,8 +1603,7 @@ __global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_persist_batch(const PItem
     const PGeom Gm = it->Gm;
     PSync Sy = it->Sy;
     Sy.seq = seq;
-    Sy.nap = nap;                 /* by the size of one tree (its hand-overs are what a nap delays; with several hundred workgroups of many small trees
-                                     in one launch no nap length measured clearly better than another) */
+    Sy.nap = nap;
     if (MSTAGE) mpersist_entry<NX, NU, MD, false>(C, O, Gm, Sy, 1, b, lds_all);
     else persist_entry<NX, NU, MD, false>(C, O, Gm, Sy, 1, b, lds_all);
 }
