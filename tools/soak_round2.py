@@ -1,6 +1,7 @@
 """Soak of the round-2 launch protocols: many back-to-back solves, every verdict and solution identical to the first.
   * launch-per-phase path with a sweep as one launch and the reductions as sweep tails (a pruned tree, an irregular tree)
   * batches of one shape as ONE launch (C1 x 24 trees, C2 x 4 trees)
+  * single persistent launches with the short and the long poll naps (C2: 73 workgroups, C3: 293)
 Usage: python tools/soak_round2.py [solves per case]"""
 import os
 import sys
@@ -56,4 +57,20 @@ for name, p, nt in (("C1 x 24 in one launch", P.spring_mass(), 24), ("C2 x 4 in 
     print(f"{name}: {n} batches identical ({rs0[0]['iter']} iterations per tree)", flush=True)
     for m in ms:
         m.close()
+for name, p in (("C2 single persistent launch", P.linear_chain(2, 9, 9)), ("C3 single persistent launch (long naps)", P.linear_chain(2, 11, 11))):
+    g = lti(p)
+    g.event_timing(False)
+    r0 = g.solve()
+    s0 = g.solution()
+    t0 = time.perf_counter()
+    for i in range(n):
+        r = g.solve()
+        assert (r["status"], r["iter"], r["ls_total"]) == (r0["status"], r0["iter"], r0["ls_total"]), (i, r, r0)
+        if i % 500 == 0:
+            print(f"  {name}: {i} solves, {(time.perf_counter() - t0) / max(i, 1) * 1e6:.0f} us each", flush=True)
+    s1 = g.solution()
+    assert all(np.array_equal(s0[k], s1[k]) for k in ("x", "u", "lam")), name
+    assert g.path == 2, g.path
+    print(f"{name}: {n} solves identical (status {r0['status']}, {r0['iter']} iterations, path {g.path})", flush=True)
+    g.close()
 print("soak ok")
