@@ -579,8 +579,8 @@ __device__ __forceinline__ double p_forward_tier(const PConst &C, const PSync &S
         /* This wait is most of a pass for the lower tiers (the step comes down only after the whole backward sweep above), and every
          * look of every waiting workgroup is memory traffic in the way of the ones at work.  In a launch of more than ~128
          * workgroups (Sy.nap, set by the host) the bottom tier -- most of the workgroups, and the last link of the downward chain --
-         * naps 16 x 64 cycles more between two looks: C3 (256 of 293 workgroups) 145 -> 136 us per solve; on C2's 64 it would
-         * cost 0.6 us.  Two loops, not one with the choice inside: ANY extra instruction in the short loop -- even a never-taken
+         * naps 32 x 64 cycles more between two looks: C3 (256 of 293 workgroups) 145 -> 134 us per solve (16 x 64: 136.5, 64 x 64:
+         * 133.8); on C2's 64 it would cost 0.6 us.  Two loops, not one with the choice inside: ANY extra instruction in the short loop -- even a never-taken
          * scalar branch -- measured 1.4 us per C2 solve (profiles/r02_v2_nap_policy.txt). */
         const u64 t0c = wall_clock64();
         if (!to_children && Sy.nap > 0) {
@@ -591,7 +591,10 @@ __device__ __forceinline__ double p_forward_tier(const PConst &C, const PSync &S
                 for (int r = 0; r < NX; r++) dv[r] = ld_tag(src + 2 * r, tag, ok);
                 pg.load(Sy);
                 if (ok || !pg.go_on(Sy, t0c)) { pg.settle(); break; }
-                __builtin_amdgcn_s_sleep(15);
+#ifndef TQ_LONG_NAP
+#define TQ_LONG_NAP 31
+#endif
+                __builtin_amdgcn_s_sleep(TQ_LONG_NAP);
             }
         } else {
             for (;;) {
