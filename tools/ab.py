@@ -1,4 +1,4 @@
-"""A/B timing of experiment builds on the GPU box: python tools/ab.py [--workload C2] [--steps 300] base wps1 ...
+"""A/B timing of experiment builds on the GPU box: python tools/ab.py [--workload C2] [--steps 300] [--trees 1] base wps1 build@VAR=VALUE ...
 Each name is a directory under treeqp_amd/lib_var/ (`base` = the product library); one bench.py child per build,
 sequentially, two rounds (run-to-run spread)."""
 import json
