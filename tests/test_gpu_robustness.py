@@ -371,6 +371,34 @@ def test_solve_n_is_n_solves(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("make", [lambda: P.spring_mass(), lambda: P.linear_chain(2, 7, 7), lambda: P.linear_chain(3, 4, 4, nm=2)],
+                         ids=["spring_mass", "chain_md2_255", "chain_md3_121"])
+def test_long_poll_naps_do_not_change_a_solve(gpu, monkeypatch, make):
+    """The bottom tier's long naps (on by themselves in launches of more than 128 workgroups) forced on for small
+    launches: same verdict, bit-identical solution; a backtracking line search (rejected trials, dropped passes) included."""
+    p = make()
+    nk = p.nk()
+    nx = np.full(p.Nn, p.nx, dtype=np.int32)
+    nu = np.where(nk > 0, p.nu, 0).astype(np.int32)
+    qp = gpu.TreeQp(nx, nu, nk).fill_lti(p)
+    lam0 = np.full_like(p.lambda0, 0.3)              # a start that makes the line search backtrack
+    out = []
+    for nap in ("0", "1"):
+        monkeypatch.setenv("TREEQP_AMD_NAP", nap)
+        g = gpu.TqGpu(nk, nx, nu).upload(qp.flat(), lam0)
+        assert g.path == 2, g.path
+        r = g.solve()
+        out.append((r, g.solution()))
+        assert gpu.lib().tqgpu_timeouts(g.h) == 0
+        g.close()
+    (r0, s0), (r1, s1) = out
+    assert (r0["status"], r0["iter"], r0["ls_total"]) == (r1["status"], r1["iter"], r1["ls_total"])
+    assert r0["status"] == 0
+    for k in ("x", "u", "lam", "mu_x", "mu_u"):
+        assert np.array_equal(s0[k], s1[k])
+
+
+@pytest.mark.gpu
 def test_batch_of_one_shape_is_one_launch_and_survives_changes(gpu, orc):
     """Trees of one shape with a batch kernel go out as ONE launch (f_persist_batch): bit-identical to single solves; a member whose
     data changed between two batch calls (asynchronous upload on its own stream) is picked up; the batch may be composed of other
