@@ -291,35 +291,7 @@ def main():
     if shard:
         g.shard_gather_solution()
 
-    # N > 1, batch mode: ALSO the configuration north_star names -- one C3 tree sharded by subtrees over the ranks (RCCL)
-    sharded = None
-    if world > 1 and not shard and args.backend == "nccl":      # (a gloo rehearsal puts several ranks on one device, which RCCL refuses)
-        try:
-            c3, c3desc, _ = make_workload("C3")
-            m3 = mirror(c3[0])
-            shard_setup(m3)
-            for _ in range(5):
-                r3 = m3.solve()
-            barrier()
-            ts = time.perf_counter()
-            ksteps = max(10, min(args.steps, 50))
-            it3 = 0
-            for _ in range(ksteps):
-                r3 = m3.solve()
-                it3 += r3["iter"]
-            m3.device_times(1)
-            barrier()
-            te = time.perf_counter() - ts
-            import torch
-            tt = torch.tensor([te], dtype=torch.float64, device=red_dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            sharded = {"workload": f"C3: {c3desc}", "value": it3 / float(tt.item()), "unit": "newton_iter/s", "steps": ksteps, "ms_per_step": 1e3 * float(tt.item()) / ksteps,
-                       "scaling": "strong", "status": int(r3["status"]), "newton_iter_per_solve": it3 / ksteps,
-                       "parallelism": f"one tree, subtrees partitioned over {world} ranks, 2 RCCL all-gathers per Newton iteration (launch-per-tier kernels)"}
-            m3.close()
-        except Exception as e:          # the replica line must not be lost to a failure of the extra leg
-            sharded = {"error": str(e)[:300]}
-
+    out = None
     if rank == 0:
         n_trees = len(mirrors)
         kkt = None
@@ -381,8 +353,6 @@ def main():
                          "algorithmic_bytes_per_iteration": bytes_it, "algorithmic_flops_per_iteration": flops_it,
                          "note": "latency-bound: a chain of dependent block factorisations per tree level; on the persistent paths state and constants are LDS-resident, so memory traffic is far below the algorithmic bytes"},
         }
-        if sharded is not None:
-            out["sharded"] = sharded
         if world == 1 and n_trees == 1 and g.path == 2 and not args.no_batched:
             # the dependent chain that bounds a solve, against its measured floors
             geo = g.geometry()
@@ -420,7 +390,57 @@ def main():
                 m.close()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(items, opts)
+    # N > 1, batch mode: ALSO the configuration north_star names -- one C3 tree sharded by subtrees over the ranks (RCCL)
+    # This leg comes LAST and under a deadline: the line of the replicas above is complete before it starts, and a communicator
+    # that never comes up (the RCCL transport has not run on more than one device yet) costs the extra object, not the line.
+    sharded = None
+    if world > 1 and not shard and (args.backend == "nccl" or os.environ.get("TREEQP_BENCH_SHARD_ANYWAY")):      # (a gloo rehearsal puts several ranks on one device, which RCCL refuses)
+        import threading
+        leg_done = threading.Event()
+        deadline = float(os.environ.get("TREEQP_BENCH_SHARD_DEADLINE", "180"))
+
+        def watchdog():
+            if leg_done.wait(deadline):
+                return
+            if rank == 0:
+                out["sharded"] = {"error": f"the sharded leg did not finish within {deadline:.0f} s; abandoned"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)                       # the main thread is stuck in a collective: no orderly teardown possible
+
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            c3, c3desc, _ = make_workload("C3")
+            m3 = mirror(c3[0])
+            shard_setup(m3)
+            for _ in range(5):
+                r3 = m3.solve()
+            barrier()
+            ts = time.perf_counter()
+            ksteps = max(10, min(args.steps, 50))
+            it3 = 0
+            for _ in range(ksteps):
+                r3 = m3.solve()
+                it3 += r3["iter"]
+            m3.device_times(1)
+            barrier()
+            te = time.perf_counter() - ts
+            import torch
+            tt = torch.tensor([te], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            sharded = {"workload": f"C3: {c3desc}", "value": it3 / float(tt.item()), "unit": "newton_iter/s", "steps": ksteps, "ms_per_step": 1e3 * float(tt.item()) / ksteps,
+                       "scaling": "strong", "status": int(r3["status"]), "newton_iter_per_solve": it3 / ksteps,
+                       "parallelism": f"one tree, subtrees partitioned over {world} ranks, 2 RCCL all-gathers per Newton iteration (launch-per-tier kernels)"}
+            m3.close()
+        except Exception as e:          # the replica line must not be lost to a failure of the extra leg
+            sharded = {"error": str(e)[:300]}
+        leg_done.set()
+
+    if rank == 0:
+        if sharded is not None:
+            out["sharded"] = sharded
         print(json.dumps(out), flush=True)
+    if sharded is not None and "error" in sharded:
+        os._exit(0)          # the other ranks may be stuck in a collective of the failed leg (their deadline ends them): no orderly teardown with them
     for m in mirrors:
         m.close()
     if dist is not None:
