@@ -119,8 +119,10 @@ def level_floors():
     return out
 
 
-def critical_path(g, p_levels: int, n_tiers: int, reps: int = 60):
-    """period of a pass = t(maxIter=2) - t(maxIter=1) (device times), against the chain of level floors"""
+def critical_path(g, p_levels: int, n_tiers: int, reps: int = 60, floors_apply: bool = True):
+    """period of a pass = t(maxIter=2) - t(maxIter=1) (device times), against the chain of level floors.  The floors were
+    measured for ONE shape (nx = 8, nu = 3, md = 2: 41-row x 16 blocks, tiers of 3 levels); for any other shape only the measured
+    period and fixed cost are reported (`floors_apply` False): a floor of another shape is not a floor."""
     def med(k):
         for _ in range(10):
             g.solve(maxIter=k)
@@ -136,13 +138,30 @@ def critical_path(g, p_levels: int, n_tiers: int, reps: int = 60):
     out = {"pass_us": t2 - t1, "fixed_us": t1 - (t2 - t1), "levels": p_levels, "tiers": n_tiers,
            "note": "pass = G+H, backward sweep (one dependent block factorisation per level), forward sweep, trial sweep; "
                    "fixed = launch, state load, first sweep, last verdict, write-back"}
-    if back:
+    if back and floors_apply:
         floor = (p_levels * back + n_tiers * (fwd or 0.0) + sg) / (CLOCK_GHZ * 1e3) + 2 * (n_tiers - 1) * handover_us
         out.update({"floor_us": floor, "achieved_over_floor": (t2 - t1) / floor,
                     "floor_terms": {"backward_level_cycles": back, "forward_tier_cycles": fwd, "stage_plus_gh_cycles": sg,
                                     "handover_us": handover_us, "handovers": 2 * (n_tiers - 1)},
                     "floor_source": "profiles/r02_v2_level_bench.txt (tools/microbench/level_bench on MI355X), cycles at 2.4 GHz"})
     return out
+
+
+def dumps(obj) -> str:
+    """json.dumps without bare NaN / Infinity (not valid JSON): non-finite floats become null"""
+    def clean(v):
+        if isinstance(v, float):
+            return v if np.isfinite(v) else None
+        if isinstance(v, (np.floating,)):
+            return float(v) if np.isfinite(v) else None
+        if isinstance(v, (np.integer,)):
+            return int(v)
+        if isinstance(v, dict):
+            return {k: clean(x) for k, x in v.items()}
+        if isinstance(v, (list, tuple)):
+            return [clean(x) for x in v]
+        return v
+    return json.dumps(clean(obj), allow_nan=False)
 
 
 def self_launch(args):
@@ -303,15 +322,16 @@ def main():
         ls_per_iter = ls / max(iters, 1)
         # algorithmic bytes: bytes per Newton iteration (closed form, per tree) x the iterations of the launch
         n_ls = max(1, round(ls_per_iter))
-        if len(items) > 1:
-            # a batch of different trees per step (C5): ONE launch per step carries them all; its duration is taken from the wall
-            # clock of the step (the per-mirror event pairs bracket the enqueue, not the shared launch)
+        if len(mirrors) > 1:
+            # a batch of trees per step (C5, or --trees B): ONE launch per step carries them all; its duration is taken from the wall
+            # clock of the step (members of a batch launch record no event pair of their own)
             rs = capi.solve_batch(mirrors, **opts)
             costs = [m.iteration_cost(n_ls) for m in mirrors]
             bytes_step = float(sum(b * rr["iter"] for (b, _), rr in zip(costs, rs)))
             bytes_it = float(np.mean([b for b, _ in costs]))
             flops_it = float(np.mean([f for _, f in costs]))
             launch_s = tmax / args.steps
+            dev_time = launch_s * ev_steps                             # device time per iteration from the same wall clock (all trees of the step)
         else:
             bytes_it, flops_it = g.iteration_cost(n_ls)
             bytes_step = bytes_it * it_per_solve                   # mirror 0's launch: one tree
@@ -319,7 +339,7 @@ def main():
         achieved = bytes_step / launch_s / 1e9
         traffic = None
         tf = ROOT / "profiles" / f"traffic_{args.workload}.json"
-        if tf.exists() and g.path == 2 and n_trees == 1:
+        if tf.exists() and n_trees == 1:
             traffic = json.loads(tf.read_text()).get("bytes_per_launch")        # from the committed PMC passes
         kernel = {2: "f_persist / f_mpersist: the whole solve in one launch (first sweep + all Newton iterations)",
                   3: "g_persist(_batch): the whole solve in one launch of one workgroup per tree",
@@ -340,7 +360,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "nodes": int(sum(w["nodes"] for w in items)), "newton_iter_per_solve": it_per_solve,
                        "ls_trials_per_iter": ls_per_iter, "ms_per_newton_iter": 1e3 * tmax / max(iters, 1),
-                       "device_ms_per_newton_iter": 1e3 * dev_time / max(ev_iters, 1) * (n_trees if len(items) > 1 else 1),
+                       "device_ms_per_newton_iter": 1e3 * dev_time / max(ev_iters, 1),
                        "kernel_launches_per_solve": launches / args.steps / n_trees, "max_kkt_residual": kkt, "trees_per_gpu": n_trees,
                        "device_path": int(g.path),
                        "parallelism": ("one tree sharded by subtrees, 2 RCCL all-gathers per Newton iteration" if shard else
@@ -348,7 +368,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kernel,
                          "traffic_note": "memory-side bytes per launch (FETCH_SIZE raw + WRITE_SIZE) from profiles/traffic_<workload>.json; one launch = one solve",
-                         "launch_us": 1e6 * launch_s, "launch_us_source": f"HIP event pair per launch on the solver's stream, mean over {ev_steps} solves of the same workload right after the timed region (the timed region itself enqueues the bare launch)",
+                         "launch_us": 1e6 * launch_s, "launch_us_source": ("wall clock of a step (one batch launch carries every tree of the step)" if len(mirrors) > 1 else f"HIP event pair per solve on the solver's stream, mean over {ev_steps} solves of the same workload right after the timed region (the timed region itself enqueues the bare launches)"),
                          "algorithmic_bytes_per_launch": bytes_step,
                          "algorithmic_bytes_per_iteration": bytes_it, "algorithmic_flops_per_iteration": flops_it,
                          "note": "latency-bound: a chain of dependent block factorisations per tree level; on the persistent paths state and constants are LDS-resident, so memory traffic is far below the algorithmic bytes"},
@@ -356,7 +376,11 @@ def main():
         if world == 1 and n_trees == 1 and g.path == 2 and not args.no_batched:
             # the dependent chain that bounds a solve, against its measured floors
             geo = g.geometry()
-            out["critical_path"] = critical_path(g, geo["levels"], geo["tiers"])
+            f0 = items[0]["flat"]
+            c2_shape = int(f0["nx"][0]) == 8 and int(f0["nu"][0]) == 3 and int(f0["nk"][0]) == 2 and len(set(map(int, f0["nk"][f0["nk"] > 0]))) == 1
+            out["critical_path"] = critical_path(g, geo["levels"], geo["tiers"], floors_apply=c2_shape)
+            if not c2_shape:
+                out["critical_path"]["floor_note"] = "level floors exist for the (8, 3, 2) shape only (tools/microbench/level_bench); not applied to this shape"
             # throughput leg (reported beside the latency metric, never as `value`): independent trees of the same workload solved by
             # one batched call per step -- what a scenario sweep (fault_tolerance.c:486-530) gets -- swept up to what is co-resident
             cap = {"workgroups_per_tree": geo["workgroups"], "capacity": geo["capacity"], "compute_units": geo["compute_units"]}
@@ -404,7 +428,8 @@ def main():
                 return
             if rank == 0:
                 out["sharded"] = {"error": f"the sharded leg did not finish within {deadline:.0f} s; abandoned"}
-                print(json.dumps(out), flush=True)
+                out["sharded_ok"] = False
+                print(dumps(out), flush=True)
             os._exit(0)                       # the main thread is stuck in a collective: no orderly teardown possible
 
         threading.Thread(target=watchdog, daemon=True).start()
@@ -432,13 +457,14 @@ def main():
                        "parallelism": f"one tree, subtrees partitioned over {world} ranks, 2 RCCL all-gathers per Newton iteration (launch-per-tier kernels)"}
             m3.close()
         except Exception as e:          # the replica line must not be lost to a failure of the extra leg
-            sharded = {"error": str(e)[:300]}
+            sharded = {"error": str(e)}
         leg_done.set()
 
     if rank == 0:
         if sharded is not None:
             out["sharded"] = sharded
-        print(json.dumps(out), flush=True)
+            out["sharded_ok"] = "error" not in sharded          # top level: a failed sharded leg must not read as success
+        print(dumps(out), flush=True)
     if sharded is not None and "error" in sharded:
         os._exit(0)          # the other ranks may be stuck in a collective of the failed leg (their deadline ends them): no orderly teardown with them
     for m in mirrors:

@@ -11,8 +11,11 @@
  *     treeqp_tdunes_create prints the HIP error and exits(1) (the reference's convention for
  *     fatal configuration errors, dual_Newton_tree_clipping.c:70-74).
  * The reference's 13-entry per-node stage-QP vtable (dual_Newton_tree.h:48-63) is replaced by
- * one batched kernel family; opts->qp_solver[] is still honoured as a per-node selector and
- * anything other than TREEQP_CLIPPING_SOLVER is rejected at create time.
+ * one batched kernel family; opts->qp_solver[] is honoured as a per-node selector:
+ * TREEQP_CLIPPING_SOLVER (diagonal weights, box bounds) and TREEQP_QPOASES_SOLVER restricted to
+ * nodes WITHOUT bounds (dense unconstrained stage QP, solved on the device) mix freely in one
+ * tree; a dense node with finite bounds would need an active-set stage solver and is rejected
+ * at create time.
  */
 #ifndef TREEQP_SRC_DUAL_NEWTON_TREE_H_
 #define TREEQP_SRC_DUAL_NEWTON_TREE_H_

@@ -144,6 +144,36 @@ def test_shared_device_takes_the_launch_per_tier_path(gpu, orc):
     g2.close()
 
 
+def test_shared_device_batch_launch_recovers_member_by_member(gpu, orc):
+    """tqgpu_solve_batch with a foreign kernel holding most compute units: the ONE launch that carries all members cannot get
+    its workgroups resident, every member's bounded wait gives up, and each member is redone on its own -- but only after the
+    batch launch (on the LEAD's stream) is over, so that workgroups of it that start late cannot run beside the redo on the same
+    device state.  Results equal the oracle; a following batch on the free device is clean and counts no further timeout."""
+    L = gpu.lib()
+    p = P.linear_chain(2, 9, 9)
+    qp = product_qp_from_lti(gpu, p)
+    flat = qp.flat()
+    ref = orc.solve(flat, lambda0=p.lambda0)
+    ms = [gpu.TqGpu(flat["nk"], flat["nx"], flat["nu"]).upload(flat, p.lambda0) for _ in range(3)]
+    assert all(m.path == 2 for m in ms)
+    rs = gpu.solve_batch(ms)
+    assert all(r["status"] == 0 and r["iter"] == ref["iter"] for r in rs) and all(L.tqgpu_timeouts(m.h) == 0 for m in ms)
+    assert L.tqgpu_debug_occupy(-1, 232, 160, 2500) == 0
+    rs = gpu.solve_batch(ms)                          # 219 workgroups, room for 24
+    assert L.tqgpu_debug_occupy_wait() == 0
+    assert all(r["status"] == 0 and r["iter"] == ref["iter"] for r in rs), rs
+    n_to = [L.tqgpu_timeouts(m.h) for m in ms]
+    assert all(n >= 1 for n in n_to)
+    for m in ms:
+        assert_solution_close(m.solution(), ref, TOL)
+    rs = gpu.solve_batch(ms)                          # device free again
+    assert all(r["status"] == 0 and r["iter"] == ref["iter"] for r in rs)
+    assert [L.tqgpu_timeouts(m.h) for m in ms] == n_to
+    for m in ms:
+        assert_solution_close(m.solution(), ref, TOL)
+        m.close()
+
+
 def _mixed_problem(seed, dense_blocks=True):
     """irregular tree; every second level uses the dense unconstrained stage solver (full Q, R, S), the others clipping
     (diagonal weights, box bounds on the inputs that become active)."""

@@ -1109,6 +1109,7 @@ struct tqgpu_solver {
     unsigned long uid = 0;                                                /* unique per mirror of this process (an address can come back) */
     bool stream_pending = false;                                          /* something was enqueued on `stream` without a synchronisation after it (asynchronous uploads, constant packing): a batch launch on ANOTHER stream waits for it first */
     hipEvent_t batch_ev = nullptr;
+    hipStream_t batch_stream = nullptr;                                   /* member of a batch launch in flight: the stream that launch is on (the lead's) */
     size_t sync_words_bytes = 0, lds_persist = 0;
     /* sharded mode */
     int nranks = 1, rank = 0, part_top = -1;      /* part_top: highest partitioned tier */
@@ -2271,7 +2272,10 @@ int wait_result_block(tqgpu_solver *s) {
     for (long spins = 0; *seq != want; spins++) {
         __builtin_ia32_pause();
         if ((spins & 0xFFFF) == 0xFFFF && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
-            /* no verdict (a wait inside the kernel timed out, or the launch failed): fall back to the stream */
+            /* no verdict (a wait inside the kernel timed out, or the launch failed): fall back to the stream.  A member of a
+             * batch launch first waits for THAT launch (it runs on the lead's stream; the member's own stream is not ordered
+             * behind it, and its control block is only final when the launch has ended) */
+            if (s->batch_stream) HIP_TRY(hipStreamSynchronize(s->batch_stream));
             return read_ctrl(s);
         }
     }
@@ -2655,6 +2659,10 @@ extern "C" int tqgpu_solve_batch(tqgpu_solver **solvers, int n, const tqgpu_opts
     std::vector<SolveCtx> cx((size_t)n);
     int first_err = TQGPU_OK;
     std::string first_msg;
+    for (int k = 0; k < n; k++) {          /* as tqgpu_solve: a mirror that backed off the persistent path returns to it after PERSIST_BACKOFF solves */
+        tqgpu_solver *sk = solvers[k];
+        if (sk->persist_backoff > 0 && --sk->persist_backoff == 0) sk->use_persist = sk->use_persist_orig;
+    }
     int i = 0;
     while (i < n) {
         /* a wave of mirrors on one device whose persistent launches fit together */
@@ -2712,7 +2720,10 @@ extern "C" int tqgpu_solve_batch(tqgpu_solver **solvers, int n, const tqgpu_opts
             for (int k : pm) mx = std::max(mx, solvers[k]->launch_no);
             unsigned nn = mx + 1;
             if (nn > 0xFFFFu) {          /* the 16-bit launch number wraps: see launch_persist */
-                for (int k : pm) HIP_TRY(hipMemsetAsync(solvers[k]->sync_slab, 0, solvers[k]->sync_bytes, solvers[k]->stream));
+                for (int k : pm) {
+                    HIP_TRY(hipMemsetAsync(solvers[k]->sync_slab, 0, solvers[k]->sync_bytes, solvers[k]->stream));
+                    solvers[k]->stream_pending = true;          /* the batch launch (on the lead's stream) waits for the wipe */
+                }
                 nn = 1;
             }
             pseq = nn << 16;
@@ -2773,14 +2784,22 @@ extern "C" int tqgpu_solve_batch(tqgpu_solver **solvers, int n, const tqgpu_opts
                 tqgpu_solver *sm = solvers[pm[m]];
                 if (sm->stream_pending) { HIP_TRY(hipStreamSynchronize(sm->stream)); sm->stream_pending = false; }
             }
+            for (int k : pm) solvers[k]->batch_stream = st0;
             int rcb = launch_persist_batch(pl, batch_kernel_index(pl), pl->d_pitems, cx[(size_t)pm[0]].O, (int)np, pseq);
-            if (rcb != TQGPU_OK) return rcb;
+            if (rcb != TQGPU_OK) { for (int k : pm) solvers[k]->batch_stream = nullptr; return rcb; }
         }
         for (int k = begun_from; k < ok_to; k++) {
-            int rc = solve_end(solvers[k], o, cx[(size_t)k], &results[k]);
-            if (rc == TQGPU_ETIMEOUT) rc = solve_after_timeout(solvers[k], o, &results[k]);     /* device shared: redone on its own, see tqgpu_solve */
+            tqgpu_solver *sk = solvers[k];
+            int rc = solve_end(sk, o, cx[(size_t)k], &results[k]);
+            if (rc == TQGPU_ETIMEOUT) {
+                /* device shared: redone on its own, see tqgpu_solve.  The redo works on the same device state as the batch launch,
+                 * whose later workgroups may not even have started: the launch has to be over before the sticky word is cleared */
+                if (sk->batch_stream) HIP_TRY(hipStreamSynchronize(sk->batch_stream));
+                rc = solve_after_timeout(sk, o, &results[k]);
+            }
             if (rc != TQGPU_OK && first_err == TQGPU_OK) { first_err = rc; first_msg = g_err; }
         }
+        for (int k = begun_from; k < begun_to; k++) solvers[k]->batch_stream = nullptr;
         /* the members' later work (solution export, the next solve) runs on their own streams: it has to find the batch launch
          * complete -- every verdict is in, so this waits for the write-back of the last workgroups only, once per batch */
         if (!pm.empty() && ok_to == begun_to) HIP_TRY(hipStreamSynchronize(solvers[pm[0]]->stream));
