@@ -163,7 +163,7 @@ def test_shared_device_batch_launch_recovers_member_by_member(gpu, orc):
     assert L.tqgpu_debug_occupy_wait() == 0
     assert all(r["status"] == 0 and r["iter"] == ref["iter"] for r in rs), rs
     n_to = [L.tqgpu_timeouts(m.h) for m in ms]
-    assert all(n >= 1 for n in n_to)
+    assert sum(n_to) >= 1, n_to                        # (a member whose workgroups only started when the device was free again needs no redo)
     for m in ms:
         assert_solution_close(m.solution(), ref, TOL)
     rs = gpu.solve_batch(ms)                          # device free again

@@ -296,7 +296,9 @@ __device__ __forceinline__ double dot_batched(const double *a, int sa, const dou
 /* mode 1: line-search trial, lam_next = lam_cur + (tau - tauPrev) * dlam, evaluate there.     */
 /* Produces qmod,rmod,x,u,xUnc,uUnc,QinvCal,RinvCal and the node's dual-function term.         */
 /* ------------------------------------------------------------------------------------------ */
-__device__ void stage_body(const Tree &T, const Data &D, int mode, int k, int lane, double *lds, bool batch = true) {
+/* xu != nullptr (k_sg): x, u of a PARENT node are also posted as tagged words -- entry j of x at xu[2 (xoff + j)], of u at
+ * xu[2 (sum_nx + uoff + j)] -- for the children's gradient in the same launch */
+__device__ void stage_body(const Tree &T, const Data &D, int mode, int k, int lane, double *lds, bool batch = true, u64 *xu = nullptr, int sum_nx = 0, unsigned xtag = 0u) {
     const Ctrl *c = D.ctrl;
     const int nxk = T.nx[k], nuk = T.nu[k], xo = T.xoff[k], uo = T.uoff[k];
     const int nkid = T.nk[k], d = T.bdim[k];
@@ -350,6 +352,7 @@ __device__ void stage_body(const Tree &T, const Data &D, int mode, int k, int la
             double acc = 0.0;
             for (int j = 0; j < nz; j++) acc = fma(P[t + (size_t)j * nz], hm[j], acc);
             zz[t] = acc;
+            if (xu && nkid > 0) st_tag(xu + 2 * (size_t)(t < nxk ? xo + t : sum_nx + uo + t - nxk), acc, xtag);
             if (t < nxk) { if (save_s) D.xUncS[xo + t] = D.xUnc[xo + t]; D.x[xo + t] = acc; D.xUnc[xo + t] = acc; }
             else { if (save_s) D.uUncS[uo + t - nxk] = D.uUnc[uo + t - nxk]; D.u[uo + t - nxk] = acc; D.uUnc[uo + t - nxk] = acc; }
         }
@@ -387,6 +390,7 @@ __device__ void stage_body(const Tree &T, const Data &D, int mode, int k, int la
             const double unc = qi * v, lo = D.xmin[xo + j], hi = D.xmax[xo + j];
             double xv, cal;
             if (unc >= hi) { xv = hi; cal = 0.0; } else if (unc <= lo) { xv = lo; cal = 0.0; } else { xv = unc; cal = qi; }
+            if (xu && nkid > 0) st_tag(xu + 2 * (size_t)(xo + j), xv, xtag);
             if (save_s) D.xUncS[xo + j] = D.xUnc[xo + j];
             D.xUnc[xo + j] = unc; D.x[xo + j] = xv; D.QinvCal[xo + j] = cal;
             p_qx = fma(D.Qd[xo + j] * xv, xv, p_qx);
@@ -397,6 +401,7 @@ __device__ void stage_body(const Tree &T, const Data &D, int mode, int k, int la
             const double unc = ri * v, lo = D.umin[uo + j], hi = D.umax[uo + j];
             double uv, cal;
             if (unc >= hi) { uv = hi; cal = 0.0; } else if (unc <= lo) { uv = lo; cal = 0.0; } else { uv = unc; cal = ri; }
+            if (xu && nkid > 0) st_tag(xu + 2 * (size_t)(sum_nx + uo + j), uv, xtag);
             if (save_s) D.uUncS[uo + j] = D.uUnc[uo + j];
             D.uUnc[uo + j] = unc; D.u[uo + j] = uv; D.RinvCal[uo + j] = cal;
             p_ru = fma(D.Rd[uo + j] * uv, uv, p_ru);
@@ -1004,6 +1009,7 @@ __global__ void __launch_bounds__(WAVE) k_ls_decide_parts(Data D, Opts O, const 
 #include "tdunes_fast.hpp"
 #include "tdunes_persist.hpp"
 #include "tdunes_wide.hpp"
+#include "tdunes_wide3.hpp"
 #include "tdunes_gpersist.hpp"
 
 }  // namespace
@@ -1031,6 +1037,12 @@ struct tqgpu_solver {
     int *fuse_cnt = nullptr;            /* ... and the counter of the workgroups that have posted theirs */
     unsigned fuse_epoch = 0;
     bool fuse_ok = false, fuse_now = false;       /* fuse_now: this solve uses them (not while phases are timed one by one) */
+    /* three launches per Newton iteration for the wide-block class (tdunes_wide3.hpp): k_sg, k_hf_w, k_fwd3 */
+    bool w3_ok = false, w3_now = false;
+    unsigned long long *w3_xu = nullptr, *w3_red = nullptr;
+    int *w3_cnt = nullptr;
+    unsigned w3_epoch = 0;
+    size_t lds_hf_w = 0;
     bool dense = false, need_dense_init = false;   /* dense unconstrained stage solver selected (generic path only) */
     double *d_Hd = nullptr;      /* writable alias of Data.Hd */
     int *d_kind = nullptr;       /* writable alias of Data.kind */
@@ -1498,6 +1510,17 @@ static Fuse next_fuse(tqgpu_solver *s) {
     return F;
 }
 static Fuse no_fuse() { Fuse F; F.red = nullptr; F.cnt = nullptr; F.tag = 0; F.on = 0; return F; }
+static W3 next_w3(tqgpu_solver *s) {
+    W3 w; w.xu = s->w3_xu; w.red = s->w3_red; w.cnt = s->w3_cnt; w.sum_nx = s->sum_nx; w.lds_wave = (int)((s->lds_stage + 7) / 8);
+    s->w3_epoch++;
+    if (s->w3_epoch == 0) s->w3_epoch = 1;
+    w.tag = s->w3_epoch;
+    return w;
+}
+static void launch_sg(tqgpu_solver *s, const Opts &O, int mode, int h, int t) {
+    const int grid = (s->T.Nn + SG_WAVES - 1) / SG_WAVES;
+    hipLaunchKernelGGL(k_sg, dim3(grid), dim3(SG_WAVES * WAVE), SG_WAVES * ((s->lds_stage + 7) / 8) * 8, s->stream, s->T, s->D, O, next_w3(s), mode, h, t);
+}
 
 void launch_trial_phase(tqgpu_solver *s, const Opts &O, bool fast, int it, int t, int phase, int &launches) {
     const Tree &T = s->T; const Data &D = s->D; hipStream_t st = s->stream;
@@ -1513,6 +1536,7 @@ void launch_trial_phase(tqgpu_solver *s, const Opts &O, bool fast, int it, int t
                 default: break;
             }
         }
+        if (!done && s->w3_now) { launch_sg(s, O, 1, it, t); done = true; }      /* with the Armijo test and the next termination test as its tail */
         if (!done) {
             if (s->fuse_now && !sharded) hipLaunchKernelGGL(k_stage_f, dim3(T.Nn), dim3(WAVE), s->lds_stage, st, T, D, O, next_fuse(s), 1, it, t);      /* with k_ls_decide as its tail */
             else hipLaunchKernelGGL(k_stage, dim3(T.Nn), dim3(WAVE), s->lds_stage, st, T, D, 1, it, t);
@@ -1521,7 +1545,7 @@ void launch_trial_phase(tqgpu_solver *s, const Opts &O, bool fast, int it, int t
         if (sharded) { hipLaunchKernelGGL(k_shard_pack2, dim3(1), dim3(WAVE), 0, st, D, s->d_node_cnt_list, s->n_nodes_counted, s->d_blk_list, s->n_blk_counted, s->d_xs, s->rank, s->bnd_b0, s->bnd_bn, s->bnd_own0, s->bnd_ownn, it, t); launches++; }
     } else {
         if (sharded) { hipLaunchKernelGGL(k_ls_decide_parts, dim3(1), dim3(WAVE), 0, st, D, O, s->d_xs, s->nranks, it, t, 0); launches++; }
-        else if (!(s->fuse_now && !fast)) { hipLaunchKernelGGL(k_ls_decide, dim3(1), dim3(256), 0, st, T, D, O, it, t, 0); launches++; }
+        else if (!((s->fuse_now || s->w3_now) && !fast)) { hipLaunchKernelGGL(k_ls_decide, dim3(1), dim3(256), 0, st, T, D, O, it, t, 0); launches++; }
     }
 }
 
@@ -1717,6 +1741,20 @@ int launch_persist(tqgpu_solver *s, const Opts &O, int &launches, int prologue, 
 void launch_generic_iteration(tqgpu_solver *s, const Opts &O, int h, int &launches, int parts = 3, bool phases = false) {
     const Tree &T = s->T; const Data &D = s->D; hipStream_t st = s->stream;
     auto mark = [&](int i) { if (phases && (size_t)(4 * h + i) < s->phase_ev.size()) (void)hipEventRecord(s->phase_ev[(size_t)(4 * h + i)], st); };
+    if (s->w3_now) {
+        /* three launches: the termination test of this iteration was the tail of the previous launch of k_sg */
+        if (!(parts & 2)) return;
+        s->bw_epoch++;
+        if (s->bw_epoch == 0) s->bw_epoch = 1;
+        hipLaunchKernelGGL(k_hf_w, dim3(T.Np), dim3(WT), s->lds_hf_w, st, T, D, O, s->sch_words, s->sch_rs, s->bw_epoch, h); launches++;
+        if (T.Np > 1) {
+            s->fw_epoch++;
+            if (s->fw_epoch == 0) s->fw_epoch = 1;
+            hipLaunchKernelGGL(k_fwd3, dim3((T.Np - 1 + SG_WAVES - 1) / SG_WAVES), dim3(SG_WAVES * WAVE), 0, st, T, D, next_w3(s), s->fw_words, s->fw_epoch, h); launches++;
+        } else { hipLaunchKernelGGL(k_ls_begin, dim3(1), dim3(256), 0, st, T, D, h); launches++; }
+        launch_sg(s, O, 1, h, 1); launches++;
+        return;
+    }
     mark(0);
     if (parts & 1) {
         if (s->fuse_now) { hipLaunchKernelGGL(k_grad_f, dim3(T.Nn - 1), dim3(WAVE), 0, st, T, D, O, next_fuse(s), h); launches++; }      /* with k_check as its tail */
@@ -1968,6 +2006,21 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
             s->fuse_ok = true;
         }
     }
+    if (s->wide && !getenv("TREEQP_AMD_NO_WIDE3")) {
+        /* the three-launch family of the wide-block class (tdunes_wide3.hpp) */
+        int nxmax = 0;
+        for (int k = 0; k < Nn; k++) { nxmax = std::max(nxmax, s->nx[k]); if (k < s->Np) s->lds_hf_w = std::max(s->lds_hf_w, wide3_lds(s->bdim[k], k > 0 ? s->nx[k] : 0, s->nx[k] + s->nu[k])); }
+        const size_t groups = (size_t)(Nn + SG_WAVES - 1) / SG_WAVES;
+        const size_t xb = sizeof(unsigned long long) * 2 * (size_t)std::max(s->sum_nx + s->sum_nu, 1), rb = sizeof(unsigned long long) * 4 * groups;
+        if (nxmax <= 32 && s->lds_hf_w <= 160 * 1024 && SG_WAVES * s->lds_stage <= 160 * 1024) {
+            if (hipMalloc(&s->w3_xu, xb) != hipSuccess || hipMemset(s->w3_xu, 0, xb) != hipSuccess ||
+                hipMalloc(&s->w3_red, rb) != hipSuccess || hipMemset(s->w3_red, 0, rb) != hipSuccess ||
+                hipMalloc(&s->w3_cnt, 4 * sizeof(int)) != hipSuccess || hipMemset(s->w3_cnt, 0, 4 * sizeof(int)) != hipSuccess)
+                return cleanup_fail(fail(TQGPU_ENOMEM, "hipMalloc failed for the three-launch hand-over words"));
+            if ((rc = allow_lds(k_hf_w, s->lds_hf_w)) || (rc = allow_lds(k_sg, SG_WAVES * ((s->lds_stage + 7) / 8) * 8))) return cleanup_fail(rc);
+            s->w3_ok = true;
+        }
+    }
     if ((rc = setup_persist(s, device))) return cleanup_fail(rc);
     {
         /* single-workgroup persistent kernel for small trees of any shape: every level must be a few rounds
@@ -2044,6 +2097,9 @@ extern "C" void tqgpu_destroy(tqgpu_solver *s) {
     if (s->d_desc) (void)hipFree(s->d_desc);
     if (s->d_pitems) (void)hipFree(s->d_pitems);
     if (s->h_pitems) (void)hipHostFree(s->h_pitems);
+    if (s->w3_xu) (void)hipFree(s->w3_xu);
+    if (s->w3_red) (void)hipFree(s->w3_red);
+    if (s->w3_cnt) (void)hipFree(s->w3_cnt);
     if (s->fuse_red) (void)hipFree(s->fuse_red);
     if (s->fuse_cnt) (void)hipFree(s->fuse_cnt);
     if (s->fw_words) (void)hipFree(s->fw_words);
@@ -2335,6 +2391,7 @@ int solve_begin(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, GItem *defer
     }
     s->iter_times.assign((size_t)std::max(o->maxIter, 1), NAN);
 
+    s->w3_now = false;
     cx.fast = tiered_capable(s) && o->profile < 3;          /* level 3: the launch-per-level kernels, whose launches ARE the reference's phases */
     cx.phases = o->profile >= 3;
     if (cx.phases) {
@@ -2369,8 +2426,10 @@ int solve_begin(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, GItem *defer
         HIP_TRY(hipMemcpyAsync(D.lam0, s->d_lam_init, sizeof(double) * (size_t)s->sum_nx, hipMemcpyDeviceToDevice, st));
         /* first sweep at lambda0 (phase S of iteration 0 + fval0); the persistent launch does it as its prologue */
         if (cx.phases) HIP_TRY(hipEventRecord(s->sweep_ev0, st));
-        s->fuse_now = s->fuse_ok && !cx.phases && !cx.fast && !s->sharded;
-        if (s->fuse_now) { hipLaunchKernelGGL(k_stage_f, dim3(T.Nn), dim3(WAVE), s->lds_stage, st, T, D, cx.O, next_fuse(s), 0, 0, 0); cx.launches++; }      /* with k_fval_init as its tail */
+        s->w3_now = s->w3_ok && !s->dense && !cx.phases && !cx.fast && !s->sharded;
+        s->fuse_now = s->fuse_ok && !cx.phases && !cx.fast && !s->sharded && !s->w3_now;
+        if (s->w3_now) { launch_sg(s, cx.O, 0, 0, 0); cx.launches++; }          /* with fval0 and the first termination test as its tail */
+        else if (s->fuse_now) { hipLaunchKernelGGL(k_stage_f, dim3(T.Nn), dim3(WAVE), s->lds_stage, st, T, D, cx.O, next_fuse(s), 0, 0, 0); cx.launches++; }      /* with k_fval_init as its tail */
         else {
             hipLaunchKernelGGL(k_stage, dim3(T.Nn), dim3(WAVE), s->lds_stage, st, T, D, 0, 0, 0); cx.launches++;
             hipLaunchKernelGGL(k_fval_init, dim3(1), dim3(256), 0, st, T, D); cx.launches++;
