@@ -344,7 +344,7 @@ def main():
         kernel = {2: "f_persist / f_mpersist: the whole solve in one launch (first sweep + all Newton iterations)",
                   3: "g_persist(_batch): the whole solve in one launch of one workgroup per tree",
                   1: "one Newton iteration = f_back x tiers, f_top, f_fwd x tiers, f_stage, k_ls_decide (tiered path)",
-                  0: "one Newton iteration = k_grad, k_check, k_hess(_w), k_factor(_w) x levels, k_forward(_w) x levels, k_ls_*, k_stage (launch per level; _w = MFMA workgroup-per-block kernels)"}[g.path]
+                  0: "blocks of 16 < d <= 64 rows: one Newton iteration = k_sgp (stage + gradient + Armijo / termination tails), k_hf_w (H + backward sweep with panel look-ahead, MFMA), k_fwd3 (forward sweep + direction test); other trees on this path: k_grad, k_check, k_hess, k_factor_all, k_forward_all, k_ls_*, k_stage"}[g.path]
         out = {
             "metric": "dual_newton_iterations_per_second",
             "value": tot_iters / tmax,

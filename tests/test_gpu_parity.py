@@ -268,6 +268,49 @@ def test_wide_block_kernels_regularisation(gpu, orc, reg):
     g.close()
 
 
+# --- the wide-block class in three launches per Newton iteration (tdunes_wide3.hpp) -------------
+
+@pytest.mark.parametrize("reg", [0, 1, 2], ids=["no_reg", "always", "on_the_fly"])
+def test_three_launch_family_matches_oracle_and_launch_per_phase(gpu, orc, reg):
+    """k_sgp / k_hf_w / k_fwd3 (stage + gradient + tails; H + backward sweep + forward preparation; forward sweep + tail) against the
+    oracle and against the launch-per-phase kernels they stand in for (TREEQP_AMD_NO_WIDE3=1), on bounded problems with d = 24
+    blocks, variable numbers of children, several Newton iterations and line-search trials, under every regularisation mode
+    (on-the-fly with a tolerance that makes blocks refactorise).  Same verdict, iteration and trial counts; 3 launches per
+    iteration + 1 instead of 11."""
+    extra_trials = 0
+    for f in (P.pruned_chain_qp(), P.pruned_chain_qp(Nh=6, seed=5)):
+        opts = dict(f.opts)
+        # (the 83-node tree under a constant shift of 1e-6 is an ill-conditioned case -- the oracle needs 13 iterations and 410
+        # trials -- in which no two implementations take the same path: it keeps the 1e-10 of fault_tolerance.c:449-469)
+        opts.update(regType=reg, regValue=1e-6 if (reg != 1 or len(f.nk) > 100) else 1e-10, regTol=1e-3 if reg == 2 else 1e-6)
+        ref = orc.solve(f.as_dict(), orc.default_opts(**opts), lambda0=f.lambda0)
+        r3, s3, _ = _solve_flat_tq(gpu, f.as_dict(), f.lambda0, "generic", **opts)
+        os.environ["TREEQP_AMD_NO_WIDE3"] = "1"
+        try:
+            r1, s1, _ = _solve_flat_tq(gpu, f.as_dict(), f.lambda0, "generic", **opts)
+        finally:
+            os.environ.pop("TREEQP_AMD_NO_WIDE3", None)
+        for r in (r3, r1):
+            assert (r["status"], r["iter"], r["ls_total"]) == (ref["status"], ref["iter"], ref["ls_total"])
+        assert ref["iter"] >= 3
+        extra_trials += ref["ls_total"] - ref["iter"]
+        assert_solution_close(s3, ref, TOL)
+        assert_solution_close(s1, ref, TOL)
+        assert r3["n_launches"] < r1["n_launches"]                                # 3 launches per iteration against 5 (small trees: reductions as sweep tails) or 11
+    assert extra_trials > 0                                                        # the cases have what they are meant to exercise
+
+
+def test_three_launch_family_c4_launch_count(gpu, orc):
+    """BASELINE config C4 (3280 nodes, 60 x 60 blocks, one Newton iteration): k_sgp, k_hf_w, k_fwd3, k_sgp."""
+    f = P.random_clipping_qp()
+    g = gpu.TqGpu(f.nk, f.nx, f.nu).upload(f.as_dict(), f.lambda0)
+    assert g.path == 0
+    g.solve(**f.opts)
+    r = g.solve(**f.opts)                                                        # (the first solve also runs k_init and enqueues a chunk of iterations ahead)
+    assert (r["status"], r["iter"], r["n_launches"]) == (0, 1, 4)
+    g.close()
+
+
 # --- full BASELINE sizes: size-independent properties ------------------------------------------
 
 @pytest.mark.parametrize("make", [lambda: P.linear_chain(2, 11, 11)], ids=["c3_chain_4095"])

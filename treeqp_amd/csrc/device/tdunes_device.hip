@@ -298,7 +298,9 @@ __device__ __forceinline__ double dot_batched(const double *a, int sa, const dou
 /* ------------------------------------------------------------------------------------------ */
 /* xu != nullptr (k_sg): x, u of a PARENT node are also posted as tagged words -- entry j of x at xu[2 (xoff + j)], of u at
  * xu[2 (sum_nx + uoff + j)] -- for the children's gradient in the same launch */
-__device__ void stage_body(const Tree &T, const Data &D, int mode, int k, int lane, double *lds, bool batch = true, u64 *xu = nullptr, int sum_nx = 0, unsigned xtag = 0u) {
+/* Cl != nullptr (k_sgp): the children's [A | B], rows stacked child after child, column major with leading dimension ldcl, are in LDS */
+__device__ void stage_body(const Tree &T, const Data &D, int mode, int k, int lane, double *lds, bool batch = true, u64 *xu = nullptr, int sum_nx = 0, unsigned xtag = 0u,
+                           const double *Cl = nullptr, int ldcl = 0) {
     const Ctrl *c = D.ctrl;
     const int nxk = T.nx[k], nuk = T.nu[k], xo = T.xoff[k], uo = T.uoff[k];
     const int nkid = T.nk[k], d = T.bdim[k];
@@ -378,9 +380,9 @@ __device__ void stage_body(const Tree &T, const Data &D, int mode, int k, int la
         int rowoff = 0;
         for (int cc = 0; cc < nkid; cc++) {
             const int kid = T.kid0[k] + cc, nxc = T.nx[kid];
-            const double *col = isx ? D.A + T.aoff[kid] + (size_t)j * nxc : D.B + T.boff[kid] + (size_t)j * nxc;
+            const double *col = Cl ? Cl + rowoff + (size_t)t * ldcl : (isx ? D.A + T.aoff[kid] + (size_t)j * nxc : D.B + T.boff[kid] + (size_t)j * nxc);
             double acc = 0.0;
-            acc = dot_batched(col, 1, lk + rowoff, 1, nxc, acc, batch);
+            acc = dot_batched(col, 1, lk + rowoff, 1, nxc, acc, batch && !Cl);
             v = fma(-1.0, acc, v);
             rowoff += nxc;
         }
@@ -1042,7 +1044,9 @@ struct tqgpu_solver {
     unsigned long long *w3_xu = nullptr, *w3_red = nullptr;
     int *w3_cnt = nullptr;
     unsigned w3_epoch = 0;
-    size_t lds_hf_w = 0;
+    size_t lds_hf_w = 0, lds_sgp = 0;
+    int sgp_accs = 0;
+    bool w3_sgp = false;                /* k_sgp (a workgroup per parent) instead of k_sg (a wave per node) */
     bool dense = false, need_dense_init = false;   /* dense unconstrained stage solver selected (generic path only) */
     double *d_Hd = nullptr;      /* writable alias of Data.Hd */
     int *d_kind = nullptr;       /* writable alias of Data.kind */
@@ -1518,6 +1522,7 @@ static W3 next_w3(tqgpu_solver *s) {
     return w;
 }
 static void launch_sg(tqgpu_solver *s, const Opts &O, int mode, int h, int t) {
+    if (s->w3_sgp) { hipLaunchKernelGGL(k_sgp, dim3(s->T.Np), dim3(WT), s->lds_sgp, s->stream, s->T, s->D, O, next_w3(s), mode, h, t, s->sgp_accs); return; }
     const int grid = (s->T.Nn + SG_WAVES - 1) / SG_WAVES;
     hipLaunchKernelGGL(k_sg, dim3(grid), dim3(SG_WAVES * WAVE), SG_WAVES * ((s->lds_stage + 7) / 8) * 8, s->stream, s->T, s->D, O, next_w3(s), mode, h, t);
 }
@@ -2006,11 +2011,11 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
             s->fuse_ok = true;
         }
     }
-    if (s->wide && !getenv("TREEQP_AMD_NO_WIDE3")) {
+    if (s->wide && s->fw_fused && s->bw_fused && !getenv("TREEQP_AMD_NO_WIDE3")) {      /* (TREEQP_AMD_FWD / BWD = levels ask for the launch-per-level kernels) */
         /* the three-launch family of the wide-block class (tdunes_wide3.hpp) */
         int nxmax = 0;
         for (int k = 0; k < Nn; k++) { nxmax = std::max(nxmax, s->nx[k]); if (k < s->Np) s->lds_hf_w = std::max(s->lds_hf_w, wide3_lds(s->bdim[k], k > 0 ? s->nx[k] : 0, s->nx[k] + s->nu[k])); }
-        const size_t groups = (size_t)(Nn + SG_WAVES - 1) / SG_WAVES;
+        const size_t groups = std::max((size_t)(Nn + SG_WAVES - 1) / SG_WAVES, (size_t)s->Np);      /* workgroups of k_sg / k_sgp / k_fwd3 */
         const size_t xb = sizeof(unsigned long long) * 2 * (size_t)std::max(s->sum_nx + s->sum_nu, 1), rb = sizeof(unsigned long long) * 4 * groups;
         if (nxmax <= 32 && s->lds_hf_w <= 160 * 1024 && SG_WAVES * s->lds_stage <= 160 * 1024) {
             if (hipMalloc(&s->w3_xu, xb) != hipSuccess || hipMemset(s->w3_xu, 0, xb) != hipSuccess ||
@@ -2018,6 +2023,12 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
                 hipMalloc(&s->w3_cnt, 4 * sizeof(int)) != hipSuccess || hipMemset(s->w3_cnt, 0, 4 * sizeof(int)) != hipSuccess)
                 return cleanup_fail(fail(TQGPU_ENOMEM, "hipMalloc failed for the three-launch hand-over words"));
             if ((rc = allow_lds(k_hf_w, s->lds_hf_w)) || (rc = allow_lds(k_sg, SG_WAVES * ((s->lds_stage + 7) / 8) * 8))) return cleanup_fail(rc);
+            /* k_sgp: one entry of a node's [x | u] per lane, one row of a block per lane */
+            bool fits = true;
+            for (int k = 0; k < Nn; k++) fits = fits && s->nx[k] + s->nu[k] <= 64;
+            for (int k = 0; k < s->Np; k++) s->sgp_accs = std::max(s->sgp_accs, std::min(s->nk[k], 8) * (s->nx[k] + s->nu[k]));      /* the children's terms in LDS: up to 8 children (more: taken by wave 0 on its own) */
+            for (int k = 0; k < s->Np; k++) s->lds_sgp = std::max(s->lds_sgp, wide3_lds_sgp(s->bdim[k], s->nx[k] + s->nu[k], s->sgp_accs));
+            s->w3_sgp = fits && s->lds_sgp <= 64 * 1024 && !getenv("TREEQP_AMD_NO_SGP");
             s->w3_ok = true;
         }
     }
@@ -2135,6 +2146,16 @@ extern "C" int tqgpu_uses_fused_path(const tqgpu_solver *s) {
 
 /* diagnostic: copy the in-kernel time stamps of the last fused iteration (8 kernels x 32 slots x
  * {shader clock, 100 MHz wall clock}); only filled when TREEQP_AMD_STAMPS is set */
+/* diagnostic builds (-DTQ_WIDE_STAMPS): per-block time stamps of k_hf_w, four 64-bit words per block kept in the (otherwise unused) CholW array */
+extern "C" int tqgpu_debug_block_stamps(tqgpu_solver *s, unsigned long long *out, int cap_blocks) {
+    if (!s || !out) return fail(TQGPU_EINVAL, "bad arguments");
+    std::vector<double> tmp((size_t)std::max(s->sum_W, 1));
+    HIP_TRY(hipMemcpy(tmp.data(), getenv("TQ_STAMPS_OF_SGP") ? s->D.W : s->D.CholW, sizeof(double) * (size_t)s->sum_W, hipMemcpyDeviceToHost));
+    const int n = std::min(cap_blocks, s->Np);
+    for (int k = 0; k < n; k++) memcpy(out + 4 * (size_t)k, tmp.data() + s->woff[k], 4 * sizeof(unsigned long long));
+    return n;
+}
+
 extern "C" int tqgpu_get_stamps(tqgpu_solver *s, unsigned long long *out, int cap) {
     if (!s || !out) return fail(TQGPU_EINVAL, "bad arguments");
     const int n = std::min(cap, 8 * 32 * 2 + 1024);

@@ -179,6 +179,272 @@ __global__ void __launch_bounds__(SG_WAVES * WAVE) k_sg(Tree T, Data D, Opts O, 
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* k_sgp: k_sg with one workgroup per PARENT.  The children's [A | B] (the matrix C of the dual Hessian block) is fetched once,     */
+/* coalesced, into LDS and serves the parent's stage QP (C' lambda) and the children's gradients (C [x; u]); everything else a node */
+/* needs from global memory (duals, step, weights, bounds, linear terms) is requested up front, ONE round trip.  k_sg's waves each   */
+/* walk the index tables and their node's columns of A and B in global memory: ~14 dependent batches of loads per node at nx = 20,  */
+/* 9 us of a node's 10.  Work of workgroup p: stage QP of node p (wave 0) and of its LEAF children (waves 1 ..; a child that is a    */
+/* parent is staged by its own workgroup), gradient of every child (a wave each).  A child that is a parent hands its x over as     */
+/* tagged words; workgroups are numbered children first, so what is waited for is running or done.  Per node the arithmetic is      */
+/* stage_body's / grad_body's, operation for operation (bit-identical x, u, res, dual terms); the sums over nodes are per workgroup. */
+/* Same tails as k_sg.  Needs nx + nu <= 64 and d <= 64 per node (true for the wide-block class).                                    */
+/* ------------------------------------------------------------------------------------------ */
+struct SgNode { double lam, dl, qv, qi, lo, hi, wd, old; };      /* one entry of a node's [x | u]: what stage_body reads for it */
+
+__device__ __forceinline__ void sgp_load(const Data &D, const double *lamc, int mode, bool save_s, bool own, int nxk, int nuk, int xo, int uo, int lane, SgNode &n) {
+    const bool isx = lane < nxk, in = lane < nxk + nuk;
+    const int j = !in ? 0 : (isx ? lane : lane - nxk);
+    const int ix = xo + (isx ? j : 0), iu = uo + (isx ? 0 : j);
+    /* (clamped addresses, masked use: every load of the node goes out together) */
+    n.lam = lamc[ix]; n.dl = D.dlam[ix];
+    n.qv = isx ? D.q[ix] : D.r[iu];
+    n.qi = isx ? D.Qinv[ix] : D.Rinv[iu];
+    n.lo = isx ? D.xmin[ix] : D.umin[iu];
+    n.hi = isx ? D.xmax[ix] : D.umax[iu];
+    n.wd = isx ? D.Qd[ix] : D.Rd[iu];
+    n.old = isx ? D.xUnc[ix] : D.uUnc[iu];
+    (void)mode; (void)save_s; (void)own;
+}
+/* the clipping stage QP of one node, one entry per lane (stage_body, clipping branch, lines in the same order); v0 = -q + lambda_own
+ * resp. -r, minus the children's terms, is passed in; returns the node's dual term (valid in every lane) */
+__device__ __forceinline__ double sgp_finish(const Data &D, const SgNode &n, double v, double p_c, bool save_s, int nxk, int nuk, int xo, int uo, int lane, double &xout) {
+    const bool isx = lane < nxk, in = lane < nxk + nuk;
+    const int j = isx ? lane : lane - nxk;
+    double p_qx = 0.0, p_hx = 0.0, p_ru = 0.0, p_hu = 0.0;
+    xout = 0.0;
+    if (in) {
+        const double unc = n.qi * v;
+        double xv, cal;
+        if (unc >= n.hi) { xv = n.hi; cal = 0.0; } else if (unc <= n.lo) { xv = n.lo; cal = 0.0; } else { xv = unc; cal = n.qi; }
+        xout = xv;
+        if (isx) {
+            D.qmod[xo + j] = v;
+            if (save_s) D.xUncS[xo + j] = n.old;
+            D.xUnc[xo + j] = unc; D.x[xo + j] = xv; D.QinvCal[xo + j] = cal;
+            p_qx = fma(n.wd * xv, xv, p_qx);
+            p_hx = fma(v, xv, p_hx);
+        } else {
+            D.rmod[uo + j] = v;
+            if (save_s) D.uUncS[uo + j] = n.old;
+            D.uUnc[uo + j] = unc; D.u[uo + j] = xv; D.RinvCal[uo + j] = cal;
+            p_ru = fma(n.wd * xv, xv, p_ru);
+            p_hu = fma(v, xv, p_hu);
+        }
+    }
+    p_qx = wave_sum(p_qx); p_hx = wave_sum(p_hx); p_ru = wave_sum(p_ru); p_hu = wave_sum(p_hu); p_c = wave_sum(p_c);
+    double f = -0.5 * p_qx - p_c;       /* clipping.c:375 */
+    f += p_hx;                          /* :376 */
+    f -= 0.5 * p_ru;                    /* :380 */
+    f += p_hu;                          /* :381 */
+    return f;
+}
+
+#ifdef TQ_WIDE_STAMPS
+#define SGSTAMP(k_) do { if (tid == 0) reinterpret_cast<unsigned long long *>(D.W + e[8])[k_] = wall_clock64(); } while (0)
+#else
+#define SGSTAMP(k_) do { } while (0)
+#endif
+__global__ void __launch_bounds__(WT) k_sgp(Tree T, Data D, Opts O, W3 Wd, int mode, int h, int t, int accs_cap) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ double part[2][WW];
+    Ctrl *c = D.ctrl;
+    const int p = T.Np - 1 - (int)blockIdx.x;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int e[28];
+#pragma unroll
+    for (int i = 0; i < 28; i++) e[i] = T.desc[(size_t)DESC_INTS * p + i];
+    const int cur = c->cur, ls_iter = c->ls_iter;
+    const double step = c->tau - c->tauPrev;
+    if (mode == 1 && !phase_trial(c, h, t)) return;
+    const int d = e[0], nxp = e[1], nup = e[2], nkp = e[3], k0 = e[4], nz = nxp + nup, xop = e[5], uop = e[6], ko = e[7];
+    SGSTAMP(0);
+    const bool save_s = mode == 1 && ls_iter == 1;      /* first trial of a line search: xUnc / uUnc still hold phase S of this iteration */
+    const double *lamc = cur ? D.lam1 : D.lam0;
+    double *lamn = cur ? D.lam0 : D.lam1;
+    const int ldc = d | 1;
+    lds_ptr Cs = to_lds(lds);                           /* d x nz, leading dimension ldc (odd: lanes over rows and lanes over columns both spread over the banks) */
+    lds_ptr lkl = Cs + ldc * nz;                        /* duals of the children = the dual block of node p (at the trial point in mode 1) */
+    lds_ptr bl = lkl + 64;                              /* b of the children */
+    lds_ptr xpl = bl + 64;                              /* [x_p | u_p] */
+    lds_ptr xkl = xpl + 64;                             /* x of the leaf children */
+    lds_ptr accs = xkl + 64;                            /* [child][entry of node p]: that child's term of C' lambda */
+    const bool kids_are_leaves = k0 >= T.Np;
+
+    /* ---- everything a node needs from global memory, requested together ---- */
+    SgNode nd;
+    double lamk = 0.0, dlk = 0.0, bk = 0.0;
+    int nxl = 0, nul = 0, xol = 0, uol = 0, ccl = -1, rowl = 0;        /* waves 1 ..: the leaf child this wave stages (first round) */
+    if (wave == 0) {
+        sgp_load(D, lamc, mode, save_s, p > 0, nxp, nup, xop, uop, lane, nd);
+        const int tt = lane < d ? lane : 0;
+        lamk = lamc[ko + tt]; dlk = D.dlam[ko + tt]; bk = D.b[ko + tt];
+    } else if (kids_are_leaves && wave - 1 < nkp) {
+        ccl = wave - 1;
+        const int kid = k0 + ccl;
+        nxl = ccl == 0 ? e[16] : ccl == 1 ? e[19] : e[22];
+        rowl = ccl == 0 ? 0 : ccl == 1 ? e[16] : e[16] + e[19];
+        nul = T.nu[kid]; xol = ko + rowl; uol = T.uoff[kid];
+        sgp_load(D, lamc, mode, save_s, true, nxl, nul, xol, uol, lane, nd);
+    }
+    /* ---- C: rows on the lanes, columns dealt over the waves, eight loads in flight per thread and child ---- */
+    for (int cc = 0, rowoff = 0; cc < nkp; cc++) {
+        const int kid = k0 + cc;
+        const bool rec = cc < 4;
+        const int rnx = cc == 0 ? e[16] : cc == 1 ? e[19] : cc == 2 ? e[22] : e[25];
+        const int rao = cc == 0 ? e[17] : cc == 1 ? e[20] : cc == 2 ? e[23] : e[26];
+        const int rbo = cc == 0 ? e[18] : cc == 1 ? e[21] : cc == 2 ? e[24] : e[27];
+        const int nxc = rec ? rnx : T.nx[kid];
+        const double *A = D.A + (rec ? rao : T.aoff[kid]), *B = D.B + (rec ? rbo : T.boff[kid]);
+        const bool rowok = lane < nxc;
+        const int i = rowok ? lane : 0;
+        for (int c0 = 0; c0 < nz; c0 += 8 * WW) {
+            double a[8];
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                const int col = c0 + wave + WW * m;
+                const int cs = (rowok && col < nz) ? col : 0;
+                const bool st = cs < nxp;
+                a[m] = (st ? A : B)[i + (st ? cs : cs - nxp) * nxc];
+            }
+            LOADS_DONE();
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                const int col = c0 + wave + WW * m;
+                if (rowok && col < nz) Cs[rowoff + i + col * ldc] = a[m];
+            }
+        }
+        rowoff += nxc;
+    }
+    if (wave == 0 && lane < d) { lkl[lane] = mode == 1 ? fma(step, dlk, lamk) : lamk; bl[lane] = bk; }
+    __syncthreads();
+    SGSTAMP(1);
+    /* ---- the children's terms of C' lambda: thread (child, entry), the products of a child in ascending row order ---- */
+    if (nkp * nz <= accs_cap) {
+        int rowoff = 0;
+        for (int cc = 0; cc < nkp; cc++) {
+            const int nxc = cc == 0 ? e[16] : cc == 1 ? e[19] : cc == 2 ? e[22] : cc == 3 ? e[25] : T.nx[k0 + cc];
+            if ((cc & (WW - 1)) == wave && lane < nz) {
+                double acc = 0.0;
+                for (int i = 0; i < nxc; i++) acc = fma(Cs[rowoff + i + lane * ldc], lkl[rowoff + i], acc);
+                accs[cc * nz + lane] = acc;
+            }
+            rowoff += nxc;
+        }
+    }
+    __syncthreads();
+    double fv = 0.0;
+    if (wave == 0) {
+        /* node p */
+        const bool isx = lane < nxp, in = lane < nz;
+        double lown = 0.0;
+        if (p > 0 && isx) { lown = mode == 1 ? fma(step, nd.dl, nd.lam) : nd.lam; if (mode == 1) lamn[xop + lane] = lown; }
+        double v = isx ? fma(-1.0, nd.qv, lown) : -1.0 * nd.qv;
+        if (in) {
+            if (nkp * nz <= accs_cap) { for (int cc = 0; cc < nkp; cc++) v = fma(-1.0, accs[cc * nz + lane], v); }
+            else {
+                int rowoff = 0;
+                for (int cc = 0; cc < nkp; cc++) {
+                    const int nxc = T.nx[k0 + cc];
+                    double acc = 0.0;
+                    for (int i = 0; i < nxc; i++) acc = fma(Cs[rowoff + i + lane * ldc], lkl[rowoff + i], acc);
+                    v = fma(-1.0, acc, v);
+                    rowoff += nxc;
+                }
+            }
+        }
+        const double p_c = lane < d ? fma(bl[lane], lkl[lane], 0.0) : 0.0;      /* cmod = sum_kids b_kid' lambda_kid */
+        double xv;
+        const double f = sgp_finish(D, nd, v, p_c, save_s, nxp, nup, xop, uop, lane, xv);
+        if (in) {
+            xpl[lane] = xv;
+            if (p > 0 && isx) st_tag(Wd.xu + 2 * (size_t)(xop + lane), xv, Wd.tag);          /* the parent's workgroup waits for x of node p */
+        }
+        if (lane == 0) { D.fval[p] = f; fv = f; }
+    } else if (kids_are_leaves) {
+        /* leaf children: no children's terms */
+        for (int cc = wave - 1; cc < nkp; cc += WW - 1) {
+            if (cc != ccl) {
+                /* (more than three children: later rounds fetch theirs now) */
+                const int kid = k0 + cc;
+                nxl = T.nx[kid]; nul = T.nu[kid]; xol = T.xoff[kid]; uol = T.uoff[kid]; rowl = xol - ko;
+                sgp_load(D, lamc, mode, save_s, true, nxl, nul, xol, uol, lane, nd);
+            }
+            const bool isx = lane < nxl;
+            double lown = 0.0;
+            if (isx) { lown = mode == 1 ? fma(step, nd.dl, nd.lam) : nd.lam; if (mode == 1) lamn[xol + lane] = lown; }
+            const double v = isx ? fma(-1.0, nd.qv, lown) : -1.0 * nd.qv;
+            double xv;
+            const double f = sgp_finish(D, nd, v, 0.0, save_s, nxl, nul, xol, uol, lane, xv);
+            if (isx) xkl[rowl + lane] = xv;
+            if (lane == 0) { D.fval[k0 + cc] = f; fv += f; }
+        }
+    }
+    SGSTAMP(2);
+    __syncthreads();
+    /* ---- gradient of the children: a wave per child, rows on the lanes (grad_body) ---- */
+    const bool mx = O.termCondition == 2;
+    double er = 0.0;
+    {
+        int rowoff = 0;
+        for (int cc = 0; cc < nkp; cc++) {
+            const int kid = k0 + cc;
+            const int nxc = cc == 0 ? e[16] : cc == 1 ? e[19] : cc == 2 ? e[22] : cc == 3 ? e[25] : T.nx[kid];
+            if ((cc & (WW - 1)) == wave) {
+                const int xo = ko + rowoff;
+                double part_k = 0.0;
+                if (lane < nxc) {                       /* (nx <= 64) */
+                    const int i = lane;
+                    double xk;
+                    if (kid < T.Np) { bool dead = false; xk = wait_tag(Wd.xu + 2 * (size_t)(xo + i), Wd.tag, dead); if (dead) { c->status = 3; __hip_atomic_store(&c->done, 1, RLX, AGENT); } }
+                    else xk = xkl[rowoff + i];
+                    double rv = fma(-1.0, xk, bl[rowoff + i]);
+                    double acc = 0.0;
+                    for (int j = 0; j < nxp; j++) acc = fma(Cs[rowoff + i + j * ldc], xpl[j], acc);
+                    rv += acc;
+                    acc = 0.0;
+                    for (int j = 0; j < nup; j++) acc = fma(Cs[rowoff + i + (nxp + j) * ldc], xpl[nxp + j], acc);
+                    rv += acc;
+                    D.res[xo + i] = rv;
+                    D.resMod[xo + i] = rv;
+                    part_k = mx ? nanmax(part_k, fabs(rv)) : fma(rv, rv, part_k);
+                }
+                part_k = mx ? wave_max(part_k) : wave_sum(part_k);
+                if (lane == 0) D.part_err[kid] = part_k;
+                er = mx ? nanmax(er, part_k) : er + part_k;
+            }
+            rowoff += nxc;
+        }
+    }
+    if (lane == 0) { part[0][wave] = fv; part[1][wave] = er; }
+    __syncthreads();
+    SGSTAMP(3);
+    if (wave != 0) return;
+    if (lane == 0) {
+        double f = 0.0, ee = 0.0;
+#pragma unroll
+        for (int w = 0; w < WW; w++) { f += part[0][w]; ee = mx ? nanmax(ee, part[1][w]) : ee + part[1][w]; }
+        st_tag(Wd.red + ((size_t)2 * blockIdx.x + 0) * 2, f, Wd.tag);
+        st_tag(Wd.red + ((size_t)2 * blockIdx.x + 1) * 2, ee, Wd.tag);
+    }
+    Fuse F; F.red = nullptr; F.cnt = Wd.cnt; F.tag = Wd.tag; F.on = 1;
+    if (!fuse_last(F, (int)gridDim.x, lane)) return;
+    double f, err;
+    w3_reduce2(Wd.red, (int)gridDim.x, Wd.tag, lane, mx, f, err);
+    if (lane == 0) {
+        bool test = true;
+        if (mode == 0) { c->fval0 = f; c->fval = f; }
+        else { ls_decide_tail(c, D, O, f); test = !c->done && !c->ls_pending; }
+        if (test) {
+            if (O.termCondition == 1) err = sqrt(err);
+            c->err = err;
+            if (err < O.tol) { c->done = 1; c->status = 0; }      /* TREEQP_OPTIMAL_SOLUTION_FOUND */
+        }
+    }
+}
+/* LDS of k_sgp: C, the four 64-entry vectors, the children's terms */
+static inline size_t wide3_lds_sgp(int d, int nz, int accs) { return ((size_t)(d | 1) * nz + 4 * 64 + accs) * sizeof(double); }
+
+/* ------------------------------------------------------------------------------------------ */
 /* k_hf_w: H + backward sweep + preparation of the forward sweep, one workgroup per block       */
 /* ------------------------------------------------------------------------------------------ */
 /* left-looking tall Cholesky of the first NC columns of a 16-column panel, one row per lane (p_potrf_rows with a
@@ -284,9 +550,12 @@ __device__ __forceinline__ bool w3_schur_tile(int wave, int slot, int nt2, int &
 #define TQ_STAMP_BLOCK 0
 #endif
 #ifdef TQ_WIDE_STAMPS      /* diagnostic builds: time stamps of the root block (slots 0..) and of the last block (slots 32..), thread 0 */
+/* per-block stamps (start, records in, record posted, end) into CholW, which this kernel family does not use */
+#define W3BSTAMP(k_) do { if (wave == 0 && lane == 0) reinterpret_cast<unsigned long long *>(D.CholW + e[8])[k_] = wall_clock64(); } while (0)
 #define W3STAMP(slot) do { if (wave == 0 && lane == 0 && (ii == TQ_STAMP_BLOCK || ii == T.Np - 1)) { const int b_ = (ii == TQ_STAMP_BLOCK ? 0 : 32) + (slot); D.stamps[2 * b_] = clock64(); D.stamps[2 * b_ + 1] = wall_clock64(); } } while (0)
 #else
 #define W3STAMP(slot) do { } while (0)
+#define W3BSTAMP(k_) do { } while (0)
 #endif
 #ifdef TQ_W3_SYNC
 #define W3_BARRIER() __syncthreads()
@@ -340,6 +609,7 @@ __global__ void __launch_bounds__(WT, TQ_W3_WPS) k_hf_w(Tree T, Data D, Opts O, 
     f64x4 gacc[3];                             /* waves 2, 3: Schur tiles */
 
     W3STAMP(0);
+    W3BSTAMP(0);
     for (int pass = 0; pass < 2; pass++) {
         const double shift = (O.regType == 1 || pass == 1) ? O.regValue : 0.0;         /* ddiare */
         if (tid == 0) small_flag = 0;
@@ -527,6 +797,7 @@ __global__ void __launch_bounds__(WT, TQ_W3_WPS) k_hf_w(Tree T, Data D, Opts O, 
             W3_BARRIER();
         }
         W3STAMP(3);
+        W3BSTAMP(1);
 
         /* ---- blocked tall Cholesky with look-ahead ---- */
 #pragma unroll
@@ -650,6 +921,7 @@ __global__ void __launch_bounds__(WT, TQ_W3_WPS) k_hf_w(Tree T, Data D, Opts O, 
     }
     W3_BARRIER();                           /* the substitution below overwrites the rows the Schur term was just read from */
     W3STAMP(12);
+    W3BSTAMP(2);
 
     /* ---- forward sweep prepared: Xt <- Xt L^-1 (rows dp ..: row 0 becomes z0 = L^-T y, row 1 + i column i of M = L^-T CholUt'), blocked
      * from the last column panel to the first, the inverses of the diagonal tiles from the identity rows.  Row tile a of Xt is wave a's:
@@ -723,6 +995,7 @@ __global__ void __launch_bounds__(WT, TQ_W3_WPS) k_hf_w(Tree T, Data D, Opts O, 
             if (lane == 0) D.part_dot[0] = pd;
         }
         W3STAMP(13);
+        W3BSTAMP(3);
     }
 }
 
