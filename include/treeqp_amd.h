@@ -146,6 +146,32 @@ int tqgpu_shard_gather_solution(tqgpu_solver *s);
 /* test / diagnostic: n virtual ranks of one tree in one process on one device, lock-step */
 int tqgpu_solve_virtual_ranks(tqgpu_solver **ranks, int n, const tqgpu_opts *opts, tqgpu_result *res);
 
+/* ---- one tree sharded over several devices INSIDE the persistent launch ----------
+ * The workgroups of the single persistent launch (one per tier subtree, tdunes_persist.hpp) are dealt over one launch per
+ * rank: tiers whose subtree count is a multiple of the number of ranks by contiguous subtree ranges (the independent subtrees
+ * of dual_Newton_tree.c:668-775), the tiers above them to rank 0.  What crosses ranks -- the Schur push of
+ * dual_Newton_tree.c:726-732, the forward pull of :768-769, the global scalars of :542, :944-945, :970 -- travels as the
+ * same tagged words as on one device: every rank has a hand-over slab, a producer writes each word into every rank's slab
+ * (system-scope stores into peer-mapped memory), a consumer polls its own.  No collective and no host in the loop; the
+ * solution is collected afterwards by any transport (tqgpu_pshard_pack / _unpack: equal-sized buffers for an all-gather).
+ *   tqgpu_pshard_init          this mirror (whole tree created, whole problem uploaded) becomes rank `rank` of `nranks` (<= 8)
+ *   tqgpu_pshard_connect_local peer r is another mirror of this process (same device: rehearsal; other device: peer access)
+ *   tqgpu_pshard_ipc_export / _ipc_connect   peers in other processes: 64-byte IPC handle of the slab out / of peer r in
+ *   tqgpu_pshard_begin / _end  one solve: enqueue this rank's launch / wait for the verdict.  All ranks' launches must be in
+ *                              flight together (they wait for each other: bounded, TQGPU_ETIMEOUT after 0.5 s) and every rank
+ *                              must solve the same number of times (the launch number tags the words)
+ *   tqgpu_pshard_solve_local   n mirrors of one process: connect, solve, collect the solution into every mirror */
+int tqgpu_pshard_init(tqgpu_solver *s, int rank, int nranks);
+int tqgpu_pshard_connect_local(tqgpu_solver *s, int r, tqgpu_solver *peer);
+int tqgpu_pshard_ipc_export(tqgpu_solver *s, void *handle64);
+int tqgpu_pshard_ipc_connect(tqgpu_solver *s, int r, const void *handle64);
+int tqgpu_pshard_begin(tqgpu_solver *s, const tqgpu_opts *opts);
+int tqgpu_pshard_end(tqgpu_solver *s, tqgpu_result *res);
+long tqgpu_pshard_pack_size(tqgpu_solver *s);
+int tqgpu_pshard_pack(tqgpu_solver *s, double *out, long cap);
+int tqgpu_pshard_unpack(tqgpu_solver *s, int src_rank, const double *in, long n_in);
+int tqgpu_pshard_solve_local(tqgpu_solver **ranks, int n, const tqgpu_opts *opts, tqgpu_result *res);
+
 /* n solves of the same problem from the same starting duals, one after the other, each waiting for its verdict: the timing loop
  * of the reference's drivers (examples/spring_mass_dual_newton_tree.c:135-140, `for (jj = 0; jj < NREP; jj++)
  * treeqp_tdunes_solve(...)`) in C.  res: the last solve; sums over the solves in *iter_sum, *ls_sum, *launch_sum (each may be NULL). */

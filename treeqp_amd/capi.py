@@ -423,6 +423,29 @@ def solve_virtual_ranks(mirrors, **kw) -> dict:
     return {f: getattr(r, f) for f, _ in GpuResult._fields_}
 
 
+def _default_opts(**kw):
+    o = GpuOpts(maxIter=100, termCondition=2, stationarityTolerance=1e-8, regType=2, regTol=1e-6, regValue=1e-6,
+                lineSearchMaxIter=50, lineSearchGamma=0.1, lineSearchBeta=0.6, lineSearchRestartTrigger=-1, profile=0, checkLastActiveSet=1)
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise KeyError(k)
+        setattr(o, k, v)
+    return o
+
+
+def pshard_solve_local(mirrors, **kw) -> list:
+    """ONE tree over the n mirrors of this process, inside the persistent launch: n launches that wait for each other (tagged
+    words in every mirror's slab).  Every mirror must be pshard_init(r, n); the solution is collected into every mirror."""
+    o = _default_opts(**kw)
+    n = len(mirrors)
+    arr = (C.c_void_p * n)(*[m.h for m in mirrors])
+    res = (GpuResult * n)()
+    rc = lib().tqgpu_pshard_solve_local(arr, n, C.byref(o), res)
+    if rc != 0:
+        raise RuntimeError(f"tqgpu_pshard_solve_local failed ({rc}): {lib().tqgpu_last_error().decode()}")
+    return [{f: getattr(res[i], f) for f, _ in GpuResult._fields_} for i in range(n)]
+
+
 def solve_batch(mirrors, profile=0, **kw) -> list:
     """Batched multi-tree solve: independent mirrors, same options; persistent launches run concurrently."""
     o = GpuOpts(maxIter=100, termCondition=2, stationarityTolerance=1e-8, regType=2, regTol=1e-6, regValue=1e-6,
@@ -589,6 +612,40 @@ class TqGpu:
 
     def shard_gather_solution(self):
         self._chk(lib().tqgpu_shard_gather_solution(self.h))
+
+    # ---- one tree sharded over several devices inside the persistent launch ----
+    def pshard_init(self, rank: int, nranks: int):
+        self._chk(lib().tqgpu_pshard_init(self.h, int(rank), int(nranks)))
+        return self
+
+    def pshard_ipc_export(self) -> bytes:
+        buf = C.create_string_buffer(64)
+        self._chk(lib().tqgpu_pshard_ipc_export(self.h, buf))
+        return bytes(buf.raw)
+
+    def pshard_ipc_connect(self, r: int, handle: bytes):
+        self._chk(lib().tqgpu_pshard_ipc_connect(self.h, int(r), C.create_string_buffer(bytes(handle), 64)))
+
+    def pshard_begin(self, **kw):
+        o = _default_opts(**kw)
+        self._chk(lib().tqgpu_pshard_begin(self.h, C.byref(o)))
+
+    def pshard_end(self) -> dict:
+        r = GpuResult()
+        self._chk(lib().tqgpu_pshard_end(self.h, C.byref(r)))
+        return {f: getattr(r, f) for f, _ in GpuResult._fields_}
+
+    def pshard_pack(self) -> np.ndarray:
+        L = lib()
+        L.tqgpu_pshard_pack_size.restype = C.c_long
+        n = int(L.tqgpu_pshard_pack_size(self.h))
+        out = np.zeros(max(n, 1), dtype=np.float64)
+        self._chk(L.tqgpu_pshard_pack(self.h, _dp(out), C.c_long(n)))
+        return out
+
+    def pshard_unpack(self, src_rank: int, buf: np.ndarray):
+        buf = _f64(buf)
+        self._chk(lib().tqgpu_pshard_unpack(self.h, int(src_rank), _dp(buf), C.c_long(len(buf))))
 
     def close(self):
         if self.h:

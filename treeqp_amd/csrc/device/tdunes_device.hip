@@ -1127,6 +1127,11 @@ struct tqgpu_solver {
     hipEvent_t batch_ev = nullptr;
     hipStream_t batch_stream = nullptr;                                   /* member of a batch launch in flight: the stream that launch is on (the lead's) */
     size_t sync_words_bytes = 0, lds_persist = 0;
+    /* ONE tree over several devices INSIDE the persistent launch (tqgpu_pshard_*): this rank's share of the workgroups */
+    bool pshard = false;
+    int *ps_wg_map = nullptr;       /* blockIdx.x -> workgroup id, this rank's workgroups (bottom tier first) */
+    int ps_G = 0;
+    void *ps_ipc[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      /* peer slabs opened through IPC handles (closed by tqgpu_destroy) */
     /* sharded mode */
     int nranks = 1, rank = 0, part_top = -1;      /* part_top: highest partitioned tier */
     bool sharded = false;     /* subtree-sharded mode (nranks > 1, or ONE rank with a communicator: the same code path, used to exercise the RCCL transport on a one-GPU box) */
@@ -1629,7 +1634,8 @@ int setup_persist(tqgpu_solver *s, int device) {
     const size_t n_parts = (size_t)G.G * 4, n_errs = (size_t)G.G * 2;
     const size_t n_bparts = (size_t)G.G * 16;
     const size_t n_sgt = (size_t)s->Nn * 2, n_rfl = (size_t)s->Nn * 2;      /* active-set signature / reuse flag of a tier subtree root (one tagged double each) */
-    const size_t bytes = (n_sch + n_dlt + n_ndt + n_parts + n_errs + 32 + n_bparts + n_sgt + n_rfl) * sizeof(unsigned long long);
+    const size_t n_verdict = 16;
+    const size_t bytes = (n_sch + n_dlt + n_ndt + n_parts + n_errs + 32 + n_bparts + n_sgt + n_rfl + n_verdict) * sizeof(unsigned long long);
     HIP_TRY(hipMalloc(&s->sync_slab, bytes));
     HIP_TRY(hipMemset(s->sync_slab, 0, bytes));
     s->sync_bytes = bytes;
@@ -1642,6 +1648,9 @@ int setup_persist(tqgpu_solver *s, int device) {
     s->psync.vrd = s->psync.errs + n_errs + 28;
     s->psync.bparts = s->psync.errs + n_errs + 32;
     s->psync.sgt = s->psync.bparts + n_bparts; s->psync.rfl = s->psync.sgt + n_sgt;
+    s->psync.verdict = s->psync.rfl + n_rfl;
+    s->psync.base = w; s->psync.npeer = 1;
+    for (int r = 0; r < 8; r++) s->psync.peer[r] = w;
     s->psync.seq = 0; s->psync.trip = 0;
     {
         const char *e = getenv("TREEQP_AMD_NAP");
@@ -1719,6 +1728,19 @@ int launch_persist(tqgpu_solver *s, const Opts &O, int &launches, int prologue, 
         s->stream_pending = true;
     }
     if (batch_seq) { launches++; return TQGPU_OK; }          /* the caller launches the batch */
+    if (s->pshard) {
+        /* this rank's share of the workgroups; the geometry (tiers, global workgroup numbers, G) is the whole tree's */
+        PGeom Gm = s->geom;
+        Gm.wg_of_block = s->ps_wg_map;
+        switch (s->fast) {
+#define X(idx, nx, nu, md) case idx: hipLaunchKernelGGL((f_persist<nx, nu, md, false>), dim3(s->ps_G), dim3(FW * WAVE), s->lds_persist, st, s->pconst, O, Gm, s->psync, prologue); break;
+            FAST_TABLE(X)
+#undef X
+            default: break;
+        }
+        launches++;
+        return TQGPU_OK;
+    }
     if (!s->mstage) {
         switch (s->fast) {
 #define X(idx, nx, nu, md) case idx: if (O.reuse) hipLaunchKernelGGL((f_persist<nx, nu, md, true>), dim3(s->geom.G), dim3(FW * WAVE), s->lds_persist, st, s->pconst, O, s->geom, s->psync, prologue); \
@@ -2108,6 +2130,8 @@ extern "C" void tqgpu_destroy(tqgpu_solver *s) {
     if (s->d_desc) (void)hipFree(s->d_desc);
     if (s->d_pitems) (void)hipFree(s->d_pitems);
     if (s->h_pitems) (void)hipHostFree(s->h_pitems);
+    if (s->ps_wg_map) (void)hipFree(s->ps_wg_map);
+    for (int r = 0; r < 8; r++) if (s->ps_ipc[r]) (void)hipIpcCloseMemHandle(s->ps_ipc[r]);
     if (s->w3_xu) (void)hipFree(s->w3_xu);
     if (s->w3_red) (void)hipFree(s->w3_red);
     if (s->w3_cnt) (void)hipFree(s->w3_cnt);
@@ -3064,6 +3088,216 @@ extern "C" int tqgpu_shard_gather_solution(tqgpu_solver *s) {
     for (auto &rg : ranges) NCCL_TRY(g_rccl.AllGather(rg.base + (size_t)s->rank * rg.per_rank, rg.base, rg.per_rank, NCCL_DOUBLE, s->comm, s->stream));
     NCCL_TRY(g_rccl.GroupEnd());
     HIP_TRY(hipStreamSynchronize(s->stream));
+    return TQGPU_OK;
+}
+
+/* ============================================================================================ */
+/* ONE tree over several devices INSIDE the persistent launch                                   */
+/* ============================================================================================ */
+/* The single-device persistent launch is a set of workgroups that talk through tagged words in one slab (tdunes_persist.hpp).
+ * Sharded, the SAME set of workgroups is dealt over one launch per device: tiers whose subtree count is a multiple of the number of
+ * ranks go to the ranks by contiguous subtree ranges, the tiers above them to rank 0 -- no workgroup exists twice,
+ * so there is nothing to keep consistent but the words themselves.  Every rank has a slab of the same layout; a producer writes
+ * each word into every slab (system-scope stores into peer-mapped memory), a consumer polls its own.  What crosses devices per
+ * Newton iteration: the Schur records and x / QinvCal of the boundary subtree roots and every workgroup's termination and
+ * dual-function partials upwards, the step of the boundary blocks, the line-search commands and the halt word downwards; no
+ * collective, no host in the loop.  RCCL (or any transport the caller has: tqgpu_pshard_pack / _unpack) is only used to collect
+ * the solution afterwards.  Every rank must call tqgpu_pshard_solve the same number of times (the launch number tags the words). */
+namespace {
+int pshard_part_top(const tqgpu_solver *s, int n) {
+    int top = -1;
+    for (int i = 0; i < s->n_tiers - 1; i++) if (s->tier_grid[i] % n == 0 && s->tier_grid[i] >= n) top = i;
+    return top;
+}
+}  // namespace
+
+extern "C" int tqgpu_pshard_init(tqgpu_solver *s, int rank, int nranks) {
+    if (!s || nranks < 1 || nranks > 8 || rank < 0 || rank >= nranks) return fail(TQGPU_EINVAL, "tqgpu_pshard_init: bad arguments (1 .. 8 ranks)");
+    HIP_TRY(hipSetDevice(s->device));
+    if (!s->persist_ok || s->mstage || s->fast < 0 || !s->use_fast || !s->use_persist) return fail(TQGPU_EUNSUPPORTED, "sharding inside the persistent launch needs the persistent path of a uniform complete tree");
+    const int top = nranks == 1 ? s->n_tiers - 1 : pshard_part_top(s, nranks);
+    if (top < 0) return fail(TQGPU_EUNSUPPORTED, "tree too small to shard over this many ranks");
+    std::vector<int> map;
+    for (int i = 0; i < s->n_tiers; i++)
+        for (int q = 0; q < s->tier_grid[i]; q++) {
+            const int owner = (nranks > 1 && i <= top) ? q / (s->tier_grid[i] / nranks) : 0;
+            if (owner == rank) map.push_back(s->geom.wg0[i] + q);
+        }
+    if ((int)map.size() > s->co_capacity) return fail(TQGPU_EUNSUPPORTED, "this rank's workgroups cannot all be resident");
+    if (s->ps_wg_map) { (void)hipFree(s->ps_wg_map); s->ps_wg_map = nullptr; }
+    HIP_TRY(hipMalloc(&s->ps_wg_map, sizeof(int) * std::max<size_t>(map.size(), 1)));
+    HIP_TRY(hipMemcpy(s->ps_wg_map, map.data(), sizeof(int) * map.size(), hipMemcpyHostToDevice));
+    s->ps_G = (int)map.size();
+    s->pshard = true; s->rank = rank; s->nranks = nranks; s->part_top = nranks > 1 ? top : -1;
+    s->psync.npeer = nranks;
+    for (int r = 0; r < 8; r++) s->psync.peer[r] = s->psync.base;          /* until connected: own slab */
+    s->psync.nap = nap_for_grid(s->ps_G);
+    s->launch_no = 0;
+    HIP_TRY(hipMemset(s->sync_slab, 0, s->sync_bytes));
+    return TQGPU_OK;
+}
+
+/* peer `r` lives in this process (several mirrors on one device, or on several devices with peer access enabled by the caller) */
+extern "C" int tqgpu_pshard_connect_local(tqgpu_solver *s, int r, tqgpu_solver *peer) {
+    if (!s || !peer || !s->pshard || r < 0 || r >= s->nranks || !peer->sync_slab || peer->sync_bytes != s->sync_bytes) return fail(TQGPU_EINVAL, "tqgpu_pshard_connect_local: bad arguments");
+    if (peer->device != s->device) {
+        HIP_TRY(hipSetDevice(s->device));
+        hipError_t e = hipDeviceEnablePeerAccess(peer->device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(TQGPU_ECOMM, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+        (void)hipGetLastError();
+    }
+    s->psync.peer[r] = static_cast<unsigned long long *>(peer->sync_slab);
+    return TQGPU_OK;
+}
+/* peers in other processes: an IPC handle of this rank's slab (64 bytes) out, the peers' handles in */
+extern "C" int tqgpu_pshard_ipc_export(tqgpu_solver *s, void *handle64) {
+    if (!s || !handle64 || !s->sync_slab) return fail(TQGPU_EINVAL, "tqgpu_pshard_ipc_export: bad arguments");
+    HIP_TRY(hipSetDevice(s->device));
+    hipIpcMemHandle_t h;
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+    hipError_t e = hipIpcGetMemHandle(&h, s->sync_slab);
+    if (e != hipSuccess) return fail(TQGPU_ECOMM, std::string("hipIpcGetMemHandle: ") + hipGetErrorString(e));
+    memcpy(handle64, &h, 64);
+    return TQGPU_OK;
+}
+extern "C" int tqgpu_pshard_ipc_connect(tqgpu_solver *s, int r, const void *handle64) {
+    if (!s || !handle64 || !s->pshard || r < 0 || r >= s->nranks || r == s->rank) return fail(TQGPU_EINVAL, "tqgpu_pshard_ipc_connect: bad arguments");
+    HIP_TRY(hipSetDevice(s->device));
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle64, 64);
+    void *ptr = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) return fail(TQGPU_ECOMM, std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e));
+    if (s->ps_ipc[r]) (void)hipIpcCloseMemHandle(s->ps_ipc[r]);
+    s->ps_ipc[r] = ptr;
+    s->psync.peer[r] = static_cast<unsigned long long *>(ptr);
+    return TQGPU_OK;
+}
+
+/* one solve in two halves (so that one process can drive several ranks): _begin enqueues this rank's launch, _end waits for the
+ * verdict.  All ranks' launches have to be in flight together: they wait for each other (bounded: 0.5 s, then TQGPU_ETIMEOUT). */
+extern "C" int tqgpu_pshard_begin(tqgpu_solver *s, const tqgpu_opts *o) {
+    if (!s || !o || !s->pshard) return fail(TQGPU_EINVAL, "tqgpu_pshard_begin: not a sharded mirror");
+    HIP_TRY(hipSetDevice(s->device));
+    if (o->profile || o->maxIter <= 0 || o->checkLastActiveSet == 2) return fail(TQGPU_EUNSUPPORTED, "sharded persistent solve: default solve options only (no profiling, no factor keeping)");
+    Opts O;
+    O.maxIter = o->maxIter; O.termCondition = o->termCondition; O.regType = o->regType;
+    O.lsMaxIter = o->lineSearchMaxIter; O.lsRestartTrigger = o->lineSearchRestartTrigger; O.reuse = 0;
+    O.tol = o->stationarityTolerance; O.regTol = o->regTol; O.regValue = o->regValue;
+    O.gamma = o->lineSearchGamma; O.beta = o->lineSearchBeta; O.stamps = 0;
+    if (O.termCondition < 0 || O.termCondition > 2 || O.regType < 0 || O.regType > 2 || O.regValue < 0) return fail(TQGPU_EINVAL, "invalid option value");
+    memset(s->h_res, 0, sizeof(HostRes));
+    int launches = 0;
+    s->solve_no++;
+    return launch_persist(s, O, launches, 1);
+}
+extern "C" int tqgpu_pshard_end(tqgpu_solver *s, tqgpu_result *res) {
+    if (!s || !res || !s->pshard) return fail(TQGPU_EINVAL, "tqgpu_pshard_end: not a sharded mirror");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    unsigned tmo = 0;
+    HIP_TRY(hipMemcpy(&tmo, s->psync.timeout, sizeof(unsigned), hipMemcpyDeviceToHost));
+    if (tmo) {
+        HIP_TRY(hipMemset(s->psync.timeout, 0, sizeof(unsigned)));
+        return fail(TQGPU_ETIMEOUT, "sharded persistent solve: a bounded wait for another rank's workgroups timed out (are all ranks' launches in flight together?)");
+    }
+    unsigned long long v[16];
+    if (s->rank == 0 && s->h_res->seq == s->psync.seq) memcpy(s->h_ctrl, &s->h_res->c, sizeof(Ctrl));      /* (already there) */
+    else {
+        HIP_TRY(hipMemcpy(v, s->psync.verdict, sizeof(v), hipMemcpyDeviceToHost));
+        if ((unsigned)v[15] != s->psync.seq) return fail(TQGPU_ECOMM, "sharded persistent solve: no verdict from the top workgroup");
+        memcpy(s->h_ctrl, v, sizeof(Ctrl));
+        HIP_TRY(hipMemcpy(s->D.ctrl, s->h_ctrl, sizeof(Ctrl), hipMemcpyHostToDevice));      /* the export kernels read the device copy */
+    }
+    const Ctrl &c = *s->h_ctrl;
+    if (!c.done) return fail(TQGPU_EUNSUPPORTED, "sharded persistent solve: the launch ended without a verdict (tag space exhausted: more than 60000 passes)");
+    res->status = c.status; res->iter = c.iter; res->ls_total = c.ls_total; res->ls_last = c.ls_last;
+    res->n_launches = 1; res->device_time = s->rank == 0 ? 1e-8 * (double)(s->h_res->t_end - s->h_res->t_start) : 0.0; res->last_error_norm = c.err; res->last_fval = c.fval;
+    s->last_iter = c.iter;
+    return TQGPU_OK;
+}
+
+/* what this rank holds of the solution (its chunk of every partitioned range; rank 0: also the levels above the partition), packed
+ * into a host buffer, and the inverse: the transport hook for callers that collect the solution themselves (any all-gather of
+ * equal-sized buffers: tqgpu_pshard_pack_size is the same on every rank) */
+namespace {
+struct PsRange { double *base; size_t n; };
+std::vector<PsRange> pshard_owned_ranges(tqgpu_solver *s, int rank) {
+    std::vector<PsRange> out;
+    const int MD = s->fMD, NX = s->fNX, NU = s->fNU, N = s->nranks;
+    const Data &D = s->D;
+    double *lamc = s->h_ctrl->cur ? D.lam1 : D.lam0;
+    const int lb = N > 1 ? s->tier_l0[s->part_top] : s->Nh + 1;
+    for (int l = 0; l <= s->Nh; l++) {
+        int wl = 1; for (int i = 0; i < l; i++) wl *= MD;
+        const size_t f0 = (size_t)uni_first(MD, l);
+        /* node data (x, u, ...) of level l belongs to the workgroup that owns the node; the duals of a node's own edge belong to the
+         * BLOCK of its parent, one level up: the duals of the boundary level are the top tiers' (rank 0) */
+        for (int what = 0; what < 2; what++) {
+            const int lbw = what == 0 ? lb : lb + 1;
+            size_t first, cnt;
+            if (l >= lbw) { cnt = (size_t)wl / N; first = f0 + (size_t)rank * cnt; }
+            else { if (rank != 0) continue; cnt = (size_t)wl; first = f0; }
+            if (what == 0) {
+                double *xs[] = {D.x, D.xUnc, D.xUncS};
+                for (double *a : xs) out.push_back({a + NX * first, cnt * NX});
+                if (l < s->Nh) { double *us[] = {D.u, D.uUnc, D.uUncS}; for (double *a : us) out.push_back({a + NU * first, cnt * NU}); }
+            } else {
+                double *ls[] = {lamc, D.dlam};
+                for (double *a : ls) out.push_back({a + NX * first, cnt * NX});
+            }
+        }
+    }
+    return out;
+}
+}  // namespace
+extern "C" long tqgpu_pshard_pack_size(tqgpu_solver *s) {
+    if (!s || !s->pshard) return -1;
+    size_t n = 0;
+    for (auto &rg : pshard_owned_ranges(s, 0)) n += rg.n;          /* rank 0 holds the most */
+    return (long)n;
+}
+extern "C" int tqgpu_pshard_pack(tqgpu_solver *s, double *out, long cap) {
+    if (!s || !out || !s->pshard) return fail(TQGPU_EINVAL, "tqgpu_pshard_pack: bad arguments");
+    HIP_TRY(hipSetDevice(s->device));
+    size_t o = 0;
+    for (auto &rg : pshard_owned_ranges(s, s->rank)) {
+        if ((long)(o + rg.n) > cap) return fail(TQGPU_EINVAL, "tqgpu_pshard_pack: buffer too small");
+        HIP_TRY(hipMemcpy(out + o, rg.base, sizeof(double) * rg.n, hipMemcpyDeviceToHost));
+        o += rg.n;
+    }
+    return TQGPU_OK;
+}
+extern "C" int tqgpu_pshard_unpack(tqgpu_solver *s, int src_rank, const double *in, long n_in) {
+    if (!s || !in || !s->pshard || src_rank < 0 || src_rank >= s->nranks) return fail(TQGPU_EINVAL, "tqgpu_pshard_unpack: bad arguments");
+    HIP_TRY(hipSetDevice(s->device));
+    size_t o = 0;
+    for (auto &rg : pshard_owned_ranges(s, src_rank)) {
+        if ((long)(o + rg.n) > n_in) return fail(TQGPU_EINVAL, "tqgpu_pshard_unpack: buffer too small");
+        HIP_TRY(hipMemcpy(rg.base, in + o, sizeof(double) * rg.n, hipMemcpyHostToDevice));
+        o += rg.n;
+    }
+    return TQGPU_OK;
+}
+
+/* n mirrors of the SAME problem in this process (one device: a rehearsal with real concurrency -- n launches on n streams that wait
+ * for each other inside the kernels -- or n devices with peer access): connect, solve, collect the solution into every mirror */
+extern "C" int tqgpu_pshard_solve_local(tqgpu_solver **R, int n, const tqgpu_opts *o, tqgpu_result *res) {
+    if (!R || n < 1 || n > 8 || !o || !res) return fail(TQGPU_EINVAL, "tqgpu_pshard_solve_local: bad arguments");
+    for (int r = 0; r < n; r++) if (!R[r] || !R[r]->pshard || R[r]->nranks != n || R[r]->rank != r) return fail(TQGPU_EINVAL, "tqgpu_pshard_solve_local: mirror r must be tqgpu_pshard_init(r, n)");
+    for (int r = 0; r < n; r++) for (int q = 0; q < n; q++) { int rc = tqgpu_pshard_connect_local(R[r], q, R[q]); if (rc) return rc; }
+    for (int r = 0; r < n; r++) HIP_TRY(hipStreamSynchronize(R[r]->stream));          /* uploads done: the launches go out back to back */
+    for (int r = 0; r < n; r++) { int rc = tqgpu_pshard_begin(R[r], o); if (rc) return rc; }
+    int first = TQGPU_OK;
+    std::string msg;
+    for (int r = 0; r < n; r++) { int rc = tqgpu_pshard_end(R[r], &res[r]); if (rc && !first) { first = rc; msg = g_err; } }
+    if (first) return fail(first, msg);
+    std::vector<double> buf((size_t)std::max<long>(tqgpu_pshard_pack_size(R[0]), 1));
+    for (int src = 0; src < n; src++) {
+        int rc = tqgpu_pshard_pack(R[src], buf.data(), (long)buf.size());
+        if (rc) return rc;
+        for (int dst = 0; dst < n; dst++) if (dst != src && (rc = tqgpu_pshard_unpack(R[dst], src, buf.data(), (long)buf.size()))) return rc;
+    }
     return TQGPU_OK;
 }
 

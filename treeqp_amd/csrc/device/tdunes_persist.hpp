@@ -108,7 +108,40 @@ struct PSync {
     unsigned seq;           /* launch number << 16 (low 16 bits of the number are never 0)            */
     unsigned trip;          /* tag of the pass the workgroup is in (kernel-local copy only)           */
     int nap;                /* > 0: a launch of several hundred workgroups -- the bottom tier's wait for its parent's step naps long (p_forward_tier) */
+    /* ONE tree over several devices (tqgpu_pshard_*): the workgroups of the launch are dealt over `npeer` launches, one per device, each
+     * with a slab of its own of this layout.  Every hand-over word is then written to EVERY slab (system-scope stores into peer-mapped
+     * memory: a posted write per peer), every poll stays local -- the protocol is the single-device one, its words merely travel
+     * further.  npeer <= 1: the slab at `base` only. */
+    u64 *base;              /* this launch's slab                                                      */
+    u64 *peer[8];           /* slabs of all ranks (peer[rank] == base)                                 */
+    int npeer;
+    u64 *verdict;           /* [16] in the slab: the control block as the top workgroup left it + seq, for the ranks that do not run the top workgroup */
 };
+#define SYS __HIP_MEMORY_SCOPE_SYSTEM
+/* a tagged double to every slab of a sharded launch */
+__device__ __forceinline__ void pst_tag(const PSync &Sy, u64 *p, double v, unsigned tag) {
+    st_tag(p, v, tag);
+    if (Sy.npeer > 1) {
+        const size_t off = (size_t)(p - Sy.base);
+        const u64 t = (u64)tag << 32, lo = t | (unsigned)__double2loint(v), hi = t | (unsigned)__double2hiint(v);
+        for (int r = 0; r < Sy.npeer; r++) {
+            u64 *q = Sy.peer[r] + off;
+            if (q != p) { __hip_atomic_store(q, lo, RLX, SYS); __hip_atomic_store(q + 1, hi, RLX, SYS); }
+        }
+    }
+}
+/* a 32-bit word (halt, timeout) to every slab */
+__device__ __forceinline__ void pst_word(const PSync &Sy, unsigned *p, unsigned v) {
+    __hip_atomic_store(p, v, RLX, AGENT);
+    if (Sy.npeer > 1) {
+        const size_t off = (size_t)(reinterpret_cast<u64 *>(p) - Sy.base);
+        const size_t sub = (size_t)(p - reinterpret_cast<unsigned *>(Sy.base + off));
+        for (int r = 0; r < Sy.npeer; r++) {
+            unsigned *q = reinterpret_cast<unsigned *>(Sy.peer[r] + off) + sub;
+            if (q != p) __hip_atomic_store(q, v, RLX, SYS);
+        }
+    }
+}
 
 /* Poll loops read the payload AND the two "launch is over" words in the same round trip (the loads are
  * independent, so they are in flight together); a poll iteration is then one memory latency long and needs
@@ -126,7 +159,7 @@ struct PollGuard {
     __device__ __forceinline__ void settle() const { asm volatile("" :: "v"(h), "v"(tmo), "v"(cm)); }
     __device__ __forceinline__ bool go_on(const PSync &Sy, u64 t0) const {
         if (h == Sy.seq || tmo || cm == Sy.trip) return false;
-        if (wall_clock64() - t0 > 50000000ull) { __hip_atomic_store(Sy.timeout, 1u, RLX, AGENT); return false; }   /* 0.5 s at 100 MHz */
+        if (wall_clock64() - t0 > 50000000ull) { pst_word(Sy, Sy.timeout, 1u); return false; }   /* 0.5 s at 100 MHz */
         /* a nap between two looks: every look is 3 - 35 loads per lane that go to the memory side, and with a few hundred workgroups
          * polling they are in each other's (and the producers') way.  Short (64 cycles) here: this is on every hand-over's critical
          * path.  The one long wait of a pass naps longer in large launches (p_forward_tier). */
@@ -153,7 +186,7 @@ __device__ __forceinline__ bool p_read_top(const PSync &Sy, const u64 *src, unsi
         const unsigned h = __hip_atomic_load(Sy.halt, RLX, AGENT), tmo = __hip_atomic_load(Sy.timeout, RLX, AGENT);
         asm volatile("" :: "v"(h), "v"(tmo));            /* as PollGuard::settle */
         if (ok || h == Sy.seq || tmo) break;
-        if (wall_clock64() - t0 > 50000000ull) { __hip_atomic_store(Sy.timeout, 1u, RLX, AGENT); break; }
+        if (wall_clock64() - t0 > 50000000ull) { pst_word(Sy, Sy.timeout, 1u); break; }
     }
     return ok;
 }
@@ -492,7 +525,7 @@ __device__ __forceinline__ void p_store_factor(const PLds<NX, NU, MD> &L, int lo
  * mine and the record is subtracted from its tall matrix in place (child number `cidx`: rows / columns cidx NX ..): the
  * parent's wave then loads rows that already carry its children -- nothing to subtract on its critical path. */
 template <int NX, int NU, int MD, bool GLOBAL, bool RU = false>
-__device__ __forceinline__ void p_schur(const PLds<NX, NU, MD> &L, int loc, int lane, int ploc, int cidx, u64 *sdst_glb, unsigned tag) {
+__device__ __forceinline__ void p_schur(const PLds<NX, NU, MD> &L, int loc, int lane, int ploc, int cidx, u64 *sdst_glb, unsigned tag, const PSync *Syp = nullptr) {
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D, S = PLds<NX, NU, MD>::S;
     lds_fence();
@@ -520,7 +553,7 @@ __device__ __forceinline__ void p_schur(const PLds<NX, NU, MD> &L, int loc, int 
     for (int rr = 0; rr < 4; rr++) {
         const int ip = g + 4 * rr;
         if (ip < NX && i <= NX) {
-            if (GLOBAL) { const int off = (i < NX) ? ip + i * NX : NX * NX + ip; st_tag(sdst_glb + 2 * off, acc[rr], tag); if (RU) L.srec[off] = acc[rr]; }      /* kept: re-posted by passes that keep the factors */
+            if (GLOBAL) { const int off = (i < NX) ? ip + i * NX : NX * NX + ip; if (Syp) pst_tag(*Syp, sdst_glb + 2 * off, acc[rr], tag); else st_tag(sdst_glb + 2 * off, acc[rr], tag); if (RU) L.srec[off] = acc[rr]; }      /* kept: re-posted by passes that keep the factors */
             else dst[rr * dstp] = old[rr] - acc[rr];
         }
     }
@@ -637,7 +670,7 @@ __device__ __forceinline__ double p_forward_tier(const PConst &C, const PSync &S
             pd = fma(L.res[loc * D + lane], mine, pd);
             if (to_children && t == th - 1) {
                 const int ii = p_slot_node<NX, NU, MD>(loc, l0, s, C);
-                st_tag(Sy.dlt + (size_t)(NX * kid0g<MD>(ii, C) + lane) * 2, mine, tag);
+                pst_tag(Sy, Sy.dlt + (size_t)(NX * kid0g<MD>(ii, C) + lane) * 2, mine, tag);
             }
         }
         if (t + 1 < th) {
@@ -720,7 +753,7 @@ __device__ __forceinline__ double p_stage16(const PConst &C, const PSync &Sy, PL
         if (!dry) { if (ch.save_s) ns[4 * NZ + t] = ns[2 * NZ + t]; ns[t] = val; ns[NZ + t] = cal; ns[2 * NZ + t] = unc; ns[3 * NZ + t] = v; }
         if (!dry && to_parent && q == 0 && isx) {         /* my subtree root: the parent workgroup's G + H reads x and QinvCal */
             u64 *dst = Sy.ndt + ((size_t)k * 2 * NX + t) * 2;
-            st_tag(dst, val, tag); st_tag(dst + 2 * NX, cal, tag);
+            pst_tag(Sy, dst, val, tag); pst_tag(Sy, dst + 2 * NX, cal, tag);
         }
         p_q = (wd * val) * val;
         p_h = v * val;
@@ -732,7 +765,7 @@ __device__ __forceinline__ double p_stage16(const PConst &C, const PSync &Sy, PL
         const unsigned code = (unsigned)((__builtin_amdgcn_ballot_w64(at_hi) >> sh) & 0xFFFFull) | ((unsigned)((__builtin_amdgcn_ballot_w64(at_lo) >> sh) & 0xFFFFull) << 16);
         if (active && t == 0) {
             L.nsig[q] = (int)code;
-            if (to_parent && q == 0) st_tag(Sy.sgt + (size_t)k * 2, (double)(code & (((1u << NX) - 1u) * 0x10001u)), tag);      /* x part: my parent's block depends on it */
+            if (to_parent && q == 0) pst_tag(Sy, Sy.sgt + (size_t)k * 2, (double)(code & (((1u << NX) - 1u) * 0x10001u)), tag);      /* x part: my parent's block depends on it */
         }
     }
     const double qx = row16_sum(isx ? p_q : 0.0), hx = row16_sum(isx ? p_h : 0.0);
@@ -868,7 +901,7 @@ __device__ __noinline__ void p_reuse_decide(const PConst &C, const PSync &Sy, PL
     const bool all_same = __all(!mine || same);
     if (lane == 0) {
         *L.ruse = all_same ? 1 : 0;
-        if (!is_top && ok) st_tag(Sy.rfl + (size_t)p_slot_node<NX, NU, MD>(0, l0, s, C) * 2, all_same ? 1.0 : 0.0, tag_pass);
+        if (!is_top && ok) pst_tag(Sy, Sy.rfl + (size_t)p_slot_node<NX, NU, MD>(0, l0, s, C) * 2, all_same ? 1.0 : 0.0, tag_pass);
     }
 }
 
@@ -922,7 +955,7 @@ __device__ __noinline__ double p_reuse_block(const PConst &C, const PSync &Sy, P
     if (lane < D) L.mz_(loc)[lane * LDM] = z;
     if (is_root) {
         if (lane < D) {
-            if (th == 1 && !is_bottom && ok) st_tag(Sy.dlt + (size_t)(NX * kid0g<MD>(0, C) + lane) * 2, z, tag);
+            if (th == 1 && !is_bottom && ok) pst_tag(Sy, Sy.dlt + (size_t)(NX * kid0g<MD>(0, C) + lane) * 2, z, tag);
             L.dl[lane] = z; pd = L.res[lane] * z;
         }
     } else if (t > 0) {
@@ -930,8 +963,8 @@ __device__ __noinline__ double p_reuse_block(const PConst &C, const PSync &Sy, P
     } else if (ok) {
         /* my subtree root: the parent workgroup gets the record again -- S as it was built, v of this pass */
         u64 *dst = Sy.sch + (size_t)ii * U::SCH * 2;
-        if (lane < NX * NX) st_tag(dst + 2 * lane, L.srec[lane], tag);
-        if (lane < NX) st_tag(dst + 2 * (NX * NX + lane), v, tag);
+        if (lane < NX * NX) pst_tag(Sy, dst + 2 * lane, L.srec[lane], tag);
+        if (lane < NX) pst_tag(Sy, dst + 2 * (NX * NX + lane), v, tag);
     }
     lds_fence();
     return pd;
@@ -1018,7 +1051,7 @@ __device__ __forceinline__ bool p_gather_batch(const PSync &Sy, PLds<NX, NU, MD>
                 const unsigned h = __hip_atomic_load(Sy.halt, RLX, AGENT), tmo = __hip_atomic_load(Sy.timeout, RLX, AGENT);
                 asm volatile("" :: "v"(h), "v"(tmo));    /* as PollGuard::settle */
                 if (ok || h == Sy.seq || tmo) break;
-                if (wall_clock64() - t0 > 50000000ull) { __hip_atomic_store(Sy.timeout, 1u, RLX, AGENT); break; }
+                if (wall_clock64() - t0 > 50000000ull) { pst_word(Sy, Sy.timeout, 1u); break; }
             }
             if (!ok) {
                 *L.abort = 1;
@@ -1167,8 +1200,8 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
     auto post_parts = [&]() {
         double f = 0.0, d = 0.0;
         for (int w = 0; w < FW; w++) { f += L.part[4 * w + 2]; d += L.part[4 * w + 1]; }
-        st_tag(Sy.parts + (size_t)wg * 4, f, Sy.seq | nd);
-        st_tag(Sy.parts + (size_t)wg * 4 + 2, d, Sy.seq | nd);
+        pst_tag(Sy, Sy.parts + (size_t)wg * 4, f, Sy.seq | nd);
+        pst_tag(Sy, Sy.parts + (size_t)wg * 4 + 2, d, Sy.seq | nd);
     };
 
     pstamp(C, O, (unsigned)O.stamps, tier, s, 26);                     /* 26: state and constants loaded */
@@ -1231,7 +1264,7 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
                 /* termination partial of my blocks to the top workgroup */
                 err = 0.0;
                 for (int w = 0; w < FW; w++) { const double v = L.part[4 * w]; err = (O.termCondition == 2) ? nanmax(err, v) : err + v; }
-                st_tag(Sy.errs + (size_t)wg * 2, err, tag_e);
+                pst_tag(Sy, Sy.errs + (size_t)wg * 2, err, tag_e);
             }
         }
         pstamp(C, O, e, tier, s, sl++);                                   /* 1: G+H done */
@@ -1260,7 +1293,7 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
                                 ls_decide_tail(c, dp->ls_log, dp->ls_log_cap, O, fa);
                                 code = c->done ? 1 : (c->ls_pending ? 2 : 0);   /* finished / more trials / accepted */
                                 if (code == 2) {                                /* line_search :985-987: lambda moves by (tau - tauPrev) dlambda */
-                                    st_tag(Sy.cmd, __dsub_rn(c->tau, c->tauPrev), tag_e); st_tag(Sy.cmd + 2, c->tau, tag_e);
+                                    pst_tag(Sy, Sy.cmd, __dsub_rn(c->tau, c->tauPrev), tag_e); pst_tag(Sy, Sy.cmd + 2, c->tau, tag_e);
                                 }
                             }
                         }
@@ -1278,7 +1311,7 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
                 __syncthreads();
             }
             if (leave == 1) {
-                if (threadIdx.x == 0) __hip_atomic_store(Sy.halt, Sy.seq, RLX, AGENT);
+                if (threadIdx.x == 0) pst_word(Sy, Sy.halt, Sy.seq);
                 break;
             }
             verdict = leave;
@@ -1344,7 +1377,7 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
                     if (!is_root) {
                         p_store_factor<NX, NU, MD>(L, loc, lane, Tc);
                         FSTAMP(3);
-                        if (t == 0) { if (ok) p_schur<NX, NU, MD, true, RU>(L, loc, lane, 0, 0, Sy.sch + (size_t)ii * U::SCH * 2, tag_e); }
+                        if (t == 0) { if (ok) p_schur<NX, NU, MD, true, RU>(L, loc, lane, 0, 0, Sy.sch + (size_t)ii * U::SCH * 2, tag_e, &Sy); }
                         else p_schur<NX, NU, MD, false>(L, loc, lane, U::first(t - 1) + wave / MD, wave % MD, nullptr, 0u);
                         FSTAMP(4);
                     } else {
@@ -1362,7 +1395,7 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
                         const double mine = (a0 + a1) + (a2 + a3);
                         const int ri = lane - U::R;
                         if (ri >= 0 && ri < D) {
-                            if (th == 1 && !is_bottom && ok) st_tag(Sy.dlt + (size_t)(NX * kid0g<MD>(0, C) + ri) * 2, mine, tag_e);
+                            if (th == 1 && !is_bottom && ok) pst_tag(Sy, Sy.dlt + (size_t)(NX * kid0g<MD>(0, C) + ri) * 2, mine, tag_e);
                             L.dl[ri] = mine; dotp = L.res[ri] * mine;
                         }
                         lds_fence();
@@ -1428,7 +1461,7 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
                 if ((int)threadIdx.x < K) {
                     double f = 0.0;
                     for (int w = 0; w < FW; w++) f += L.bat[w * 8 + threadIdx.x];
-                    st_tag(Sy.bparts + ((size_t)wg * 8 + threadIdx.x) * 2, f, tag_b);
+                    pst_tag(Sy, Sy.bparts + ((size_t)wg * 8 + threadIdx.x) * 2, f, tag_b);
                 }
                 if (is_top) {
                     double fa[8];
@@ -1444,7 +1477,7 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
                             }
                         }
                         if (acc) c->cur = cur ^ 1;                  /* the control block flips per trial, the buffers once per stored sweep */
-                        st_tag(Sy.vrd, (double)acc, tag_b);
+                        pst_tag(Sy, Sy.vrd, (double)acc, tag_b);
                     }
                 }
                 double vv[1];
@@ -1458,7 +1491,7 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
                 n0 += K;
             }
             if (dead) {
-                if (is_top && threadIdx.x == 0) __hip_atomic_store(Sy.halt, Sy.seq, RLX, AGENT);
+                if (is_top && threadIdx.x == 0) pst_word(Sy, Sy.halt, Sy.seq);
                 break;
             }
             ch.n = nacc; ch.save_s = false;
@@ -1497,6 +1530,16 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
 #endif
             *cg = *c;                                                         /* for the next launch and for the stream-ordered readers */
             const unsigned long long *src = reinterpret_cast<const unsigned long long *>(c);
+            if (Sy.npeer > 1) {
+                /* sharded launch: the ranks that do not run this workgroup read the verdict from their own slab once their launch has ended */
+                const size_t voff = (size_t)(Sy.verdict - Sy.base);
+                for (int r = 0; r < Sy.npeer; r++) {
+                    u64 *vq = Sy.peer[r] + voff;
+                    for (int i = 0; i < (int)(sizeof(Ctrl) / 8); i++) __hip_atomic_store(vq + i, src[i], RLX, SYS);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                for (int r = 0; r < Sy.npeer; r++) __hip_atomic_store(Sy.peer[r] + voff + 15, (u64)Sy.seq, RLX, SYS);
+            }
             unsigned long long *dst = reinterpret_cast<unsigned long long *>(&hr->c);
             for (int i = 0; i < (int)(sizeof(Ctrl) / 8); i++) __hip_atomic_store(dst + i, src[i], RLX, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(&hr->t_start, t_start, RLX, __HIP_MEMORY_SCOPE_SYSTEM);
