@@ -178,7 +178,50 @@ def self_launch(args):
     raise SystemExit(0)
 
 
+def pshard_child(steps: int):
+    """The sharded leg of a multi-GPU run, in a process of its own per rank (see main): ONE C3 tree over WORLD_SIZE ranks inside the
+    persistent launch.  gloo carries the 64-byte IPC handles of the hand-over slabs and the timing reduction; rank 0 prints the result."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    os.environ["MASTER_PORT"] = os.environ["TREEQP_PSHARD_PORT"]
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from treeqp_amd import capi
+    ndev = max(1, capi.device_count())
+    dev = int(os.environ.get("TREEQP_PSHARD_DEVICE", "0")) % ndev
+    c3, _, _ = make_workload("C3")
+    f = c3[0]["flat"]
+    m = capi.TqGpu(f["nk"], f["nx"], f["nu"], device=dev).upload(f, c3[0]["lambda0"])
+    m.pshard_init(rank, world)
+    handles = [None] * world
+    dist.all_gather_object(handles, m.pshard_ipc_export())
+    for r in range(world):
+        if r != rank:
+            m.pshard_ipc_connect(r, handles[r])
+    for _ in range(5):
+        dist.barrier()
+        m.pshard_begin()
+        res = m.pshard_end()
+    dist.barrier()
+    t0 = time.perf_counter()
+    iters = 0
+    for _ in range(steps):
+        m.pshard_begin()
+        res = m.pshard_end()
+        iters += res["iter"]
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"iters": iters, "seconds": float(t.item()), "status": int(res["status"])}), flush=True)
+    m.close()
+    dist.destroy_process_group()
+
+
 def main():
+    if "--pshard-child" in sys.argv:
+        pshard_child(int(sys.argv[sys.argv.index("--steps") + 1]))
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -455,26 +498,25 @@ def main():
                 return r3, it3, float(tt.item())
 
             # (1) the MI355X-native form: the workgroups of the ONE persistent launch dealt over the ranks, hand-over words written into
-            # every rank's slab through IPC-mapped peer memory (tqgpu_pshard_*): no collective, no host in the loop
-            family, err_p = None, None
+            # every rank's slab through IPC-mapped peer memory (tqgpu_pshard_*): no collective, no host in the loop.  It runs in a CHILD
+            # process per rank (own gloo group for the handle exchange): the kernels write into other devices' memory, and a fault there
+            # -- this path has run on one device only so far -- must not take the replicas' line with it.
+            family, err_p, child = None, None, None
             try:
-                m3 = mirror(c3[0])
-                m3.pshard_init(rank, world)
-                mine = torch.frombuffer(bytearray(m3.pshard_ipc_export()), dtype=torch.uint8).to(red_dev)
-                allh = [torch.zeros(64, dtype=torch.uint8, device=red_dev) for _ in range(world)]
-                dist.all_gather(allh, mine)
-                for r_ in range(world):
-                    if r_ != rank:
-                        m3.pshard_ipc_connect(r_, bytes(allh[r_].cpu().numpy().tobytes()))
-
-                def once():
-                    m3.pshard_begin()
-                    return m3.pshard_end()
-                r3, it3, te = timed(once, lambda: None)
-                family = "persistent launch per rank (f_persist), tagged hand-over words in peer-mapped slabs, no collective"
-                m3.close()
+                env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}      # the children's rank 0 hosts their store itself
+                env["TREEQP_PSHARD_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 17)
+                env["TREEQP_PSHARD_DEVICE"] = str(local_rank)
+                cp = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--pshard-child", "--steps", str(ksteps)], env=env,
+                                    capture_output=True, text=True, timeout=max(30.0, deadline - 30.0))
+                lines = [l for l in cp.stdout.splitlines() if l.startswith("{")]
+                if cp.returncode != 0:
+                    err_p = (cp.stderr or cp.stdout)[-600:]
+                elif rank == 0:
+                    child = json.loads(lines[-1])
             except Exception as e:
                 err_p = str(e)
+            if err_p is None:
+                family = "persistent launch per rank (f_persist), tagged hand-over words in peer-mapped slabs, no collective"
             # every rank takes the same branch: if any rank failed on the way, all fall back
             flag = torch.tensor([0.0 if family else 1.0], dtype=torch.float64, device=red_dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
@@ -486,6 +528,10 @@ def main():
                 r3, it3, te = timed(lambda: m3.solve(), lambda: m3.device_times(1))
                 family = "launch-per-tier kernels, 2 RCCL all-gathers per Newton iteration"
                 m3.close()
+            if flag.item() == 0 and rank == 0:
+                it3, te, r3 = child["iters"], child["seconds"], {"status": child["status"]}
+            elif flag.item() == 0:
+                it3, te, r3 = 0, 1.0, {"status": 0}
             sharded = {"workload": f"C3: {c3desc}", "value": it3 / te, "unit": "newton_iter/s", "steps": ksteps, "ms_per_step": 1e3 * te / ksteps,
                        "scaling": "strong", "status": int(r3["status"]), "newton_iter_per_solve": it3 / ksteps, "kernel_family": family,
                        "parallelism": f"one tree, subtrees partitioned over {world} ranks", "persistent_path_error": err_p}
