@@ -24,7 +24,7 @@ process -- before anything touches a GPU -- and forwards the child's JSON line.
               pairs are recorded in a second region of the same solves right after the timed one: the timed
               region enqueues a solve as the bare kernel launch it is (an event pair is two more queue packets).
 * critical_path = the dependent chain that actually bounds a solve: tree levels x measured floor of a level step in
-              isolation (tools/microbench/level_bench, profiles/r02_v2_level_bench.txt) + tier hand-overs, against the
+              isolation (tools/microbench/level_bench, profiles/r03_v1_level_bench.txt) + tier hand-overs, against the
               measured period of a pass (solves stopped after 1 and 2 iterations).
 * cpu_baseline = the CPU oracle ("port": restatement of the reference algorithm, NOT BLASFEO
               HIGH_PERFORMANCE) on the same workload, min over repetitions, rank 0 at N=1 only.
@@ -109,7 +109,7 @@ def cpu_baseline(items, opts, budget_s: float = 12.0):
 def level_floors():
     """floors of a level step in isolation (cycles), from the committed microbenchmark output"""
     out = {}
-    f = ROOT / "profiles" / "r02_v2_level_bench.txt"
+    f = ROOT / "profiles" / "r03_v1_level_bench.txt"
     if f.exists():
         import re
         for line in f.read_text().splitlines():
@@ -143,7 +143,7 @@ def critical_path(g, p_levels: int, n_tiers: int, reps: int = 60, floors_apply: 
         out.update({"floor_us": floor, "achieved_over_floor": (t2 - t1) / floor,
                     "floor_terms": {"backward_level_cycles": back, "forward_tier_cycles": fwd, "stage_plus_gh_cycles": sg,
                                     "handover_us": handover_us, "handovers": 2 * (n_tiers - 1)},
-                    "floor_source": "profiles/r02_v2_level_bench.txt (tools/microbench/level_bench on MI355X), cycles at 2.4 GHz"})
+                    "floor_source": "profiles/r03_v1_level_bench.txt (tools/microbench/level_bench on MI355X), cycles at 2.4 GHz"})
     return out
 
 
@@ -382,7 +382,7 @@ def main():
         achieved = bytes_step / launch_s / 1e9
         traffic = None
         tf = ROOT / "profiles" / f"traffic_{args.workload}.json"
-        if tf.exists() and n_trees == 1:
+        if tf.exists() and args.trees == 1:
             traffic = json.loads(tf.read_text()).get("bytes_per_launch")        # from the committed PMC passes
         kernel = {2: "f_persist / f_mpersist: the whole solve in one launch (first sweep + all Newton iterations)",
                   3: "g_persist(_batch): the whole solve in one launch of one workgroup per tree",

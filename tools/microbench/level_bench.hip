@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(FW * WAVE) level_bench(Ctrl *c, Opts O, long l
                     }
                 }
                 if (MASK & 8) p_store_factor<NX, NU, MD>(L, loc, lane, Tc);
-                if ((MASK & 16) && t > 0) p_schur<NX, NU, MD, false>(L, loc, lane, U::first(t - 1) + wave / MD, wave % MD, nullptr, 0u);
+                if ((MASK & 16) && t > 0) { PSync nosy{}; p_schur<NX, NU, MD, false>(L, loc, lane, U::first(t - 1) + wave / MD, wave % MD, nullptr, 0u, nosy); }
             }
             if (MASK & 32) lds_barrier();
         }

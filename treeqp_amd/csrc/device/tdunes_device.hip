@@ -1132,6 +1132,8 @@ struct tqgpu_solver {
     int *ps_wg_map = nullptr;       /* blockIdx.x -> workgroup id, this rank's workgroups (bottom tier first) */
     int ps_G = 0;
     void *ps_ipc[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      /* peer slabs opened through IPC handles (closed by tqgpu_destroy) */
+    unsigned long long *h_peers[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   /* slabs of all ranks ... */
+    unsigned long long **d_peers = nullptr;                                                               /* ... and the device copy of the table the kernel reads */
     /* sharded mode */
     int nranks = 1, rank = 0, part_top = -1;      /* part_top: highest partitioned tier */
     bool sharded = false;     /* subtree-sharded mode (nranks > 1, or ONE rank with a communicator: the same code path, used to exercise the RCCL transport on a one-GPU box) */
@@ -1256,6 +1258,19 @@ int allow_lds(K kernel, size_t bytes) {
 #define FAST_TABLE(X) X(0, 8, 3, 2) X(1, 4, 1, 2) X(2, 4, 1, 3) X(3, 2, 1, 2) X(4, 8, 2, 2) X(5, 6, 2, 2) X(6, 4, 1, 4) \
     X(7, 8, 1, 2) X(8, 8, 4, 2) X(9, 4, 2, 2) X(10, 4, 3, 2) X(11, 4, 2, 3) X(12, 4, 2, 4) X(13, 6, 1, 2) X(14, 6, 3, 2) X(15, 2, 1, 4) X(16, 2, 2, 2)
 #endif
+
+/* shapes with a sharded instantiation of the persistent kernel (f_persist_sh; one table line per shape) */
+#ifdef TQ_SMALL_TABLE
+#define SHARD_TABLE(X) X(0, 8, 3, 2)
+#else
+#define SHARD_TABLE(X) X(0, 8, 3, 2) X(1, 4, 1, 2) X(4, 8, 2, 2) X(5, 6, 2, 2)
+#endif
+bool shard_instantiated(int idx) {
+#define X(i, nx, nu, md) if (idx == i) return true;
+    SHARD_TABLE(X)
+#undef X
+    return false;
+}
 
 int fast_index(int NX, int NU, int MD) {
 #define X(idx, nx, nu, md) if (NX == nx && NU == nu && MD == md) return idx;
@@ -1649,8 +1664,11 @@ int setup_persist(tqgpu_solver *s, int device) {
     s->psync.bparts = s->psync.errs + n_errs + 32;
     s->psync.sgt = s->psync.bparts + n_bparts; s->psync.rfl = s->psync.sgt + n_sgt;
     s->psync.verdict = s->psync.rfl + n_rfl;
-    s->psync.base = w; s->psync.npeer = 1;
-    for (int r = 0; r < 8; r++) s->psync.peer[r] = w;
+    s->psync.base = w; s->psync.npeer = 1; s->psync.relay_wg = -1;
+    HIP_TRY(hipMalloc(&s->d_peers, 8 * sizeof(unsigned long long *)));
+    for (int r = 0; r < 8; r++) s->h_peers[r] = w;
+    HIP_TRY(hipMemcpy(s->d_peers, s->h_peers, sizeof(s->h_peers), hipMemcpyHostToDevice));
+    s->psync.peers = s->d_peers;
     s->psync.seq = 0; s->psync.trip = 0;
     {
         const char *e = getenv("TREEQP_AMD_NAP");
@@ -1733,10 +1751,10 @@ int launch_persist(tqgpu_solver *s, const Opts &O, int &launches, int prologue, 
         PGeom Gm = s->geom;
         Gm.wg_of_block = s->ps_wg_map;
         switch (s->fast) {
-#define X(idx, nx, nu, md) case idx: hipLaunchKernelGGL((f_persist<nx, nu, md, false>), dim3(s->ps_G), dim3(FW * WAVE), s->lds_persist, st, s->pconst, O, Gm, s->psync, prologue); break;
-            FAST_TABLE(X)
+#define X(idx, nx, nu, md) case idx: hipLaunchKernelGGL((f_persist_sh<nx, nu, md>), dim3(s->ps_G), dim3(FW * WAVE), s->lds_persist, st, s->pconst, O, Gm, s->psync, prologue); break;
+            SHARD_TABLE(X)
 #undef X
-            default: break;
+            default: return fail(TQGPU_EUNSUPPORTED, "the sharded persistent kernel is not instantiated for this shape");
         }
         launches++;
         return TQGPU_OK;
@@ -2131,6 +2149,7 @@ extern "C" void tqgpu_destroy(tqgpu_solver *s) {
     if (s->d_pitems) (void)hipFree(s->d_pitems);
     if (s->h_pitems) (void)hipHostFree(s->h_pitems);
     if (s->ps_wg_map) (void)hipFree(s->ps_wg_map);
+    if (s->d_peers) (void)hipFree(s->d_peers);
     for (int r = 0; r < 8; r++) if (s->ps_ipc[r]) (void)hipIpcCloseMemHandle(s->ps_ipc[r]);
     if (s->w3_xu) (void)hipFree(s->w3_xu);
     if (s->w3_red) (void)hipFree(s->w3_red);
@@ -3115,6 +3134,13 @@ extern "C" int tqgpu_pshard_init(tqgpu_solver *s, int rank, int nranks) {
     if (!s || nranks < 1 || nranks > 8 || rank < 0 || rank >= nranks) return fail(TQGPU_EINVAL, "tqgpu_pshard_init: bad arguments (1 .. 8 ranks)");
     HIP_TRY(hipSetDevice(s->device));
     if (!s->persist_ok || s->mstage || s->fast < 0 || !s->use_fast || !s->use_persist) return fail(TQGPU_EUNSUPPORTED, "sharding inside the persistent launch needs the persistent path of a uniform complete tree");
+    if (!shard_instantiated(s->fast)) return fail(TQGPU_EUNSUPPORTED, "the sharded persistent kernel is not instantiated for this shape (SHARD_TABLE)");
+    switch (s->fast) {
+#define X(idx, nx, nu, md) case idx: { int rca = allow_lds(f_persist_sh<nx, nu, md>, s->lds_persist); if (rca) return rca; } break;
+        SHARD_TABLE(X)
+#undef X
+        default: break;
+    }
     const int top = nranks == 1 ? s->n_tiers - 1 : pshard_part_top(s, nranks);
     if (top < 0) return fail(TQGPU_EUNSUPPORTED, "tree too small to shard over this many ranks");
     std::vector<int> map;
@@ -3130,7 +3156,9 @@ extern "C" int tqgpu_pshard_init(tqgpu_solver *s, int rank, int nranks) {
     s->ps_G = (int)map.size();
     s->pshard = true; s->rank = rank; s->nranks = nranks; s->part_top = nranks > 1 ? top : -1;
     s->psync.npeer = nranks;
-    for (int r = 0; r < 8; r++) s->psync.peer[r] = s->psync.base;          /* until connected: own slab */
+    s->psync.relay_wg = (rank > 0 && !map.empty()) ? map[0] : -1;          /* ranks without the top workgroup: their first workgroup passes the verdict on to the host */
+    for (int r = 0; r < 8; r++) s->h_peers[r] = s->psync.base;             /* until connected: own slab */
+    HIP_TRY(hipMemcpy(s->d_peers, s->h_peers, sizeof(s->h_peers), hipMemcpyHostToDevice));
     s->psync.nap = nap_for_grid(s->ps_G);
     s->launch_no = 0;
     HIP_TRY(hipMemset(s->sync_slab, 0, s->sync_bytes));
@@ -3146,7 +3174,8 @@ extern "C" int tqgpu_pshard_connect_local(tqgpu_solver *s, int r, tqgpu_solver *
         if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(TQGPU_ECOMM, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
         (void)hipGetLastError();
     }
-    s->psync.peer[r] = static_cast<unsigned long long *>(peer->sync_slab);
+    s->h_peers[r] = static_cast<unsigned long long *>(peer->sync_slab);
+    HIP_TRY(hipMemcpy(s->d_peers, s->h_peers, sizeof(s->h_peers), hipMemcpyHostToDevice));
     return TQGPU_OK;
 }
 /* peers in other processes: an IPC handle of this rank's slab (64 bytes) out, the peers' handles in */
@@ -3170,7 +3199,8 @@ extern "C" int tqgpu_pshard_ipc_connect(tqgpu_solver *s, int r, const void *hand
     if (e != hipSuccess) return fail(TQGPU_ECOMM, std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e));
     if (s->ps_ipc[r]) (void)hipIpcCloseMemHandle(s->ps_ipc[r]);
     s->ps_ipc[r] = ptr;
-    s->psync.peer[r] = static_cast<unsigned long long *>(ptr);
+    s->h_peers[r] = static_cast<unsigned long long *>(ptr);
+    HIP_TRY(hipMemcpy(s->d_peers, s->h_peers, sizeof(s->h_peers), hipMemcpyHostToDevice));
     return TQGPU_OK;
 }
 
@@ -3194,20 +3224,27 @@ extern "C" int tqgpu_pshard_begin(tqgpu_solver *s, const tqgpu_opts *o) {
 extern "C" int tqgpu_pshard_end(tqgpu_solver *s, tqgpu_result *res) {
     if (!s || !res || !s->pshard) return fail(TQGPU_EINVAL, "tqgpu_pshard_end: not a sharded mirror");
     HIP_TRY(hipSetDevice(s->device));
-    HIP_TRY(hipStreamSynchronize(s->stream));
-    unsigned tmo = 0;
-    HIP_TRY(hipMemcpy(&tmo, s->psync.timeout, sizeof(unsigned), hipMemcpyDeviceToHost));
-    if (tmo) {
-        HIP_TRY(hipMemset(s->psync.timeout, 0, sizeof(unsigned)));
-        return fail(TQGPU_ETIMEOUT, "sharded persistent solve: a bounded wait for another rank's workgroups timed out (are all ranks' launches in flight together?)");
+    /* the verdict reaches every rank's host through its pinned result block: written by the top workgroup (rank 0) or passed on from the
+     * rank's slab by its relay workgroup -- no stream synchronisation on the way (the state write-back of the other workgroups is still
+     * running; everything the host does next on this mirror is stream-ordered behind the launch) */
+    {
+        volatile unsigned *seq = &s->h_res->seq;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (long spins = 0; *seq != s->psync.seq; spins++) {
+            __builtin_ia32_pause();
+            if ((spins & 0xFFFF) == 0xFFFF && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
     }
-    unsigned long long v[16];
-    if (s->rank == 0 && s->h_res->seq == s->psync.seq) memcpy(s->h_ctrl, &s->h_res->c, sizeof(Ctrl));      /* (already there) */
-    else {
-        HIP_TRY(hipMemcpy(v, s->psync.verdict, sizeof(v), hipMemcpyDeviceToHost));
-        if ((unsigned)v[15] != s->psync.seq) return fail(TQGPU_ECOMM, "sharded persistent solve: no verdict from the top workgroup");
-        memcpy(s->h_ctrl, v, sizeof(Ctrl));
-        HIP_TRY(hipMemcpy(s->D.ctrl, s->h_ctrl, sizeof(Ctrl), hipMemcpyHostToDevice));      /* the export kernels read the device copy */
+    if (s->h_res->seq != s->psync.seq) {
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        unsigned tmo = 0;
+        HIP_TRY(hipMemcpy(&tmo, s->psync.timeout, sizeof(unsigned), hipMemcpyDeviceToHost));
+        if (tmo) {
+            HIP_TRY(hipMemset(s->psync.timeout, 0, sizeof(unsigned)));
+            return fail(TQGPU_ETIMEOUT, "sharded persistent solve: a bounded wait for another rank's workgroups timed out (are all ranks' launches in flight together?)");
+        }
+        return fail(TQGPU_ECOMM, "sharded persistent solve: no verdict from the top workgroup");
     }
     const Ctrl &c = *s->h_ctrl;
     if (!c.done) return fail(TQGPU_EUNSUPPORTED, "sharded persistent solve: the launch ended without a verdict (tag space exhausted: more than 60000 passes)");

@@ -113,9 +113,11 @@ struct PSync {
      * memory: a posted write per peer), every poll stays local -- the protocol is the single-device one, its words merely travel
      * further.  npeer <= 1: the slab at `base` only. */
     u64 *base;              /* this launch's slab                                                      */
-    u64 *peer[8];           /* slabs of all ranks (peer[rank] == base)                                 */
+    u64 *const *peers;      /* [npeer] in device memory: slabs of all ranks (peers[rank] == base).  (A table in memory, not an array member: a
+                               dynamically indexed member keeps the whole struct in scratch memory -- 18 us per C2 solve.) */
     int npeer;
     u64 *verdict;           /* [16] in the slab: the control block as the top workgroup left it + seq, for the ranks that do not run the top workgroup */
+    int relay_wg;           /* sharded launch without the top workgroup: the workgroup (global number) that passes the verdict on to THIS rank's host, else -1 */
 };
 #define SYS __HIP_MEMORY_SCOPE_SYSTEM
 /* a tagged double to every slab of a sharded launch */
@@ -125,7 +127,7 @@ __device__ __forceinline__ void pst_tag(const PSync &Sy, u64 *p, double v, unsig
         const size_t off = (size_t)(p - Sy.base);
         const u64 t = (u64)tag << 32, lo = t | (unsigned)__double2loint(v), hi = t | (unsigned)__double2hiint(v);
         for (int r = 0; r < Sy.npeer; r++) {
-            u64 *q = Sy.peer[r] + off;
+            u64 *q = Sy.peers[r] + off;
             if (q != p) { __hip_atomic_store(q, lo, RLX, SYS); __hip_atomic_store(q + 1, hi, RLX, SYS); }
         }
     }
@@ -137,7 +139,7 @@ __device__ __forceinline__ void pst_word(const PSync &Sy, unsigned *p, unsigned 
         const size_t off = (size_t)(reinterpret_cast<u64 *>(p) - Sy.base);
         const size_t sub = (size_t)(p - reinterpret_cast<unsigned *>(Sy.base + off));
         for (int r = 0; r < Sy.npeer; r++) {
-            unsigned *q = reinterpret_cast<unsigned *>(Sy.peer[r] + off) + sub;
+            unsigned *q = reinterpret_cast<unsigned *>(Sy.peers[r] + off) + sub;
             if (q != p) __hip_atomic_store(q, v, RLX, SYS);
         }
     }
@@ -525,7 +527,7 @@ __device__ __forceinline__ void p_store_factor(const PLds<NX, NU, MD> &L, int lo
  * mine and the record is subtracted from its tall matrix in place (child number `cidx`: rows / columns cidx NX ..): the
  * parent's wave then loads rows that already carry its children -- nothing to subtract on its critical path. */
 template <int NX, int NU, int MD, bool GLOBAL, bool RU = false>
-__device__ __forceinline__ void p_schur(const PLds<NX, NU, MD> &L, int loc, int lane, int ploc, int cidx, u64 *sdst_glb, unsigned tag, const PSync *Syp = nullptr) {
+__device__ __forceinline__ void p_schur(const PLds<NX, NU, MD> &L, int loc, int lane, int ploc, int cidx, u64 *sdst_glb, unsigned tag, const PSync &Sy) {
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D, S = PLds<NX, NU, MD>::S;
     lds_fence();
@@ -553,7 +555,7 @@ __device__ __forceinline__ void p_schur(const PLds<NX, NU, MD> &L, int loc, int 
     for (int rr = 0; rr < 4; rr++) {
         const int ip = g + 4 * rr;
         if (ip < NX && i <= NX) {
-            if (GLOBAL) { const int off = (i < NX) ? ip + i * NX : NX * NX + ip; if (Syp) pst_tag(*Syp, sdst_glb + 2 * off, acc[rr], tag); else st_tag(sdst_glb + 2 * off, acc[rr], tag); if (RU) L.srec[off] = acc[rr]; }      /* kept: re-posted by passes that keep the factors */
+            if (GLOBAL) { const int off = (i < NX) ? ip + i * NX : NX * NX + ip; pst_tag(Sy, sdst_glb + 2 * off, acc[rr], tag); if (RU) L.srec[off] = acc[rr]; }      /* kept: re-posted by passes that keep the factors */
             else dst[rr * dstp] = old[rr] - acc[rr];
         }
     }
@@ -1377,8 +1379,8 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
                     if (!is_root) {
                         p_store_factor<NX, NU, MD>(L, loc, lane, Tc);
                         FSTAMP(3);
-                        if (t == 0) { if (ok) p_schur<NX, NU, MD, true, RU>(L, loc, lane, 0, 0, Sy.sch + (size_t)ii * U::SCH * 2, tag_e, &Sy); }
-                        else p_schur<NX, NU, MD, false>(L, loc, lane, U::first(t - 1) + wave / MD, wave % MD, nullptr, 0u);
+                        if (t == 0) { if (ok) p_schur<NX, NU, MD, true, RU>(L, loc, lane, 0, 0, Sy.sch + (size_t)ii * U::SCH * 2, tag_e, Sy); }
+                        else p_schur<NX, NU, MD, false>(L, loc, lane, U::first(t - 1) + wave / MD, wave % MD, nullptr, 0u, Sy);
                         FSTAMP(4);
                     } else {
                         if (RU) p_store_factor<NX, NU, MD>(L, loc, lane, Tc);          /* a later pass may keep the root's factor as well */
@@ -1534,11 +1536,11 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
                 /* sharded launch: the ranks that do not run this workgroup read the verdict from their own slab once their launch has ended */
                 const size_t voff = (size_t)(Sy.verdict - Sy.base);
                 for (int r = 0; r < Sy.npeer; r++) {
-                    u64 *vq = Sy.peer[r] + voff;
+                    u64 *vq = Sy.peers[r] + voff;
                     for (int i = 0; i < (int)(sizeof(Ctrl) / 8); i++) __hip_atomic_store(vq + i, src[i], RLX, SYS);
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                for (int r = 0; r < Sy.npeer; r++) __hip_atomic_store(Sy.peer[r] + voff + 15, (u64)Sy.seq, RLX, SYS);
+                for (int r = 0; r < Sy.npeer; r++) __hip_atomic_store(Sy.peers[r] + voff + 15, (u64)Sy.seq, RLX, SYS);
             }
             unsigned long long *dst = reinterpret_cast<unsigned long long *>(&hr->c);
             for (int i = 0; i < (int)(sizeof(Ctrl) / 8); i++) __hip_atomic_store(dst + i, src[i], RLX, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1548,6 +1550,23 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
              * (NOT a system-scope release: that writes back the whole L2 of this XCD first -- 6 us measured, on the host's critical path) */
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(&hr->seq, Sy.seq, RLX, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (Sy.npeer > 1 && wg == Sy.relay_wg && threadIdx.x == 0) {
+            /* a rank that does not run the top workgroup: the verdict arrives in this rank's slab (pushed by the top workgroup); one of its
+             * workgroups passes it on to the rank's own host, which polls its result block as on a single device */
+            const u64 t0v = wall_clock64();
+            bool got = true;
+            while ((unsigned)__hip_atomic_load(Sy.verdict + 15, RLX, AGENT) != Sy.seq) {
+                if (wall_clock64() - t0v > 50000000ull) { got = false; break; }      /* 0.5 s: the top workgroup's rank is gone */
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (got) {
+                HostRes *hr = dp->hres;
+                unsigned long long *dst = reinterpret_cast<unsigned long long *>(&hr->c);
+                for (int i = 0; i < (int)(sizeof(Ctrl) / 8); i++) { const u64 wv = __hip_atomic_load(Sy.verdict + i, RLX, AGENT); __hip_atomic_store(dst + i, wv, RLX, SYS); reinterpret_cast<unsigned long long *>(C.ctrl)[i] = wv; }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&hr->seq, Sy.seq, RLX, SYS);
+            }
         }
         pstamp(C, O, (unsigned)O.stamps, tier, s, 29);                 /* 29: verdict on the host's way */
         if (nd > 0u) {
@@ -1603,7 +1622,14 @@ __device__ __forceinline__ void persist_entry(const PConst &C, const Opts &O, co
 template <int NX, int NU, int MD, bool RU>
 __global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_persist(PConst C, Opts O, PGeom Gm, PSync Sy, int prologue) {
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
+    Sy.npeer = 1; Sy.relay_wg = -1;          /* one device: a compile-time fact here, so that the stores to peer slabs and the verdict relay fold away (left as run-time tests they cost 18 us per C2 solve: scalar registers) */
     persist_entry<NX, NU, MD, RU>(C, O, Gm, Sy, prologue, (int)blockIdx.x, lds_all);
+}
+/* the same launch as one rank's share of a sharded solve (tqgpu_pshard_*): hand-over words go to every rank's slab */
+template <int NX, int NU, int MD>
+__global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_persist_sh(PConst C, Opts O, PGeom Gm, PSync Sy, int prologue) {
+    extern __shared__ __attribute__((aligned(16))) double lds_all[];
+    persist_entry<NX, NU, MD, false>(C, O, Gm, Sy, prologue, (int)blockIdx.x, lds_all);
 }
 
 /* multistage trees (branching for Nr stages, then one child per node -- the reference's setup_multistage_tree
@@ -1631,6 +1657,7 @@ __device__ __forceinline__ void mpersist_entry(const PConst &C, const Opts &O, c
 template <int NX, int NU, int MD, bool RU>
 __global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_mpersist(PConst C, Opts O, PGeom Gm, PSync Sy, int prologue) {
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
+    Sy.npeer = 1; Sy.relay_wg = -1;
     mpersist_entry<NX, NU, MD, RU>(C, O, Gm, Sy, prologue, (int)blockIdx.x, lds_all);
 }
 
@@ -1650,6 +1677,7 @@ __global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_persist_batch(const PItem
     PSync Sy = it->Sy;
     Sy.seq = seq;
     Sy.nap = nap;
+    Sy.npeer = 1; Sy.relay_wg = -1;
     if (MSTAGE) mpersist_entry<NX, NU, MD, false>(C, O, Gm, Sy, 1, b, lds_all);
     else persist_entry<NX, NU, MD, false>(C, O, Gm, Sy, 1, b, lds_all);
 }
