@@ -161,6 +161,8 @@ int tqgpu_solve_virtual_ranks(tqgpu_solver **ranks, int n, const tqgpu_opts *opt
  *                              flight together (they wait for each other: bounded, TQGPU_ETIMEOUT after 0.5 s) and every rank
  *                              must solve the same number of times (the launch number tags the words)
  *   tqgpu_pshard_solve_local   n mirrors of one process: connect, solve, collect the solution into every mirror */
+/* the partition without a device (host arithmetic; tqgpu_pshard_init uses it): this rank's workgroups of the persistent launch */
+int tqgpu_pshard_plan(int md, int Nh, int nranks, int rank, int *wgs, int cap, int *n, int *part_top, int *boundary_level);
 int tqgpu_pshard_init(tqgpu_solver *s, int rank, int nranks);
 int tqgpu_pshard_connect_local(tqgpu_solver *s, int r, tqgpu_solver *peer);
 int tqgpu_pshard_ipc_export(tqgpu_solver *s, void *handle64);

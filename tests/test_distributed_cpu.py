@@ -120,3 +120,87 @@ def test_gloo_world2_exchange_protocol():
     assert e0 == e1 == 1.25                     # same termination norm everywhere
     assert f0 == f1 and d0 == d1                # rank-ordered sums: bitwise identical on both ranks
     assert t0 == t1 == 2.0 and n0 == n1 == 60.0  # bench: max time over ranks, summed iterations
+
+
+# ---- sharded mode INSIDE the persistent launch (tqgpu_pshard_*): host side ------------------------------------------------
+
+def test_pshard_plan_deals_every_workgroup_exactly_once(capi):
+    """The product's planner (tqgpu_pshard_plan, host arithmetic, used by tqgpu_pshard_init) against its Python restatement; over
+    the ranks every workgroup of the single-device launch appears exactly once, partitioned tiers in equal contiguous ranges."""
+    import ctypes as C
+    L = capi.lib()
+    for md, Nh, n in [(2, 9, 1), (2, 9, 2), (2, 9, 4), (2, 9, 8), (2, 11, 2), (2, 11, 4), (2, 11, 8), (2, 6, 8), (3, 4, 3), (4, 4, 4), (2, 14, 8)]:
+        seen = []
+        for r in range(n):
+            pl = sharding.pshard_plan(md, Nh, n, r)
+            cnt, top, lb = C.c_int(), C.c_int(), C.c_int()
+            assert L.tqgpu_pshard_plan(md, Nh, n, r, None, 0, C.byref(cnt), C.byref(top), C.byref(lb)) == 0
+            wgs = (C.c_int * max(1, cnt.value))()
+            assert L.tqgpu_pshard_plan(md, Nh, n, r, wgs, cnt.value, C.byref(cnt), None, None) == 0
+            assert list(wgs)[:cnt.value] == list(pl["wgs"]) and (top.value, lb.value) == (pl["part_top"], pl["boundary_level"]), (md, Nh, n, r)
+            seen += list(pl["wgs"])
+            # every rank's node / dual chunks partition each level
+        assert sorted(seen) == list(range(sharding.pshard_plan(md, Nh, n, 0)["total"])), (md, Nh, n)
+        for l in range(Nh + 1):
+            for key in ("node_chunks", "dual_chunks"):
+                chunks = [sharding.pshard_plan(md, Nh, n, r)[key][l] for r in range(n)]
+                cover = sorted(i for f0, c in chunks for i in range(f0, f0 + c))
+                f0 = sharding.first_of_level(md, l)
+                assert cover == list(range(f0, f0 + md ** l)), (md, Nh, n, l, key)
+    assert L.tqgpu_pshard_plan(2, 3, 64, 0, None, 0, None, None, None) != 0          # too many ranks for the tree
+    with pytest.raises(ValueError):
+        sharding.pshard_plan(2, 3, 64, 0)
+
+
+def _pshard_collect_worker(rank, world, port, md, Nh, q):
+    """What tqgpu_pshard_pack / _unpack + an all-gather do after a sharded solve, on host arrays: every rank holds its chunks of the
+    per-node and per-edge data (and rank 0 the levels above the partition); after the exchange every rank holds everything."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    Nn = sharding.first_of_level(md, Nh + 1)
+    truth_x = np.arange(Nn, dtype=np.float64) * 1.5 + 0.25
+    truth_l = -np.arange(Nn, dtype=np.float64) - 7.0
+    pl = sharding.pshard_plan(md, Nh, world, rank)
+    x = np.full(Nn, np.nan)
+    lam = np.full(Nn, np.nan)
+    for f0, c in pl["node_chunks"]:
+        x[f0:f0 + c] = truth_x[f0:f0 + c]
+    for f0, c in pl["dual_chunks"]:
+        lam[f0:f0 + c] = truth_l[f0:f0 + c]
+    p0 = sharding.pshard_plan(md, Nh, world, 0)
+    size = sum(c for _, c in p0["node_chunks"]) + sum(c for _, c in p0["dual_chunks"])          # rank 0 holds the most: equal-sized buffers
+    def pack():
+        out = np.zeros(size)
+        o = 0
+        for (f0, c), (g0, e) in zip(pl["node_chunks"], pl["dual_chunks"]):
+            out[o:o + c] = x[f0:f0 + c]; o += c
+            out[o:o + e] = lam[g0:g0 + e]; o += e
+        return out
+    bufs = [torch.zeros(size, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(bufs, torch.from_numpy(pack()))
+    for r in range(world):
+        pr = sharding.pshard_plan(md, Nh, world, r)
+        b, o = bufs[r].numpy(), 0
+        for (f0, c), (g0, e) in zip(pr["node_chunks"], pr["dual_chunks"]):
+            x[f0:f0 + c] = b[o:o + c]; o += c
+            lam[g0:g0 + e] = b[o:o + e]; o += e
+    q.put((rank, bool(np.array_equal(x, truth_x) and np.array_equal(lam, truth_l))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pshard_solution_collection_protocol_world_size_2():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pshard_collect_worker, args=(r, 2, port, 2, 9, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p_ in procs:
+        p_.join(timeout=60)
+    assert res == [(0, True), (1, True)]
+

@@ -1047,6 +1047,7 @@ struct tqgpu_solver {
     size_t lds_hf_w = 0, lds_sgp = 0;
     int sgp_accs = 0;
     bool w3_sgp = false;                /* k_sgp (a workgroup per parent) instead of k_sg (a wave per node) */
+    std::vector<int> ls_pred;           /* trials per iteration of the previous solve: that many trial launches are enqueued behind an iteration's forward sweep (a trial beyond the accepted one is a no-op; a read-back per extra trial is 20 us) */
     bool dense = false, need_dense_init = false;   /* dense unconstrained stage solver selected (generic path only) */
     double *d_Hd = nullptr;      /* writable alias of Data.Hd */
     int *d_kind = nullptr;       /* writable alias of Data.kind */
@@ -1541,8 +1542,8 @@ static W3 next_w3(tqgpu_solver *s) {
     w.tag = s->w3_epoch;
     return w;
 }
-static void launch_sg(tqgpu_solver *s, const Opts &O, int mode, int h, int t) {
-    if (s->w3_sgp) { hipLaunchKernelGGL(k_sgp, dim3(s->T.Np), dim3(WT), s->lds_sgp, s->stream, s->T, s->D, O, next_w3(s), mode, h, t, s->sgp_accs); return; }
+static void launch_sg(tqgpu_solver *s, const Opts &O, int mode, int h, int t, bool fresh = false) {
+    if (s->w3_sgp) { hipLaunchKernelGGL(k_sgp, dim3(s->T.Np), dim3(WT), s->lds_sgp, s->stream, s->T, s->D, O, next_w3(s), mode, h, t, s->sgp_accs, fresh ? s->d_lam_init : nullptr); return; }
     const int grid = (s->T.Nn + SG_WAVES - 1) / SG_WAVES;
     hipLaunchKernelGGL(k_sg, dim3(grid), dim3(SG_WAVES * WAVE), SG_WAVES * ((s->lds_stage + 7) / 8) * 8, s->stream, s->T, s->D, O, next_w3(s), mode, h, t);
 }
@@ -1798,6 +1799,8 @@ void launch_generic_iteration(tqgpu_solver *s, const Opts &O, int h, int &launch
             hipLaunchKernelGGL(k_fwd3, dim3((T.Np - 1 + SG_WAVES - 1) / SG_WAVES), dim3(SG_WAVES * WAVE), 0, st, T, D, next_w3(s), s->fw_words, s->fw_epoch, h); launches++;
         } else { hipLaunchKernelGGL(k_ls_begin, dim3(1), dim3(256), 0, st, T, D, h); launches++; }
         launch_sg(s, O, 1, h, 1); launches++;
+        const int kpred = h < (int)s->ls_pred.size() ? std::min(s->ls_pred[(size_t)h], O.lsMaxIter) : 1;
+        for (int tt = 2; tt <= kpred; tt++) { launch_sg(s, O, 1, h, tt); launches++; }
         return;
     }
     mark(0);
@@ -2378,6 +2381,7 @@ extern "C" int tqgpu_set_problem(tqgpu_solver *s, const double *A, const double 
 namespace {
 
 int read_ctrl(tqgpu_solver *s) {
+    if (s->w3_now) HIP_TRY(hipMemcpyAsync(s->h_ls_log, s->D.ls_log, sizeof(int) * (size_t)std::min(s->ls_log_cap, 256), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipMemcpyAsync(s->h_ctrl, s->D.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     return TQGPU_OK;
@@ -2475,7 +2479,9 @@ int solve_begin(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, GItem *defer
     cx.events = (s->ev_timing || !cx.persist) && !cx.batch_seq;
     s->ring_ok[(size_t)cx.ring] = cx.events ? 1 : 0;
     if (cx.events) HIP_TRY(hipEventRecord(cx.ev0, st));
-    if (!cx.persist) HIP_TRY(hipMemsetAsync(D.ctrl, 0, sizeof(Ctrl), st));     /* persistent path: reset by the launch's prologue */
+    /* the three-launch family with k_sgp: the first launch of the solve takes the starting duals and resets the control block itself */
+    const bool w3_fresh = !cx.persist && s->w3_ok && s->w3_sgp && !s->dense && o->profile < 3 && !tiered_capable(s) && !s->sharded;
+    if (!cx.persist && !w3_fresh) HIP_TRY(hipMemsetAsync(D.ctrl, 0, sizeof(Ctrl), st));     /* persistent path: reset by the launch's prologue */
     if (s->need_init && !cx.gpersist) {     /* g_persist recomputes the reciprocal weights itself; dense nodes never read theirs */
         hipLaunchKernelGGL(k_init, dim3((nxu + 255) / 256), dim3(256), 0, st, s->sum_nx, s->sum_nu, D); cx.launches++;
         s->need_init = false;
@@ -2487,12 +2493,12 @@ int solve_begin(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, GItem *defer
     }
     if (!cx.persist) {
         /* the current buffer is lam0 at the start of every solve */
-        HIP_TRY(hipMemcpyAsync(D.lam0, s->d_lam_init, sizeof(double) * (size_t)s->sum_nx, hipMemcpyDeviceToDevice, st));
+        if (!w3_fresh) HIP_TRY(hipMemcpyAsync(D.lam0, s->d_lam_init, sizeof(double) * (size_t)s->sum_nx, hipMemcpyDeviceToDevice, st));
         /* first sweep at lambda0 (phase S of iteration 0 + fval0); the persistent launch does it as its prologue */
         if (cx.phases) HIP_TRY(hipEventRecord(s->sweep_ev0, st));
         s->w3_now = s->w3_ok && !s->dense && !cx.phases && !cx.fast && !s->sharded;
         s->fuse_now = s->fuse_ok && !cx.phases && !cx.fast && !s->sharded && !s->w3_now;
-        if (s->w3_now) { launch_sg(s, cx.O, 0, 0, 0); cx.launches++; }          /* with fval0 and the first termination test as its tail */
+        if (s->w3_now) { launch_sg(s, cx.O, 0, 0, 0, w3_fresh); cx.launches++; }          /* with fval0 and the first termination test as its tail */
         else if (s->fuse_now) { hipLaunchKernelGGL(k_stage_f, dim3(T.Nn), dim3(WAVE), s->lds_stage, st, T, D, cx.O, next_fuse(s), 0, 0, 0); cx.launches++; }      /* with k_fval_init as its tail */
         else {
             hipLaunchKernelGGL(k_stage, dim3(T.Nn), dim3(WAVE), s->lds_stage, st, T, D, 0, 0, 0); cx.launches++;
@@ -2548,7 +2554,7 @@ int solve_end(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, tqgpu_result *
      * backtracked last time is fed two iterations at a time (TREEQP_AMD_LS_CHUNK; one C5-class tree: 1.15 ms with chunks of 8, 1.04 / 1.01 / 1.06 ms with 4 / 2 / 1),
      * a read-back per chunk instead */
     static const int ls_chunk = getenv("TREEQP_AMD_LS_CHUNK") ? std::max(1, atoi(getenv("TREEQP_AMD_LS_CHUNK"))) : 2;
-    if (s->last_ls_extra && !fast && !persist && chunk > ls_chunk) { chunk = ls_chunk; predicted = false; }
+    if (s->last_ls_extra && !fast && !persist && chunk > ls_chunk && !(s->w3_now && !s->ls_pred.empty())) { chunk = ls_chunk; predicted = false; }      /* (three-launch family: the further trials are predicted too) */
     if (cx.phases) { chunk = 1; predicted = false; }            /* phase timing: one iteration per read-back, so that every recorded event belongs to work that ran */
     int rest_due = -1;                                          /* iteration whose termination test ran, whose step did not */
     while (!finished) {
@@ -2646,6 +2652,10 @@ int solve_end(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, tqgpu_result *
     res->n_launches = launches; res->device_time = 1e-3 * ms; res->last_error_norm = c.err; res->last_fval = c.fval;
     s->last_iter = c.iter;
     s->last_ls_extra = c.ls_total > c.iter ? 1 : 0;
+    if (s->w3_now) {
+        s->ls_pred.clear();
+        if (c.status == 0 && c.ls_total > c.iter) s->ls_pred.assign(s->h_ls_log, s->h_ls_log + std::min(c.iter, std::min(s->ls_log_cap, 256)));
+    }
     return TQGPU_OK;
 }
 
@@ -3141,14 +3151,12 @@ extern "C" int tqgpu_pshard_init(tqgpu_solver *s, int rank, int nranks) {
 #undef X
         default: break;
     }
-    const int top = nranks == 1 ? s->n_tiers - 1 : pshard_part_top(s, nranks);
-    if (top < 0) return fail(TQGPU_EUNSUPPORTED, "tree too small to shard over this many ranks");
-    std::vector<int> map;
-    for (int i = 0; i < s->n_tiers; i++)
-        for (int q = 0; q < s->tier_grid[i]; q++) {
-            const int owner = (nranks > 1 && i <= top) ? q / (s->tier_grid[i] / nranks) : 0;
-            if (owner == rank) map.push_back(s->geom.wg0[i] + q);
-        }
+    int nwg = 0, top = -1;
+    if (tqgpu_pshard_plan(s->fMD, s->Nh, nranks, rank, nullptr, 0, &nwg, &top, nullptr) != 0) return fail(TQGPU_EUNSUPPORTED, "tree too small to shard over this many ranks");
+    std::vector<int> map((size_t)std::max(nwg, 1));
+    (void)tqgpu_pshard_plan(s->fMD, s->Nh, nranks, rank, map.data(), nwg, &nwg, &top, nullptr);
+    map.resize((size_t)nwg);
+    if (nranks == 1) top = s->n_tiers - 1;
     if ((int)map.size() > s->co_capacity) return fail(TQGPU_EUNSUPPORTED, "this rank's workgroups cannot all be resident");
     if (s->ps_wg_map) { (void)hipFree(s->ps_wg_map); s->ps_wg_map = nullptr; }
     HIP_TRY(hipMalloc(&s->ps_wg_map, sizeof(int) * std::max<size_t>(map.size(), 1)));

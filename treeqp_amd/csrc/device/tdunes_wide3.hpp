@@ -244,7 +244,10 @@ __device__ __forceinline__ double sgp_finish(const Data &D, const SgNode &n, dou
 #else
 #define SGSTAMP(k_) do { } while (0)
 #endif
-__global__ void __launch_bounds__(WT) k_sgp(Tree T, Data D, Opts O, W3 Wd, int mode, int h, int t, int accs_cap) {
+/* mode 0 with lam_src != nullptr: the first sweep of a solve reads the starting duals from lam_src, copies them into the current buffer
+ * (every node's own slice is written by the workgroup that stages the node) and its tail writes the WHOLE control block: no copy and
+ * no memset in front of the launch */
+__global__ void __launch_bounds__(WT) k_sgp(Tree T, Data D, Opts O, W3 Wd, int mode, int h, int t, int accs_cap, const double *lam_src) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double part[2][WW];
     Ctrl *c = D.ctrl;
@@ -253,13 +256,14 @@ __global__ void __launch_bounds__(WT) k_sgp(Tree T, Data D, Opts O, W3 Wd, int m
     int e[28];
 #pragma unroll
     for (int i = 0; i < 28; i++) e[i] = T.desc[(size_t)DESC_INTS * p + i];
-    const int cur = c->cur, ls_iter = c->ls_iter;
+    const bool fresh = mode == 0 && lam_src != nullptr;
+    const int cur = fresh ? 0 : c->cur, ls_iter = c->ls_iter;
     const double step = c->tau - c->tauPrev;
     if (mode == 1 && !phase_trial(c, h, t)) return;
     const int d = e[0], nxp = e[1], nup = e[2], nkp = e[3], k0 = e[4], nz = nxp + nup, xop = e[5], uop = e[6], ko = e[7];
     SGSTAMP(0);
     const bool save_s = mode == 1 && ls_iter == 1;      /* first trial of a line search: xUnc / uUnc still hold phase S of this iteration */
-    const double *lamc = cur ? D.lam1 : D.lam0;
+    const double *lamc = fresh ? lam_src : (cur ? D.lam1 : D.lam0);
     double *lamn = cur ? D.lam0 : D.lam1;
     const int ldc = d | 1;
     lds_ptr Cs = to_lds(lds);                           /* d x nz, leading dimension ldc (odd: lanes over rows and lanes over columns both spread over the banks) */
@@ -337,7 +341,7 @@ __global__ void __launch_bounds__(WT) k_sgp(Tree T, Data D, Opts O, W3 Wd, int m
         /* node p */
         const bool isx = lane < nxp, in = lane < nz;
         double lown = 0.0;
-        if (p > 0 && isx) { lown = mode == 1 ? fma(step, nd.dl, nd.lam) : nd.lam; if (mode == 1) lamn[xop + lane] = lown; }
+        if (p > 0 && isx) { lown = mode == 1 ? fma(step, nd.dl, nd.lam) : nd.lam; if (mode == 1) lamn[xop + lane] = lown; else if (fresh) D.lam0[xop + lane] = lown; }
         double v = isx ? fma(-1.0, nd.qv, lown) : -1.0 * nd.qv;
         if (in) {
             if (nkp * nz <= accs_cap) { for (int cc = 0; cc < nkp; cc++) v = fma(-1.0, accs[cc * nz + lane], v); }
@@ -371,7 +375,7 @@ __global__ void __launch_bounds__(WT) k_sgp(Tree T, Data D, Opts O, W3 Wd, int m
             }
             const bool isx = lane < nxl;
             double lown = 0.0;
-            if (isx) { lown = mode == 1 ? fma(step, nd.dl, nd.lam) : nd.lam; if (mode == 1) lamn[xol + lane] = lown; }
+            if (isx) { lown = mode == 1 ? fma(step, nd.dl, nd.lam) : nd.lam; if (mode == 1) lamn[xol + lane] = lown; else if (fresh) D.lam0[xol + lane] = lown; }
             const double v = isx ? fma(-1.0, nd.qv, lown) : -1.0 * nd.qv;
             double xv;
             const double f = sgp_finish(D, nd, v, 0.0, save_s, nxl, nul, xol, uol, lane, xv);
@@ -432,7 +436,10 @@ __global__ void __launch_bounds__(WT) k_sgp(Tree T, Data D, Opts O, W3 Wd, int m
     w3_reduce2(Wd.red, (int)gridDim.x, Wd.tag, lane, mx, f, err);
     if (lane == 0) {
         bool test = true;
-        if (mode == 0) { c->fval0 = f; c->fval = f; }
+        if (mode == 0) {
+            if (fresh) { Ctrl z{}; *c = z; }          /* a new solve: the control block starts from zero (k_hf_w counts regularised blocks into it) */
+            c->fval0 = f; c->fval = f;
+        }
         else { ls_decide_tail(c, D, O, f); test = !c->done && !c->ls_pending; }
         if (test) {
             if (O.termCondition == 1) err = sqrt(err);

@@ -119,3 +119,41 @@ void setup_multistage_tree(int md, int Nr, int Nh, int *nk)
     }
     for (int i = 0; i < width; i++) nk[first + i] = 0;
 }
+
+/* Partition of the persistent launch's workgroups over the ranks of a sharded solve (treeqp_amd.h: tqgpu_pshard_*), host
+ * arithmetic only.  Uniform complete md-ary tree with Nh block levels; tiers of the fused path bottom-up (3 levels for md = 2,
+ * 2 for md <= 4, else 1; the top tier takes the rest); workgroups are numbered tier by tier from the bottom, one per tier subtree.
+ * Tiers whose subtree count is a multiple of nranks go to the ranks by contiguous subtree ranges (the independent subtrees of
+ * dual_Newton_tree.c:668-775), the tiers above them to rank 0.  wgs (may be NULL): this rank's workgroups, bottom tier first;
+ * *n: how many; *part_top: the highest partitioned tier (-1: one rank); *boundary_level: the tree level of the partitioned
+ * subtree roots.  Returns 0, or -1 when the tree is too small for that many ranks. */
+int tqgpu_pshard_plan(int md, int Nh, int nranks, int rank, int *wgs, int cap, int *n, int *part_top, int *boundary_level)
+{
+    if (md < 2 || Nh < 1 || nranks < 1 || rank < 0 || rank >= nranks) return -1;
+    const int TH = md == 2 ? 3 : (md <= 4 ? 2 : 1);
+    const int nt = (Nh + TH - 1) / TH;
+    int l0v[64], gridv[64];
+    if (nt > 64) return -1;
+    for (int i = 0; i < nt; i++) {
+        const int l1 = Nh - i * TH, l0 = l1 - TH > 0 ? l1 - TH : 0;
+        int grid = 1;
+        for (int l = 0; l < l0; l++) grid *= md;
+        l0v[i] = l0; gridv[i] = grid;
+    }
+    int top = nranks == 1 ? nt - 1 : -1;
+    if (nranks > 1) for (int i = 0; i < nt - 1; i++) if (gridv[i] % nranks == 0 && gridv[i] >= nranks) top = i;
+    if (top < 0) return -1;
+    int count = 0, wg0 = 0;
+    for (int i = 0; i < nt; i++) {
+        for (int q = 0; q < gridv[i]; q++) {
+            const int owner = (nranks > 1 && i <= top) ? q / (gridv[i] / nranks) : 0;
+            if (owner == rank) { if (wgs && count < cap) wgs[count] = wg0 + q; count++; }
+        }
+        wg0 += gridv[i];
+    }
+    if (n) *n = count;
+    if (part_top) *part_top = nranks > 1 ? top : -1;
+    if (boundary_level) *boundary_level = nranks > 1 ? l0v[top] : 0;
+    return 0;
+}
+
