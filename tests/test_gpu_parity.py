@@ -300,6 +300,19 @@ def test_three_launch_family_matches_oracle_and_launch_per_phase(gpu, orc, reg):
     assert extra_trials > 0                                                        # the cases have what they are meant to exercise
 
 
+@pytest.mark.parametrize("term", [0, 1], ids=["sum_of_squares", "two_norm"])
+def test_three_launch_family_termination_norms(gpu, orc, term):
+    """The termination partials of k_sgp are per workgroup (sum of squares) instead of per node: same verdicts as the oracle for the
+    norms that are sums (termCondition 0 / 1; the default, the maximum norm, is order-independent)."""
+    f = P.pruned_chain_qp()
+    opts = dict(f.opts)
+    opts.update(termCondition=term, stationarityTolerance=1e-7 if term == 0 else 1e-8)
+    ref = orc.solve(f.as_dict(), orc.default_opts(**opts), lambda0=f.lambda0)
+    r3, s3, _ = _solve_flat_tq(gpu, f.as_dict(), f.lambda0, "generic", **opts)
+    assert (r3["status"], r3["iter"], r3["ls_total"]) == (ref["status"], ref["iter"], ref["ls_total"]) and ref["status"] == 0
+    assert_solution_close(s3, ref, TOL)
+
+
 def test_three_launch_family_c4_launch_count(gpu, orc):
     """BASELINE config C4 (3280 nodes, 60 x 60 blocks, one Newton iteration): k_sgp, k_hf_w, k_fwd3, k_sgp."""
     f = P.random_clipping_qp()

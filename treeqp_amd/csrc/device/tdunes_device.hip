@@ -2381,7 +2381,6 @@ extern "C" int tqgpu_set_problem(tqgpu_solver *s, const double *A, const double 
 namespace {
 
 int read_ctrl(tqgpu_solver *s) {
-    if (s->w3_now) HIP_TRY(hipMemcpyAsync(s->h_ls_log, s->D.ls_log, sizeof(int) * (size_t)std::min(s->ls_log_cap, 256), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipMemcpyAsync(s->h_ctrl, s->D.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     return TQGPU_OK;
@@ -2654,7 +2653,12 @@ int solve_end(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, tqgpu_result *
     s->last_ls_extra = c.ls_total > c.iter ? 1 : 0;
     if (s->w3_now) {
         s->ls_pred.clear();
-        if (c.status == 0 && c.ls_total > c.iter) s->ls_pred.assign(s->h_ls_log, s->h_ls_log + std::min(c.iter, std::min(s->ls_log_cap, 256)));
+        if (c.status == 0 && c.ls_total > c.iter) {
+            /* some iteration needed further trials: fetch the trial counts (only then: a copy is a packet on the queue and a synchronisation) */
+            const int nlog = std::min(c.iter, std::min(s->ls_log_cap, 256));
+            HIP_TRY(hipMemcpy(s->h_ls_log, s->D.ls_log, sizeof(int) * (size_t)nlog, hipMemcpyDeviceToHost));
+            s->ls_pred.assign(s->h_ls_log, s->h_ls_log + nlog);
+        }
     }
     return TQGPU_OK;
 }

@@ -779,6 +779,7 @@ __global__ void __launch_bounds__(WT, TQ_W3_WPS) k_hf_w(Tree T, Data D, Opts O, 
 #pragma unroll
                 for (int m = 0; m < MP; m++) if (dst[m] >= 0) pending |= 1u << m;
                 const u64 t0 = wall_clock64();
+                int looks = 0;
                 while (pending) {
 #pragma unroll
                     for (int m = 0; m < MP; m++) {
@@ -789,13 +790,21 @@ __global__ void __launch_bounds__(WT, TQ_W3_WPS) k_hf_w(Tree T, Data D, Opts O, 
                         }
                     }
                     if (!pending) break;
+                    looks++;
                     if (wall_clock64() - t0 > 50000000ull) {      /* 0.5 s at 100 MHz: cannot happen (children are started first) */
 #pragma unroll
                         for (int m = 0; m < MP; m++) if (pending & (1u << m)) val[m] = 0.0;
                         pending = 0u; dead = true;
                         break;
                     }
-                    __builtin_amdgcn_s_sleep(TQ_WIDE_NAP);
+#ifndef TQ_W3_BACKOFF
+#define TQ_W3_BACKOFF 0
+#endif
+                    /* the upper levels wait tens of microseconds while the levels below them work, and every look of a waiting workgroup
+                     * (12 loads per thread) is in the way of the working ones: look less often the longer the wait already is */
+                    if (TQ_W3_BACKOFF >= 2 && looks > 24) __builtin_amdgcn_s_sleep(16);
+                    else if (TQ_W3_BACKOFF >= 1 && looks > 6) __builtin_amdgcn_s_sleep(4);
+                    else __builtin_amdgcn_s_sleep(TQ_WIDE_NAP);
                 }
 #pragma unroll
                 for (int m = 0; m < MP; m++) if (dst[m] >= 0) Tm[dst[m]] -= val[m];
