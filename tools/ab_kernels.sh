@@ -1,3 +1,5 @@
+# A/B of device-code builds (treeqp_amd/lib_var/<name>, see tools/vbuild.sh) on C4: rocprofv3 kernel averages of 40 solves per build, two rounds.
+# usage (through gpurun): bash tools/ab_kernels.sh dev other ...
 # A/B of device-code variants on C4: rocprofv3 kernel averages of 30 solves each, two rounds
 mkdir -p gpurun_out/r3e && cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for round in 1 2; do

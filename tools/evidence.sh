@@ -1,3 +1,5 @@
+# Evidence set for one BASELINE workload on the GPU box: bench line, rocprofv3 kernel statistics, PMC passes (traffic + SQ / MFMA counters).
+# usage (through gpurun): bash tools/evidence.sh C4 r03_v1   ->  gpurun_out/r03_v1/C4_{bench.json,kernel_stats.csv,pmc.txt}
 # full evidence run for one workload: tests (optional), bench line, kernel stats, PMC traffic
 W=${1:-C4}; TAG=${2:-r03_v1}
 mkdir -p gpurun_out/$TAG && cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
