@@ -201,9 +201,59 @@ __device__ __forceinline__ void potrf_v0m(double (&T)[D]) {
     }
 }
 
+/* variant 11 (round 3; asked for in round 2's review): 4-column panels factorised on VALU (row per lane, readlane broadcasts INSIDE the
+ * panel only: 6 per panel instead of 120 for the block), the rank-4 trailing update of the later columns as v_mfma_f64_16x16x4 tiles on
+ * the matrix pipe (three row tiles of 16 for the 41 rows).  The wave holds the block one row per lane; an MFMA wants lane (r, g) = (row or
+ * column r of the tile, k-group g): the panel goes to LDS row by row (two ds_write_b128 per lane), comes back as A / B operands, the
+ * product goes to LDS in the accumulator layout and comes back as rows. */
+typedef double f64x4_b __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void potrf_v11(double (&T)[D], lds_f64 *P /* 48 x 4 */, lds_f64 *U /* 48 x 17 */, int lane) {
+    const int r16 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        /* the panel: columns 4p .. 4p + 3, left-looking inside the panel */
+#pragma unroll
+        for (int j = 4 * p; j < 4 * p + 4; j++) {
+            double s = T[j];
+#pragma unroll
+            for (int k = 4 * p; k < j; k++) s = fma(-T[k], rdlane(T[k], j), s);
+            const double pj = rdlane(s, j);
+            T[j] = s * pivot_rsqrt3m(pj);
+        }
+        if (p == 3) break;
+        /* rows of the panel -> LDS (row i: P[4 i .. 4 i + 3]) */
+        if (lane < 48) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) P[4 * lane + k] = T[4 * p + k];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        /* update = L[rows][panel] * L[cols][panel]' for the columns behind the panel; A: lane (j, k) = L[j][4p + k] for columns j >= 4 (p + 1), else 0 */
+        const double a = (r16 >= 4 * (p + 1)) ? P[4 * r16 + g] : 0.0;
+        f64x4_b acc[3];
+#pragma unroll
+        for (int I = 0; I < 3; I++) {
+            const double b = P[4 * (16 * I + r16) + g];
+            acc[I] = f64x4_b{0.0, 0.0, 0.0, 0.0};
+            acc[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[I], 0, 0, 0);
+        }
+        /* accumulator layout: lane (r, g), register q = element (row 16 I + r, column g + 4 q) -> LDS U[row][column] (ld 17) */
+#pragma unroll
+        for (int I = 0; I < 3; I++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) U[(16 * I + r16) * 17 + g + 4 * q] = acc[I][q];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        /* back as rows: lane i takes its row of the update for the columns behind the panel */
+        if (lane < 48) {
+#pragma unroll
+            for (int c = 4 * (p + 1); c < D; c++) T[c] -= U[lane * 17 + c];
+        }
+    }
+}
+
 template <int V>
 __global__ void bench(const double *in, double *out, long long *cycles, int reps) {
     __shared__ __attribute__((aligned(16))) double lds_raw[17 * 18 + 8];
+    __shared__ __attribute__((aligned(16))) double lds_p[48 * 4], lds_u[48 * 17 + 8];
     lds_f64 *Lw = (lds_f64 *)lds_raw;
     const int lane = threadIdx.x, c = lane & 15;
     /* `in`: 41 rows x 16: rows 0..15 W, 16..24 rhs / Ut, 25..40 identity */
@@ -229,6 +279,7 @@ __global__ void bench(const double *in, double *out, long long *cycles, int reps
         if (V == 8) { double z[D]; for (int k = 0; k < D; k++) z[k] = 0.0; LdsLeft<0, false>::run(T, Lw, lane, z); }
         if (V == 9) { double z[D]; for (int k = 0; k < D; k++) z[k] = 0.0; LdsLeft<0, true>::run(T, Lw, lane, z); }
         if (V == 10) potrf_v0m(T);
+        if (V == 11) potrf_v11(T, (lds_f64 *)lds_p, (lds_f64 *)lds_u, lane);
 #pragma unroll
         for (int j = 0; j < D; j++) acc += T[j];
     }
@@ -284,7 +335,7 @@ int main() {
     hipMemcpy(din, h.data(), sizeof(double) * 42 * D, hipMemcpyHostToDevice);
     long long c[8];
     std::vector<double> ref(41 * D), got(41 * D);
-    for (int v = 0; v <= 10; v++) {
+    for (int v = 0; v <= 11; v++) {
         hipMemset(dout, 0, sizeof(double) * 64 * D);
         for (int it = 0; it < 2; it++) {
             switch (v) {
@@ -299,6 +350,7 @@ int main() {
                 case 8: hipLaunchKernelGGL(bench<8>, dim3(1), dim3(64), 0, 0, din, dout, dc, 200); break;
                 case 9: hipLaunchKernelGGL(bench<9>, dim3(1), dim3(64), 0, 0, din, dout, dc, 200); break;
                 case 10: hipLaunchKernelGGL(bench<10>, dim3(1), dim3(64), 0, 0, din, dout, dc, 200); break;
+                case 11: hipLaunchKernelGGL(bench<11>, dim3(1), dim3(64), 0, 0, din, dout, dc, 200); break;
             }
             hipDeviceSynchronize();
         }
@@ -311,7 +363,8 @@ int main() {
             err = fmax(err, fabs(got[i * D + j] - ref[i * D + j]));
         }
         const char *names[] = {"readlane left-looking (production)", "dpp left-looking, nops", "dpp left-looking, no nops", "dpp right-looking, nops",
-                               "readlane, two columns per step", "dpp two columns per step, nops", "dpp two columns per step, no nops", "dpp right-looking, no nops", "lds row broadcast, left-looking", "lds row broadcast, max-select pivot", "readlane, max-select pivot"};
+                               "readlane, two columns per step", "dpp two columns per step, nops", "dpp two columns per step, no nops", "dpp right-looking, no nops", "lds row broadcast, left-looking", "lds row broadcast, max-select pivot", "readlane, max-select pivot",
+                               "4-col panels on VALU + rank-4 MFMA updates"};
         printf("variant %d %-40s %6lld cycles per 41x16 tall potrf   (max diff vs v0 %.2e)\n", v, names[v], c[0], err);
     }
     hipLaunchKernelGGL(probe, dim3(1), dim3(64), 0, 0, dout, dc); hipDeviceSynchronize();
