@@ -168,6 +168,10 @@ int tqgpu_pshard_connect_local(tqgpu_solver *s, int r, tqgpu_solver *peer);
 int tqgpu_pshard_ipc_export(tqgpu_solver *s, void *handle64);
 int tqgpu_pshard_ipc_connect(tqgpu_solver *s, int r, const void *handle64);
 int tqgpu_pshard_begin(tqgpu_solver *s, const tqgpu_opts *opts);
+/* after 65535 sharded solves tqgpu_pshard_begin refuses (the 16-bit launch number tags the hand-over words): every rank then calls
+ * tqgpu_pshard_rewind -- launch numbers back to zero, slab wiped, peers stay connected -- with no sharded solve in flight anywhere, i.e.
+ * between two barriers of the caller's.  tqgpu_pshard_solve_local does it by itself. */
+int tqgpu_pshard_rewind(tqgpu_solver *s);
 int tqgpu_pshard_end(tqgpu_solver *s, tqgpu_result *res);
 long tqgpu_pshard_pack_size(tqgpu_solver *s);
 int tqgpu_pshard_pack(tqgpu_solver *s, double *out, long cap);

@@ -69,6 +69,36 @@ def test_four_and_eight_ranks_of_one_process(gpu, tmp_path, levels, ranks):
         assert f"{n} ranks: ok" in out.stdout
 
 
+def test_launch_number_wrap_is_refused_until_every_rank_rewinds(gpu):
+    """The launch number that tags the hand-over words has 16 bits.  A single device wipes its slab when it wraps; ranks that write
+    into each other's slabs cannot do that on their own (a peer's early words would be wiped): after 65535 solves tqgpu_pshard_begin
+    refuses, tqgpu_pshard_rewind on every rank (all idle) resets, and the solves continue with identical results."""
+    p = P.linear_chain(2, 6, 6)
+    nk, nx, nu, flat = _lti(gpu, p)
+    g = gpu.TqGpu(nk, nx, nu).upload(flat, p.lambda0)
+    ref_r, ref = g.solve(), g.solution()
+    g.close()
+    ms = [gpu.TqGpu(nk, nx, nu).upload(flat, p.lambda0).pshard_init(r, 2) for r in range(2)]
+    gpu.pshard_solve_local(ms)                              # connects; solve 1
+    done = 1
+    with pytest.raises(RuntimeError, match="65535"):
+        while done < 70000:
+            ms[0].pshard_begin()
+            ms[1].pshard_begin()
+            r0, r1 = ms[0].pshard_end(), ms[1].pshard_end()
+            assert (r0["status"], r0["iter"]) == (ref_r["status"], ref_r["iter"]) == (r1["status"], r1["iter"])
+            done += 1
+    assert done == 65535
+    for m in ms:
+        m.pshard_rewind()
+    rs = gpu.pshard_solve_local(ms)
+    assert all((r["status"], r["iter"], r["ls_total"]) == (ref_r["status"], ref_r["iter"], ref_r["ls_total"]) for r in rs)
+    for m in ms:
+        sol = m.solution()
+        assert all(np.array_equal(sol[k], ref[k]) for k in ("x", "u", "lam", "mu_x", "mu_u"))
+        m.close()
+
+
 def test_pshard_rejects_what_it_cannot_shard(gpu):
     f = P.irregular_clipping_qp()
     g = gpu.TqGpu(f.nk, f.nx, f.nu)

@@ -46,6 +46,8 @@ for name, levels, ranks in (("C2", 9, 2), ("C2", 9, 4), ("C3", 11, 2), ("C3", 11
     capi.pshard_solve_local(ms)
     t0 = time.perf_counter()
     for i in range(n):
+        if i % 50000 == 49999:                               # the 16-bit launch number: rewind before it wraps (all ranks idle here)
+            for m in ms: m.pshard_rewind()
         for m in ms: m.pshard_begin()
         rs = [m.pshard_end() for m in ms]
         assert all((r["status"], r["iter"], r["ls_total"]) == (ref_r["status"], ref_r["iter"], ref_r["ls_total"]) for r in rs), (i, rs)

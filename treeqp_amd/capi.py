@@ -630,6 +630,9 @@ class TqGpu:
         o = _default_opts(**kw)
         self._chk(lib().tqgpu_pshard_begin(self.h, C.byref(o)))
 
+    def pshard_rewind(self):
+        self._chk(lib().tqgpu_pshard_rewind(self.h))
+
     def pshard_end(self) -> dict:
         r = GpuResult()
         self._chk(lib().tqgpu_pshard_end(self.h, C.byref(r)))

@@ -26,6 +26,11 @@
  *
  * Control flow lives in a device control block (struct Ctrl): every kernel first looks at it and
  * returns if its phase is not due, so the host may enqueue ahead without reading back.
+ *
+ * The kernels above are the launch-per-phase protocol (any tree).  Faster protocols for the trees that admit them are in the
+ * headers included below: tdunes_fast.hpp / tdunes_persist.hpp (uniform and multistage trees: the whole solve as ONE launch, also
+ * dealt over several devices: tqgpu_pshard_*), tdunes_wide.hpp / tdunes_wide3.hpp (dual blocks of 16 < d <= 64 rows: MFMA kernels,
+ * three launches per Newton iteration), tdunes_gpersist.hpp (small trees of any shape: one workgroup per tree).
  */
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
@@ -1148,7 +1153,7 @@ struct tqgpu_solver {
 };
 
 extern "C" const char *tqgpu_last_error(void) { return g_err.c_str(); }
-extern "C" const char *tqgpu_version(void) { return "treeqp_amd tdunes device path r1 (gfx950, generic wave-per-block kernels)"; }
+extern "C" const char *tqgpu_version(void) { return "treeqp_amd tdunes device path r3 (gfx950: persistent single launch, three-launch MFMA family for 16 < d <= 64, single-workgroup and launch-per-phase kernels; sharded persistent mode)"; }
 
 extern "C" int tqgpu_device_count(void) {
     int n = 0;
@@ -1654,6 +1659,7 @@ int setup_persist(tqgpu_solver *s, int device) {
     const size_t bytes = (n_sch + n_dlt + n_ndt + n_parts + n_errs + 32 + n_bparts + n_sgt + n_rfl + n_verdict) * sizeof(unsigned long long);
     HIP_TRY(hipMalloc(&s->sync_slab, bytes));
     HIP_TRY(hipMemset(s->sync_slab, 0, bytes));
+    HIP_TRY(hipDeviceSynchronize());          /* (a device memset may return before it has happened, and the solver's non-blocking stream does not wait for the null stream) */
     s->sync_bytes = bytes;
     unsigned long long *w = static_cast<unsigned long long *>(s->sync_slab);
     s->psync.sch = w; s->psync.dlt = w + n_sch; s->psync.ndt = s->psync.dlt + n_dlt; s->psync.parts = s->psync.ndt + n_ndt;
@@ -2127,6 +2133,9 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
                 return cleanup_fail(fail(TQGPU_ENOMEM, "hipMalloc failed"));
         }
     }
+    /* the zeroing of the slabs above went out as device memsets, which may return before they have happened, on the null stream, which
+     * the solver's non-blocking stream does not wait for: everything is in place before the first solve can be enqueued */
+    if (hipDeviceSynchronize() != hipSuccess) return cleanup_fail(fail(TQGPU_ENODEVICE, "hipDeviceSynchronize failed"));
     *out = s;
     return TQGPU_OK;
 }
@@ -3173,7 +3182,8 @@ extern "C" int tqgpu_pshard_init(tqgpu_solver *s, int rank, int nranks) {
     HIP_TRY(hipMemcpy(s->d_peers, s->h_peers, sizeof(s->h_peers), hipMemcpyHostToDevice));
     s->psync.nap = nap_for_grid(s->ps_G);
     s->launch_no = 0;
-    HIP_TRY(hipMemset(s->sync_slab, 0, s->sync_bytes));
+    HIP_TRY(hipMemsetAsync(s->sync_slab, 0, s->sync_bytes, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
     return TQGPU_OK;
 }
 
@@ -3228,10 +3238,27 @@ extern "C" int tqgpu_pshard_begin(tqgpu_solver *s, const tqgpu_opts *o) {
     O.tol = o->stationarityTolerance; O.regTol = o->regTol; O.regValue = o->regValue;
     O.gamma = o->lineSearchGamma; O.beta = o->lineSearchBeta; O.stamps = 0;
     if (O.termCondition < 0 || O.termCondition > 2 || O.regType < 0 || O.regType > 2 || O.regValue < 0) return fail(TQGPU_EINVAL, "invalid option value");
+    if (((s->launch_no + 1) & 0xFFFFu) == 0)
+        return fail(TQGPU_EUNSUPPORTED, "65535 sharded solves since the launch numbers were last reset: call tqgpu_pshard_rewind on every rank, between two barriers of the caller's "
+                                        "(the 16-bit launch number tags the hand-over words; a single device wipes its slab when it wraps, ranks that write into each other's slabs cannot do that on their own)");
     memset(s->h_res, 0, sizeof(HostRes));
     int launches = 0;
     s->solve_no++;
     return launch_persist(s, O, launches, 1);
+}
+/* launch numbers back to zero and the slab wiped; peers stay connected.  EVERY rank, with no sharded solve in flight anywhere (a barrier
+ * of the caller's before and after): a peer's launch that is still running, or already running again, writes into the slab being wiped */
+extern "C" int tqgpu_pshard_rewind(tqgpu_solver *s) {
+    if (!s || !s->pshard) return fail(TQGPU_EINVAL, "tqgpu_pshard_rewind: not a sharded mirror");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    /* (hipMemset of device memory may return before the wipe has happened; it runs on the null stream, which the solver's non-blocking
+     * stream does not wait for: the wipe goes on the solver's stream and is waited for -- found by the 100 000-solve soak, where the
+     * first C3 solve after a rewind lost words to the wipe) */
+    HIP_TRY(hipMemsetAsync(s->sync_slab, 0, s->sync_bytes, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    s->launch_no = 0;
+    return TQGPU_OK;
 }
 extern "C" int tqgpu_pshard_end(tqgpu_solver *s, tqgpu_result *res) {
     if (!s || !res || !s->pshard) return fail(TQGPU_EINVAL, "tqgpu_pshard_end: not a sharded mirror");
@@ -3253,13 +3280,24 @@ extern "C" int tqgpu_pshard_end(tqgpu_solver *s, tqgpu_result *res) {
         unsigned tmo = 0;
         HIP_TRY(hipMemcpy(&tmo, s->psync.timeout, sizeof(unsigned), hipMemcpyDeviceToHost));
         if (tmo) {
-            HIP_TRY(hipMemset(s->psync.timeout, 0, sizeof(unsigned)));
+            HIP_TRY(hipMemsetAsync(s->psync.timeout, 0, sizeof(unsigned), s->stream));
+            HIP_TRY(hipStreamSynchronize(s->stream));
             return fail(TQGPU_ETIMEOUT, "sharded persistent solve: a bounded wait for another rank's workgroups timed out (are all ranks' launches in flight together?)");
         }
         return fail(TQGPU_ECOMM, "sharded persistent solve: no verdict from the top workgroup");
     }
     const Ctrl &c = *s->h_ctrl;
-    if (!c.done) return fail(TQGPU_EUNSUPPORTED, "sharded persistent solve: the launch ended without a verdict (tag space exhausted: more than 60000 passes)");
+    if (!c.done) {
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        unsigned tmo = 0;
+        HIP_TRY(hipMemcpy(&tmo, s->psync.timeout, sizeof(unsigned), hipMemcpyDeviceToHost));
+        if (tmo) {
+            HIP_TRY(hipMemsetAsync(s->psync.timeout, 0, sizeof(unsigned), s->stream));
+            HIP_TRY(hipStreamSynchronize(s->stream));
+            return fail(TQGPU_ETIMEOUT, "sharded persistent solve: a bounded wait for another rank's workgroups timed out");
+        }
+        return fail(TQGPU_EUNSUPPORTED, "sharded persistent solve: the launch ended without a verdict (tag space exhausted: more than 60000 passes)");
+    }
     res->status = c.status; res->iter = c.iter; res->ls_total = c.ls_total; res->ls_last = c.ls_last;
     res->n_launches = 1; res->device_time = s->rank == 0 ? 1e-8 * (double)(s->h_res->t_end - s->h_res->t_start) : 0.0; res->last_error_norm = c.err; res->last_fval = c.fval;
     s->last_iter = c.iter;
@@ -3336,6 +3374,7 @@ extern "C" int tqgpu_pshard_solve_local(tqgpu_solver **R, int n, const tqgpu_opt
     for (int r = 0; r < n; r++) if (!R[r] || !R[r]->pshard || R[r]->nranks != n || R[r]->rank != r) return fail(TQGPU_EINVAL, "tqgpu_pshard_solve_local: mirror r must be tqgpu_pshard_init(r, n)");
     for (int r = 0; r < n; r++) for (int q = 0; q < n; q++) { int rc = tqgpu_pshard_connect_local(R[r], q, R[q]); if (rc) return rc; }
     for (int r = 0; r < n; r++) HIP_TRY(hipStreamSynchronize(R[r]->stream));          /* uploads done: the launches go out back to back */
+    if (R[0]->launch_no >= 0x8000u) for (int r = 0; r < n; r++) { int rc = tqgpu_pshard_rewind(R[r]); if (rc) return rc; }      /* (all ranks idle here) */
     for (int r = 0; r < n; r++) { int rc = tqgpu_pshard_begin(R[r], o); if (rc) return rc; }
     int first = TQGPU_OK;
     std::string msg;
