@@ -1,4 +1,4 @@
-"""Worker of tests/test_gpu_pshard.py::test_two_processes_share_one_tree_through_ipc_slabs: rank `r` of `n` PROCESSES on one GPU.
+"""Worker of tests/test_gpu_pshard.py::test_processes_share_one_tree_through_ipc_slabs: rank `r` of `n` PROCESSES on one GPU.
 Each process creates a mirror of the whole tree, becomes a rank of the sharded persistent solve, exchanges the IPC handles of
 the hand-over slabs and -- afterwards -- its share of the solution through torch.distributed (gloo: host-staged; RCCL refuses
 two ranks on one device), and checks the collected solution against an unsharded solve of its own."""

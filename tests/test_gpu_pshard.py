@@ -113,16 +113,17 @@ def test_pshard_rejects_what_it_cannot_shard(gpu):
     g.close()
 
 
-def test_two_processes_share_one_tree_through_ipc_slabs(gpu, tmp_path):
-    """The product's sharded solve across REAL processes: two processes on this GPU, each a rank; slabs mapped into each other by
+@pytest.mark.parametrize("nproc,levels", [(2, 9), (4, 11)], ids=["2_processes_c2", "4_processes_c3"])
+def test_processes_share_one_tree_through_ipc_slabs(gpu, tmp_path, nproc, levels):
+    """The product's sharded solve across REAL processes: 2 / 4 processes on this GPU, each a rank; slabs mapped into each other by
     hipIpcGetMemHandle / hipIpcOpenMemHandle; handles and, afterwards, the solution shares travel through gloo."""
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     env = dict(os.environ)
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
-    procs = [subprocess.Popen([sys.executable, str(ROOT / "tests" / "pshard_worker.py"), str(r), "2", str(port), "9"], cwd=tmp_path, env=env,
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, str(ROOT / "tests" / "pshard_worker.py"), str(r), str(nproc), str(port), str(levels)], cwd=tmp_path, env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(nproc)]
     outs = []
     for pr in procs:
         try:

@@ -3145,14 +3145,6 @@ extern "C" int tqgpu_shard_gather_solution(tqgpu_solver *s) {
  * dual-function partials upwards, the step of the boundary blocks, the line-search commands and the halt word downwards; no
  * collective, no host in the loop.  RCCL (or any transport the caller has: tqgpu_pshard_pack / _unpack) is only used to collect
  * the solution afterwards.  Every rank must call tqgpu_pshard_solve the same number of times (the launch number tags the words). */
-namespace {
-int pshard_part_top(const tqgpu_solver *s, int n) {
-    int top = -1;
-    for (int i = 0; i < s->n_tiers - 1; i++) if (s->tier_grid[i] % n == 0 && s->tier_grid[i] >= n) top = i;
-    return top;
-}
-}  // namespace
-
 extern "C" int tqgpu_pshard_init(tqgpu_solver *s, int rank, int nranks) {
     if (!s || nranks < 1 || nranks > 8 || rank < 0 || rank >= nranks) return fail(TQGPU_EINVAL, "tqgpu_pshard_init: bad arguments (1 .. 8 ranks)");
     HIP_TRY(hipSetDevice(s->device));
