@@ -444,9 +444,11 @@ def main():
                 g.device_times(1)                                            # synchronises
                 tb = time.perf_counter() - tb0
                 sweep.append({"trees_per_gpu": nb, "value": nit / tb, "ms_per_step": 1e3 * tb / ksteps})
+                fit = min(64, cap["capacity"] // cap["workgroups_per_tree"])      # the largest batch that is co-resident closes the sweep
                 nxt = nb + 1 if nb < 4 else nb + max(1, nb // 3)
-                if nxt * cap["workgroups_per_tree"] > cap["capacity"] or nxt > 40:
+                if nb >= fit:
                     break
+                nxt = min(nxt, fit)
                 nb = nxt
             best = max(sweep, key=lambda e: e["value"])
             out["batched"] = {"trees_per_gpu": best["trees_per_gpu"], "value": best["value"], "unit": "newton_iter/s", "ms_per_step": best["ms_per_step"],

@@ -465,9 +465,23 @@ def test_batch_of_one_shape_is_one_launch_and_survives_changes(gpu, orc):
     p5, f5, _ = built[5]
     ms[2].upload(f5, p5.lambda0)
     check(ms, singles[:2] + [singles[5]] + singles[3:])
-    # 30 trees of 10 workgroups: more than one workgroup per CU on some CUs
-    many = [gpu.TqGpu(*built[i % 6][2]).upload(built[i % 6][1], built[i % 6][0].lambda0) for i in range(30)]
-    check(many, [singles[i % 6] for i in range(30)])
+    # batches back to back with nothing in between (no synchronisation with the launch's end: the next launch is ordered behind it by
+    # the lead's stream), then another lead (the members wait for the old lead's stream first), then a member on its own
+    for _ in range(3):
+        gpu.solve_batch(ms)
+    check(ms[::-1], (singles[:2] + [singles[5]] + singles[3:])[::-1])
+    gpu.solve_batch(ms)
+    r3 = ms[3].solve()
+    assert (r3["status"], r3["iter"], r3["ls_total"]) == (singles[3][0]["status"], singles[3][0]["iter"], singles[3][0]["ls_total"])
+    assert np.array_equal(ms[3].solution()["x"], singles[3][1]["x"])
+    # as many trees as are co-resident (every CU but one carries two workgroups): the capacity figure is exact, no margin
+    geo = ms[0].geometry()
+    n_many = min(60, geo["capacity"] // geo["workgroups"])
+    assert n_many >= 30
+    many = [gpu.TqGpu(*built[i % 6][2]).upload(built[i % 6][1], built[i % 6][0].lambda0) for i in range(n_many)]
+    check(many, [singles[i % 6] for i in range(n_many)])
+    check(many, [singles[i % 6] for i in range(n_many)])
+    assert all(gpu.lib().tqgpu_timeouts(m.h) == 0 for m in many)
     for m in ms + many:
         m.close()
 

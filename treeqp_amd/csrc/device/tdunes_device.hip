@@ -1132,6 +1132,8 @@ struct tqgpu_solver {
     bool stream_pending = false;                                          /* something was enqueued on `stream` without a synchronisation after it (asynchronous uploads, constant packing): a batch launch on ANOTHER stream waits for it first */
     hipEvent_t batch_ev = nullptr;
     hipStream_t batch_stream = nullptr;                                   /* member of a batch launch in flight: the stream that launch is on (the lead's) */
+    hipStream_t settle_stream = nullptr;                                  /* member of a batch launch whose verdict is in but whose last workgroups may still write back:
+                                                                           * the lead's stream, to be waited for before this mirror is touched through its own stream (settle) */
     size_t sync_words_bytes = 0, lds_persist = 0;
     /* ONE tree over several devices INSIDE the persistent launch (tqgpu_pshard_*): this rank's share of the workgroups */
     bool pshard = false;
@@ -1153,6 +1155,18 @@ struct tqgpu_solver {
 };
 
 extern "C" const char *tqgpu_last_error(void) { return g_err.c_str(); }
+/* A batch launch runs on its lead's stream; the other members' own streams are not ordered behind it.  Its end is waited for lazily:
+ * a loop of batch solves on the same lead stays stream-ordered by itself and pays no synchronisation per step (10 - 15 us of a
+ * 150 us step), anything else that touches a member comes through here first. */
+static int settle(tqgpu_solver *s) {
+    if (s && s->settle_stream) {
+        hipStream_t t = s->settle_stream;
+        s->settle_stream = nullptr;
+        if (t != s->stream) HIP_TRY(hipStreamSynchronize(t));
+    }
+    return TQGPU_OK;
+}
+#define SETTLE(s) do { int rc_ = settle(const_cast<tqgpu_solver *>(s)); if (rc_ != TQGPU_OK) return rc_; } while (0)
 extern "C" const char *tqgpu_version(void) { return "treeqp_amd tdunes device path r3 (gfx950: persistent single launch, three-launch MFMA family for 16 < d <= 64, single-workgroup and launch-per-phase kernels; sharded persistent mode)"; }
 
 extern "C" int tqgpu_device_count(void) {
@@ -1644,7 +1658,12 @@ int setup_persist(tqgpu_solver *s, int device) {
     per_cu = std::min(per_cu, per_cu_r);
     /* one workgroup per CU needs no margin (the figure is exact when registers allow a single 4-wave workgroup);
      * with more per CU keep half a CU-load of workgroups in hand */
-    const int capacity = per_cu <= 1 ? prop.multiProcessorCount * per_cu : prop.multiProcessorCount * per_cu - prop.multiProcessorCount / 2;
+    /* (rounds 1 - 2 kept half a CU-load in hand; the admission rule of the MI355X guide -- min(API answer, 8, 800 / (sgpr rounded up to
+     * 16 + 16)) per CU -- is what per_cu_r holds, the grid is admitted CU by CU, and a launch that is not resident after all ends in the
+     * bounded waits' timeout and the launch-per-tier redo, not in a hang: no margin.  C2 batched: 5 trees 99 k it/s -> 7 trees 133 k.) */
+    int margin = 0;
+    if (const char *e = getenv("TREEQP_AMD_CAPACITY_MARGIN")) margin = atoi(e);      /* experiment */
+    const int capacity = per_cu <= 1 ? prop.multiProcessorCount * per_cu : prop.multiProcessorCount * per_cu - margin;
     if (getenv("TREEQP_AMD_VERBOSE")) fprintf(stderr, "[treeqp_amd] persistent path: %d workgroups, %d per CU possible, capacity %d\n", G.G, per_cu, capacity);
     s->co_capacity = std::max(1, capacity);
     s->n_cu = prop.multiProcessorCount;
@@ -2141,6 +2160,7 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
 }
 
 extern "C" void tqgpu_destroy(tqgpu_solver *s) {
+    (void)settle(s);
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
@@ -2203,6 +2223,7 @@ extern "C" int tqgpu_uses_fused_path(const tqgpu_solver *s) {
  * {shader clock, 100 MHz wall clock}); only filled when TREEQP_AMD_STAMPS is set */
 /* diagnostic builds (-DTQ_WIDE_STAMPS): per-block time stamps of k_hf_w, four 64-bit words per block kept in the (otherwise unused) CholW array */
 extern "C" int tqgpu_debug_block_stamps(tqgpu_solver *s, unsigned long long *out, int cap_blocks) {
+    SETTLE(s);
     if (!s || !out) return fail(TQGPU_EINVAL, "bad arguments");
     std::vector<double> tmp((size_t)std::max(s->sum_W, 1));
     HIP_TRY(hipMemcpy(tmp.data(), getenv("TQ_STAMPS_OF_SGP") ? s->D.W : s->D.CholW, sizeof(double) * (size_t)s->sum_W, hipMemcpyDeviceToHost));
@@ -2212,6 +2233,7 @@ extern "C" int tqgpu_debug_block_stamps(tqgpu_solver *s, unsigned long long *out
 }
 
 extern "C" int tqgpu_get_stamps(tqgpu_solver *s, unsigned long long *out, int cap) {
+    SETTLE(s);
     if (!s || !out) return fail(TQGPU_EINVAL, "bad arguments");
     const int n = std::min(cap, 8 * 32 * 2 + 1024);
     HIP_TRY(hipMemcpy(out, s->D.stamps, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToHost));
@@ -2235,6 +2257,7 @@ extern "C" int tqgpu_dims(const tqgpu_solver *s, int *sum_nx, int *sum_nu, int *
     } while (0)
 
 extern "C" int tqgpu_set_dynamics(tqgpu_solver *s, const double *A, const double *B, const double *b) {
+    SETTLE(s);
     if (!s) return fail(TQGPU_EINVAL, "null solver");
     HIP_TRY(hipSetDevice(s->device));
     s->in_valid = false;
@@ -2246,6 +2269,7 @@ extern "C" int tqgpu_set_dynamics(tqgpu_solver *s, const double *A, const double
 }
 
 extern "C" int tqgpu_set_objective_diag(tqgpu_solver *s, const double *Qd, const double *Rd, const double *q, const double *r) {
+    SETTLE(s);
     if (!s) return fail(TQGPU_EINVAL, "null solver");
     HIP_TRY(hipSetDevice(s->device));
     s->in_valid = false;
@@ -2262,6 +2286,7 @@ extern "C" int tqgpu_set_objective_diag(tqgpu_solver *s, const double *Qd, const
  * tree_qp_in_set_ltv_objective_colmajor (tree_qp_common.c): per node Q (nx x nx), R (nu x nu), S (nu x nx),
  * all column major, then q, r.  Selects the generic device path; tqgpu_set_objective_diag selects clipping again. */
 extern "C" int tqgpu_set_objective_dense(tqgpu_solver *s, const double *Q, const double *R, const double *S, const double *q, const double *r) {
+    SETTLE(s);
     return tqgpu_set_objective_mixed(s, nullptr, Q, R, S, q, r);
 }
 
@@ -2269,6 +2294,7 @@ extern "C" int tqgpu_set_objective_dense(tqgpu_solver *s, const double *Q, const
  * kind[k] = 0: clipping (the diagonals of Q_k, R_k are its weights; their off-diagonals and S_k must be zero), 1: dense
  * unconstrained.  kind == NULL: every node dense. */
 extern "C" int tqgpu_set_objective_mixed(tqgpu_solver *s, const int *kind, const double *Q, const double *R, const double *S, const double *q, const double *r) {
+    SETTLE(s);
     if (!s || !Q || !q) return fail(TQGPU_EINVAL, "tqgpu_set_objective_mixed: bad arguments");
     if (s->sharded) return fail(TQGPU_EINVAL, "the dense stage solver is not available in sharded mode");
     HIP_TRY(hipSetDevice(s->device));
@@ -2319,6 +2345,7 @@ extern "C" int tqgpu_set_objective_mixed(tqgpu_solver *s, const int *kind, const
 }
 
 extern "C" int tqgpu_set_bounds(tqgpu_solver *s, const double *xmin, const double *xmax, const double *umin, const double *umax) {
+    SETTLE(s);
     if (!s) return fail(TQGPU_EINVAL, "null solver");
     HIP_TRY(hipSetDevice(s->device));
     s->in_valid = false;
@@ -2329,6 +2356,7 @@ extern "C" int tqgpu_set_bounds(tqgpu_solver *s, const double *xmin, const doubl
 }
 
 extern "C" int tqgpu_set_lambda(tqgpu_solver *s, const double *lambda) {
+    SETTLE(s);
     if (!s) return fail(TQGPU_EINVAL, "null solver");
     HIP_TRY(hipSetDevice(s->device));
     /* kept in a resident buffer: every tqgpu_solve starts from it (device-to-device copy) */
@@ -2346,6 +2374,7 @@ extern "C" int tqgpu_set_lambda(tqgpu_solver *s, const double *lambda) {
 extern "C" int tqgpu_set_problem(tqgpu_solver *s, const double *A, const double *B, const double *b,
                                  const double *Qd, const double *Rd, const double *q, const double *r,
                                  const double *xmin, const double *xmax, const double *umin, const double *umax, const double *lambda) {
+    SETTLE(s);
     if (!s) return fail(TQGPU_EINVAL, "null solver");
     HIP_TRY(hipSetDevice(s->device));
     if (s->dense) { s->dense = false; s->D.dense = 0; s->use_fast = s->use_fast_orig; s->in_valid = false; s->need_init = true; s->need_pack = true; }
@@ -2695,6 +2724,7 @@ static int solve_after_timeout(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_resul
 }
 
 extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *res) {
+    SETTLE(s);
     if (!s || !o || !res) return fail(TQGPU_EINVAL, "tqgpu_solve: bad arguments");
     if (s->persist_backoff > 0 && --s->persist_backoff == 0) s->use_persist = s->use_persist_orig;
     SolveCtx cx;
@@ -2710,6 +2740,7 @@ extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *r
  * the loop is in C, so what is timed is the solver and not the caller's interpreter.  res = the last solve's result; sums over
  * the n solves in iter_sum / ls_sum / launch_sum.  Stops at the first solve that does not end with status 0 or 1. */
 extern "C" int tqgpu_solve_n(tqgpu_solver *s, const tqgpu_opts *o, int n, tqgpu_result *res, long *iter_sum, long *ls_sum, long *launch_sum) {
+    SETTLE(s);
     if (!s || !o || !res || n < 1) return fail(TQGPU_EINVAL, "tqgpu_solve_n: bad arguments");
     long it = 0, ls = 0, la = 0;
     /* (waiting for the stream to drain, or a few microseconds, before the next launch measured slower than launching at once) */
@@ -2860,12 +2891,19 @@ extern "C" int tqgpu_solve_batch(tqgpu_solver **solvers, int n, const tqgpu_opts
             }
             if (pm.size() < 2 || getenv("TREEQP_AMD_BATCH_LAUNCHES")) pm.clear();      /* (=1: one launch per tree, the round-1 protocol) */
         }
+        for (int k = begun_from; k < begun_to; k++) {
+            /* a member of the previous batch launch that goes out again on the same lead's stream is ordered behind it by that stream */
+            const bool same_lead = !pm.empty() && solvers[k]->settle_stream == solvers[pm[0]]->stream && std::find(pm.begin(), pm.end(), k) != pm.end();
+            if (same_lead) { if (k == pm[0]) solvers[k]->settle_stream = nullptr; }
+            else SETTLE(solvers[k]);
+        }
         unsigned pseq = 0;
         if (!pm.empty()) {
             unsigned mx = 0;
             for (int k : pm) mx = std::max(mx, solvers[k]->launch_no);
             unsigned nn = mx + 1;
             if (nn > 0xFFFFu) {          /* the 16-bit launch number wraps: see launch_persist */
+                HIP_TRY(hipStreamSynchronize(solvers[pm[0]]->stream));      /* (the previous batch launch's last workgroups are done with the slabs) */
                 for (int k : pm) {
                     HIP_TRY(hipMemsetAsync(solvers[k]->sync_slab, 0, solvers[k]->sync_bytes, solvers[k]->stream));
                     solvers[k]->stream_pending = true;          /* the batch launch (on the lead's stream) waits for the wipe */
@@ -2948,7 +2986,10 @@ extern "C" int tqgpu_solve_batch(tqgpu_solver **solvers, int n, const tqgpu_opts
         for (int k = begun_from; k < begun_to; k++) solvers[k]->batch_stream = nullptr;
         /* the members' later work (solution export, the next solve) runs on their own streams: it has to find the batch launch
          * complete -- every verdict is in, so this waits for the write-back of the last workgroups only, once per batch */
-        if (!pm.empty() && ok_to == begun_to) HIP_TRY(hipStreamSynchronize(solvers[pm[0]]->stream));
+        if (!pm.empty() && ok_to == begun_to) {
+            if (first_err != TQGPU_OK || getenv("TREEQP_AMD_BATCH_SYNC")) HIP_TRY(hipStreamSynchronize(solvers[pm[0]]->stream));
+            else for (size_t m = 1; m < pm.size(); m++) solvers[pm[m]]->settle_stream = solvers[pm[0]]->stream;      /* see settle() */
+        }
         if (first_err != TQGPU_OK) break;
         i = j;
     }
@@ -3099,6 +3140,7 @@ extern "C" int tqgpu_shard_plan(int md, int nx, int Nh, int nranks, int rank, in
 }
 
 extern "C" int tqgpu_shard_init(tqgpu_solver *s, int rank, int nranks, const void *id128) {
+    SETTLE(s);
     if (!s || nranks < 1 || rank < 0 || rank >= nranks) return fail(TQGPU_EINVAL, "tqgpu_shard_init: bad arguments");
     HIP_TRY(hipSetDevice(s->device));
     if (s->comm) { (void)g_rccl.CommDestroy(s->comm); s->comm = nullptr; }      /* a second call replaces the communicator, it does not leak it */
@@ -3121,6 +3163,7 @@ extern "C" int tqgpu_shard_init(tqgpu_solver *s, int rank, int nranks, const voi
 /* after a sharded solve every rank holds valid x,u,lambda,... only for its own and the replicated
  * nodes: gather the partitioned ranges so that tqgpu_get_solution returns the full solution */
 extern "C" int tqgpu_shard_gather_solution(tqgpu_solver *s) {
+    SETTLE(s);
     if (!s) return fail(TQGPU_EINVAL, "null solver");
     if (!s->sharded) return TQGPU_OK;
     if (!s->comm) return fail(TQGPU_ECOMM, "no communicator (virtual ranks gather through tqgpu_solve_virtual_ranks)");
@@ -3146,6 +3189,7 @@ extern "C" int tqgpu_shard_gather_solution(tqgpu_solver *s) {
  * collective, no host in the loop.  RCCL (or any transport the caller has: tqgpu_pshard_pack / _unpack) is only used to collect
  * the solution afterwards.  Every rank must call tqgpu_pshard_solve the same number of times (the launch number tags the words). */
 extern "C" int tqgpu_pshard_init(tqgpu_solver *s, int rank, int nranks) {
+    SETTLE(s);
     if (!s || nranks < 1 || nranks > 8 || rank < 0 || rank >= nranks) return fail(TQGPU_EINVAL, "tqgpu_pshard_init: bad arguments (1 .. 8 ranks)");
     HIP_TRY(hipSetDevice(s->device));
     if (!s->persist_ok || s->mstage || s->fast < 0 || !s->use_fast || !s->use_persist) return fail(TQGPU_EUNSUPPORTED, "sharding inside the persistent launch needs the persistent path of a uniform complete tree");
@@ -3181,6 +3225,7 @@ extern "C" int tqgpu_pshard_init(tqgpu_solver *s, int rank, int nranks) {
 
 /* peer `r` lives in this process (several mirrors on one device, or on several devices with peer access enabled by the caller) */
 extern "C" int tqgpu_pshard_connect_local(tqgpu_solver *s, int r, tqgpu_solver *peer) {
+    SETTLE(s);
     if (!s || !peer || !s->pshard || r < 0 || r >= s->nranks || !peer->sync_slab || peer->sync_bytes != s->sync_bytes) return fail(TQGPU_EINVAL, "tqgpu_pshard_connect_local: bad arguments");
     if (peer->device != s->device) {
         HIP_TRY(hipSetDevice(s->device));
@@ -3221,6 +3266,7 @@ extern "C" int tqgpu_pshard_ipc_connect(tqgpu_solver *s, int r, const void *hand
 /* one solve in two halves (so that one process can drive several ranks): _begin enqueues this rank's launch, _end waits for the
  * verdict.  All ranks' launches have to be in flight together: they wait for each other (bounded: 0.5 s, then TQGPU_ETIMEOUT). */
 extern "C" int tqgpu_pshard_begin(tqgpu_solver *s, const tqgpu_opts *o) {
+    SETTLE(s);
     if (!s || !o || !s->pshard) return fail(TQGPU_EINVAL, "tqgpu_pshard_begin: not a sharded mirror");
     HIP_TRY(hipSetDevice(s->device));
     if (o->profile || o->maxIter <= 0 || o->checkLastActiveSet == 2) return fail(TQGPU_EUNSUPPORTED, "sharded persistent solve: default solve options only (no profiling, no factor keeping)");
@@ -3241,6 +3287,7 @@ extern "C" int tqgpu_pshard_begin(tqgpu_solver *s, const tqgpu_opts *o) {
 /* launch numbers back to zero and the slab wiped; peers stay connected.  EVERY rank, with no sharded solve in flight anywhere (a barrier
  * of the caller's before and after): a peer's launch that is still running, or already running again, writes into the slab being wiped */
 extern "C" int tqgpu_pshard_rewind(tqgpu_solver *s) {
+    SETTLE(s);
     if (!s || !s->pshard) return fail(TQGPU_EINVAL, "tqgpu_pshard_rewind: not a sharded mirror");
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipStreamSynchronize(s->stream));
@@ -3253,6 +3300,7 @@ extern "C" int tqgpu_pshard_rewind(tqgpu_solver *s) {
     return TQGPU_OK;
 }
 extern "C" int tqgpu_pshard_end(tqgpu_solver *s, tqgpu_result *res) {
+    SETTLE(s);
     if (!s || !res || !s->pshard) return fail(TQGPU_EINVAL, "tqgpu_pshard_end: not a sharded mirror");
     HIP_TRY(hipSetDevice(s->device));
     /* the verdict reaches every rank's host through its pinned result block: written by the top workgroup (rank 0) or passed on from the
@@ -3337,6 +3385,7 @@ extern "C" long tqgpu_pshard_pack_size(tqgpu_solver *s) {
     return (long)n;
 }
 extern "C" int tqgpu_pshard_pack(tqgpu_solver *s, double *out, long cap) {
+    SETTLE(s);
     if (!s || !out || !s->pshard) return fail(TQGPU_EINVAL, "tqgpu_pshard_pack: bad arguments");
     HIP_TRY(hipSetDevice(s->device));
     size_t o = 0;
@@ -3348,6 +3397,7 @@ extern "C" int tqgpu_pshard_pack(tqgpu_solver *s, double *out, long cap) {
     return TQGPU_OK;
 }
 extern "C" int tqgpu_pshard_unpack(tqgpu_solver *s, int src_rank, const double *in, long n_in) {
+    SETTLE(s);
     if (!s || !in || !s->pshard || src_rank < 0 || src_rank >= s->nranks) return fail(TQGPU_EINVAL, "tqgpu_pshard_unpack: bad arguments");
     HIP_TRY(hipSetDevice(s->device));
     size_t o = 0;
@@ -3362,6 +3412,7 @@ extern "C" int tqgpu_pshard_unpack(tqgpu_solver *s, int src_rank, const double *
 /* n mirrors of the SAME problem in this process (one device: a rehearsal with real concurrency -- n launches on n streams that wait
  * for each other inside the kernels -- or n devices with peer access): connect, solve, collect the solution into every mirror */
 extern "C" int tqgpu_pshard_solve_local(tqgpu_solver **R, int n, const tqgpu_opts *o, tqgpu_result *res) {
+    for (int r_ = 0; R && r_ < n; r_++) SETTLE(R[r_]);
     if (!R || n < 1 || n > 8 || !o || !res) return fail(TQGPU_EINVAL, "tqgpu_pshard_solve_local: bad arguments");
     for (int r = 0; r < n; r++) if (!R[r] || !R[r]->pshard || R[r]->nranks != n || R[r]->rank != r) return fail(TQGPU_EINVAL, "tqgpu_pshard_solve_local: mirror r must be tqgpu_pshard_init(r, n)");
     for (int r = 0; r < n; r++) for (int q = 0; q < n; q++) { int rc = tqgpu_pshard_connect_local(R[r], q, R[q]); if (rc) return rc; }
@@ -3386,6 +3437,7 @@ extern "C" int tqgpu_pshard_solve_local(tqgpu_solver **R, int n, const tqgpu_opt
  * decision logic without a multi-GPU node.  Every mirror must have been shard-initialised with
  * (rank = its index, nranks = n, id128 = NULL).  The full solution is gathered into every mirror. */
 extern "C" int tqgpu_solve_virtual_ranks(tqgpu_solver **R, int n, const tqgpu_opts *o, tqgpu_result *res) {
+    for (int r_ = 0; R && r_ < n; r_++) SETTLE(R[r_]);
     if (!R || n < 2 || !o || !res) return fail(TQGPU_EINVAL, "tqgpu_solve_virtual_ranks: bad arguments");
     for (int r = 0; r < n; r++) if (!R[r] || R[r]->nranks != n || R[r]->rank != r || R[r]->comm) return fail(TQGPU_EINVAL, "mirror is not virtual rank r of n");
     HIP_TRY(hipSetDevice(R[0]->device));
@@ -3453,6 +3505,7 @@ extern "C" int tqgpu_solve_virtual_ranks(tqgpu_solver **R, int n, const tqgpu_op
 }
 
 extern "C" int tqgpu_get_solution(tqgpu_solver *s, double *x, double *u, double *lam, double *mu_x, double *mu_u, double *dlam) {
+    SETTLE(s);
     if (!s) return fail(TQGPU_EINVAL, "null solver");
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t st = s->stream;
@@ -3475,6 +3528,7 @@ extern "C" int tqgpu_get_solution(tqgpu_solver *s, double *x, double *u, double 
 }
 
 extern "C" int tqgpu_get_iteration_log(tqgpu_solver *s, int *ls_iters, double *iter_times, int cap) {
+    SETTLE(s);
     if (!s) return fail(TQGPU_EINVAL, "null solver");
     const int n = std::min(std::min(cap, s->last_iter), s->ls_log_cap);
     if (n > 0 && ls_iters) {
@@ -3496,6 +3550,7 @@ extern "C" int tqgpu_get_iteration_log(tqgpu_solver *s, int *ls_iters, double *i
  * read-back and are NOT in this figure).  stage_qps[0] = the first sweep of the solve; phase S of every later iteration IS the accepted
  * trial sweep of the line search before it, so stage_qps[i > 0] = 0.  NaN where nothing was recorded (opts.profile < 3). */
 extern "C" int tqgpu_get_phase_log(tqgpu_solver *s, double *stage_qps, double *build_dual, double *newton_direction, double *line_search, int cap) {
+    SETTLE(s);
     if (!s) return fail(TQGPU_EINVAL, "null solver");
     const int n = std::min(cap, s->last_iter);
     for (int i = 0; i < n; i++) {
@@ -3511,6 +3566,7 @@ extern "C" int tqgpu_get_phase_log(tqgpu_solver *s, double *stage_qps, double *b
 /* Device times (HIP events on the solver's stream, first to last enqueued operation of a solve) of the
  * last `n` solves, oldest first; synchronises the stream.  Returns the number written. */
 extern "C" int tqgpu_get_device_times(tqgpu_solver *s, double *out, int n) {
+    SETTLE(s);
     if (!s || !out || n < 0) return -1;
     if (hipSetDevice(s->device) != hipSuccess || hipStreamSynchronize(s->stream) != hipSuccess) return -1;
     const long have = std::min<long>(std::min<long>(n, s->solve_no), EV_RING);
