@@ -324,6 +324,55 @@ def test_three_launch_family_c4_launch_count(gpu, orc):
     g.close()
 
 
+def test_three_launch_family_verdict_through_the_result_block(gpu, orc, monkeypatch):
+    """The last launch of what the host enqueues before it looks posts the control block to pinned host memory (w3_mirror) and the
+    host polls for that launch's tag -- no device-to-host copy, no stream synchronisation per read, no HIP event pair per solve.
+    Same verdicts, counts and solutions (bit for bit) as with the copy (TREEQP_AMD_NO_W3_MIRROR=1): several iterations with predicted
+    and unpredicted further trials (pruned trees, solved repeatedly so that the trial counts of the previous solve are used), a
+    solve that is over after its first sweep (started from its own solution: the sweep is not a launch that posts, a one-thread
+    launch does), the kernel's own clock as device time, and the event pair when it is asked for."""
+    for f in (P.pruned_chain_qp(), P.pruned_chain_qp(Nh=6, seed=5), P.random_shape_qp(5, 2, 6, (3, 9), (2, 5))):
+        ref = orc.solve(f.as_dict(), orc.default_opts(**f.opts), lambda0=f.lambda0)
+        out = {}
+        for mirror in (True, False):
+            if mirror:
+                monkeypatch.delenv("TREEQP_AMD_NO_W3_MIRROR", raising=False)
+            else:
+                monkeypatch.setenv("TREEQP_AMD_NO_W3_MIRROR", "1")
+            monkeypatch.setenv("TREEQP_AMD_PATH", "generic")
+            g = gpu.TqGpu(f.nk, f.nx, f.nu).upload(f.as_dict(), f.lambda0)
+            monkeypatch.delenv("TREEQP_AMD_PATH")
+            assert g.path == 0
+            g.event_timing(False)
+            rs = [g.solve(**f.opts) for _ in range(3)]                             # the second and third with the first one's trial counts
+            for r in rs:
+                assert (r["status"], r["iter"], r["ls_total"]) == (ref["status"], ref["iter"], ref["ls_total"]), (mirror, r)
+                assert 0.0 < r["device_time"] < 0.05
+            sol = g.solution()
+            assert_solution_close(sol, ref, TOL)
+            g.event_timing(True)
+            r = g.solve(**f.opts)
+            assert (r["status"], r["iter"], r["ls_total"]) == (ref["status"], ref["iter"], ref["ls_total"])
+            assert np.isfinite(g.device_times(1)[0])
+            # from its own solution: optimal at the first test, no iteration
+            g.event_timing(False)
+            g.upload(f.as_dict(), sol["lam"])
+            r0 = g.solve(**f.opts)
+            assert (r0["status"], r0["iter"]) == (0, 0), r0
+            sol0 = g.solution()
+            # one iteration allowed, after a solve that took several: the first chunk is the termination test alone, which was the tail
+            # of the first sweep -- nothing is launched before the host looks (the one-thread post)
+            g.upload(f.as_dict(), f.lambda0)
+            g.solve(**f.opts)
+            o1 = dict(f.opts); o1["maxIter"] = 1
+            r1 = g.solve(**o1)
+            assert (r1["status"], r1["iter"]) == (1, 1), r1                       # TREEQP_MAXIMUM_ITERATIONS_REACHED
+            out[mirror] = (sol, sol0, g.solution())
+            g.close()
+        for k in ("x", "u", "lam", "mu_x", "mu_u"):
+            assert all(np.array_equal(out[True][i][k], out[False][i][k]) for i in range(3))
+
+
 # --- full BASELINE sizes: size-independent properties ------------------------------------------
 
 @pytest.mark.parametrize("make", [lambda: P.linear_chain(2, 11, 11)], ids=["c3_chain_4095"])

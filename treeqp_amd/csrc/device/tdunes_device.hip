@@ -1052,6 +1052,11 @@ struct tqgpu_solver {
     size_t lds_hf_w = 0, lds_sgp = 0;
     int sgp_accs = 0;
     bool w3_sgp = false;                /* k_sgp (a workgroup per parent) instead of k_sg (a wave per node) */
+    bool w3_mirror = false;             /* this solve: the launches of k_sg / k_sgp post the control block to h_res (w3_mirror in tdunes_wide3.hpp) */
+    bool w3_tail_sg = false;            /* the last launch enqueued is one of them: its tag (w3_wait) is what the host polls for */
+    unsigned w3_wait = 0;
+    bool w3_post_next = false;          /* the next launch of k_sg / k_sgp is the last of what the host enqueues before it reads the verdict: it posts */
+    bool w3_seen = false;               /* the last read of the control block came through the result block */
     std::vector<int> ls_pred;           /* trials per iteration of the previous solve: that many trial launches are enqueued behind an iteration's forward sweep (a trial beyond the accepted one is a no-op; a read-back per extra trial is 20 us) */
     bool dense = false, need_dense_init = false;   /* dense unconstrained stage solver selected (generic path only) */
     double *d_Hd = nullptr;      /* writable alias of Data.Hd */
@@ -1556,15 +1561,22 @@ static Fuse next_fuse(tqgpu_solver *s) {
 static Fuse no_fuse() { Fuse F; F.red = nullptr; F.cnt = nullptr; F.tag = 0; F.on = 0; return F; }
 static W3 next_w3(tqgpu_solver *s) {
     W3 w; w.xu = s->w3_xu; w.red = s->w3_red; w.cnt = s->w3_cnt; w.sum_nx = s->sum_nx; w.lds_wave = (int)((s->lds_stage + 7) / 8);
+    w.hm = nullptr;
+    s->w3_tail_sg = false;
     s->w3_epoch++;
     if (s->w3_epoch == 0) s->w3_epoch = 1;
     w.tag = s->w3_epoch;
     return w;
 }
 static void launch_sg(tqgpu_solver *s, const Opts &O, int mode, int h, int t, bool fresh = false) {
-    if (s->w3_sgp) { hipLaunchKernelGGL(k_sgp, dim3(s->T.Np), dim3(WT), s->lds_sgp, s->stream, s->T, s->D, O, next_w3(s), mode, h, t, s->sgp_accs, fresh ? s->d_lam_init : nullptr); return; }
+    W3 w = next_w3(s);
+    /* (a post is ~14 system-scope stores to host memory and the wait for their acknowledgements, on the launch's critical path: only
+     * where the host is going to look) */
+    if (s->w3_mirror && s->w3_post_next) { w.hm = s->h_res; s->w3_wait = w.tag; s->w3_tail_sg = true; }
+    s->w3_post_next = false;
+    if (s->w3_sgp) { hipLaunchKernelGGL(k_sgp, dim3(s->T.Np), dim3(WT), s->lds_sgp, s->stream, s->T, s->D, O, w, mode, h, t, s->sgp_accs, fresh ? s->d_lam_init : nullptr); return; }
     const int grid = (s->T.Nn + SG_WAVES - 1) / SG_WAVES;
-    hipLaunchKernelGGL(k_sg, dim3(grid), dim3(SG_WAVES * WAVE), SG_WAVES * ((s->lds_stage + 7) / 8) * 8, s->stream, s->T, s->D, O, next_w3(s), mode, h, t);
+    hipLaunchKernelGGL(k_sg, dim3(grid), dim3(SG_WAVES * WAVE), SG_WAVES * ((s->lds_stage + 7) / 8) * 8, s->stream, s->T, s->D, O, w, mode, h, t);
 }
 
 void launch_trial_phase(tqgpu_solver *s, const Opts &O, bool fast, int it, int t, int phase, int &launches) {
@@ -1809,7 +1821,7 @@ int launch_persist(tqgpu_solver *s, const Opts &O, int &launches, int prologue, 
 /* one Newton iteration on the generic path = its termination test (gradient + check) and the rest (Newton system, step,
  * first trial); `parts` bit 0 / bit 1 select them.  The host enqueues the iteration it expects to be the last one
  * (warm: as many as the previous solve needed) without the rest: ~17 launches that would only find `done` set. */
-void launch_generic_iteration(tqgpu_solver *s, const Opts &O, int h, int &launches, int parts = 3, bool phases = false) {
+void launch_generic_iteration(tqgpu_solver *s, const Opts &O, int h, int &launches, int parts = 3, bool phases = false, bool last = false) {
     const Tree &T = s->T; const Data &D = s->D; hipStream_t st = s->stream;
     auto mark = [&](int i) { if (phases && (size_t)(4 * h + i) < s->phase_ev.size()) (void)hipEventRecord(s->phase_ev[(size_t)(4 * h + i)], st); };
     if (s->w3_now) {
@@ -1817,15 +1829,17 @@ void launch_generic_iteration(tqgpu_solver *s, const Opts &O, int h, int &launch
         if (!(parts & 2)) return;
         s->bw_epoch++;
         if (s->bw_epoch == 0) s->bw_epoch = 1;
+        s->w3_tail_sg = false;
         hipLaunchKernelGGL(k_hf_w, dim3(T.Np), dim3(WT), s->lds_hf_w, st, T, D, O, s->sch_words, s->sch_rs, s->bw_epoch, h); launches++;
         if (T.Np > 1) {
             s->fw_epoch++;
             if (s->fw_epoch == 0) s->fw_epoch = 1;
             hipLaunchKernelGGL(k_fwd3, dim3((T.Np - 1 + SG_WAVES - 1) / SG_WAVES), dim3(SG_WAVES * WAVE), 0, st, T, D, next_w3(s), s->fw_words, s->fw_epoch, h); launches++;
         } else { hipLaunchKernelGGL(k_ls_begin, dim3(1), dim3(256), 0, st, T, D, h); launches++; }
-        launch_sg(s, O, 1, h, 1); launches++;
         const int kpred = h < (int)s->ls_pred.size() ? std::min(s->ls_pred[(size_t)h], O.lsMaxIter) : 1;
-        for (int tt = 2; tt <= kpred; tt++) { launch_sg(s, O, 1, h, tt); launches++; }
+        s->w3_post_next = last && kpred < 2;
+        launch_sg(s, O, 1, h, 1); launches++;
+        for (int tt = 2; tt <= kpred; tt++) { s->w3_post_next = last && tt == kpred; launch_sg(s, O, 1, h, tt); launches++; }
         return;
     }
     mark(0);
@@ -2419,6 +2433,25 @@ extern "C" int tqgpu_set_problem(tqgpu_solver *s, const double *A, const double 
 namespace {
 
 int read_ctrl(tqgpu_solver *s) {
+    if (s->w3_now && s->w3_mirror && !s->w3_tail_sg) {
+        /* the last launch enqueued does not post (the first sweep of a solve whose chunk launches nothing else): a one-thread launch does */
+        W3 w = next_w3(s);
+        w.hm = s->h_res; s->w3_wait = w.tag; s->w3_tail_sg = true;
+        hipLaunchKernelGGL(k_w3_post, dim3(1), dim3(WAVE), 0, s->stream, s->D, w);
+    }
+    if (s->w3_now && s->w3_mirror && s->w3_tail_sg) {
+        /* three-launch family: the last launch enqueued posts the control block to pinned memory itself (w3_mirror) */
+        volatile unsigned *seq = &s->h_res->seq;
+        const unsigned want = s->w3_wait;
+        const auto t0 = std::chrono::steady_clock::now();
+        bool seen = true;
+        for (long spins = 0; *seq != want; spins++) {
+            __builtin_ia32_pause();
+            if ((spins & 0xFFFF) == 0xFFFF && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) { seen = false; break; }
+        }
+        if (seen) { std::atomic_thread_fence(std::memory_order_acquire); s->w3_seen = true; return TQGPU_OK; }      /* h_ctrl IS the block's control block */
+    }
+    s->w3_seen = false;
     HIP_TRY(hipMemcpyAsync(s->h_ctrl, s->D.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     return TQGPU_OK;
@@ -2513,7 +2546,14 @@ int solve_begin(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, GItem *defer
     s->solve_no++;
     /* the event pair costs two more packets on the queue per solve; a single persistent launch reports its own clock (launch
      * start to verdict) anyway, so there the pair is optional */
-    cx.events = (s->ev_timing || !cx.persist) && !cx.batch_seq;
+    /* the three-launch family reports through the pinned result block as well (launches of k_sg / k_sgp post the control block and
+     * their own clock: w3_mirror) */
+    const bool w3_will = !cx.persist && s->w3_ok && !s->dense && !cx.phases && !cx.fast && !s->sharded;
+    const bool no_mirror = getenv("TREEQP_AMD_NO_W3_MIRROR") != nullptr;        /* (A/B and tests: copy + synchronisation per read, HIP events per solve, as before) */
+    s->w3_mirror = w3_will && !o->profile && !no_mirror;
+    s->w3_seen = false;
+    if (s->w3_mirror) s->h_res->seq = 0;          /* (no launch of this mirror is in flight) */
+    cx.events = (s->ev_timing || (!cx.persist && !s->w3_mirror)) && !cx.batch_seq;
     s->ring_ok[(size_t)cx.ring] = cx.events ? 1 : 0;
     if (cx.events) HIP_TRY(hipEventRecord(cx.ev0, st));
     /* the three-launch family with k_sgp: the first launch of the solve takes the starting duals and resets the control block itself */
@@ -2613,7 +2653,9 @@ int solve_end(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, tqgpu_result *
                 int parts = 3;
                 if (rest_due == h + i) parts &= ~1;                                   /* its test already ran */
                 if (predicted && i == n - 1) { parts &= ~2; deferred = h + i; }
-                if (parts) launch_generic_iteration(s, O, h + i, launches, parts, cx.phases);
+                /* (three-launch family: the last iteration of the chunk that launches anything posts the verdict to the host) */
+                const bool last = i == n - 1 || (predicted && i == n - 2);
+                if (parts) launch_generic_iteration(s, O, h + i, launches, parts, cx.phases, last);
             }
             if (o->profile && ev_idx + 1 < (int)s->iter_ev.size()) HIP_TRY(hipEventRecord(s->iter_ev[++ev_idx], st));
         }
@@ -2637,7 +2679,11 @@ int solve_end(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, tqgpu_result *
             /* the line search of iteration `iter` wants more trials: a batch of them */
             const int it = s->h_ctrl->iter, t0 = s->h_ctrl->ls_iter;
             if (it != ls_of) { ls_of = it; trial_batch = trial_batch0; }
-            for (int t = t0; t < t0 + trial_batch && t <= O.lsMaxIter; t++) { int rcx = launch_trial(s, O, fast, it, t, launches); if (rcx != TQGPU_OK) return rcx; }
+            for (int t = t0; t < t0 + trial_batch && t <= O.lsMaxIter; t++) {
+                s->w3_post_next = t + 1 >= t0 + trial_batch || t + 1 > O.lsMaxIter;      /* the last of the batch */
+                int rcx = launch_trial(s, O, fast, it, t, launches);
+                if (rcx != TQGPU_OK) return rcx;
+            }
             trial_batch = std::min(2 * trial_batch, 16);
             if ((rc = read_ctrl(s)) != TQGPU_OK) return rc;
         }
@@ -2658,7 +2704,13 @@ int solve_end(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, tqgpu_result *
     }
     const int host_iter = ev_idx;
     float ms = 0.f;
-    if (!tail_done) {
+    if (!tail_done && !persist && s->w3_now && s->w3_mirror && s->w3_seen && !cx.events && !o->profile && !cx.phases) {
+        /* three-launch family: every launch of the solve is accounted for (the last one's tail has posted the verdict; what its other
+         * workgroups still write is stream-ordered before anything the host does next): no synchronisation, the device's own clock */
+        unsigned long long t_first;
+        memcpy(&t_first, &s->h_ctrl->pad0, sizeof(t_first));
+        ms = 1e-5f * (float)(s->h_res->t_end - t_first);
+    } else if (!tail_done) {
         if (cx.events) HIP_TRY(hipEventRecord(cx.ev1, st));
         HIP_TRY(hipStreamSynchronize(st));
         if (cx.events) HIP_TRY(hipEventElapsedTime(&ms, cx.ev0, cx.ev1));
@@ -2694,7 +2746,8 @@ int solve_end(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, tqgpu_result *
         if (c.status == 0 && c.ls_total > c.iter) {
             /* some iteration needed further trials: fetch the trial counts (only then: a copy is a packet on the queue and a synchronisation) */
             const int nlog = std::min(c.iter, std::min(s->ls_log_cap, 256));
-            HIP_TRY(hipMemcpy(s->h_ls_log, s->D.ls_log, sizeof(int) * (size_t)nlog, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpyAsync(s->h_ls_log, s->D.ls_log, sizeof(int) * (size_t)nlog, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
             s->ls_pred.assign(s->h_ls_log, s->h_ls_log + nlog);
         }
     }

@@ -38,7 +38,24 @@ struct W3 {
     unsigned tag;
     int sum_nx;
     int lds_wave;        /* doubles of LDS per wave of k_sg (a node's stage window) */
+    HostRes *hm;         /* pinned host memory: the control block as the launch leaves it, then the launch's tag (w3_mirror); nullptr: none */
 };
+/* The verdict of a launch of k_sg / k_sgp goes straight to the host, as on the persistent path: the control block by system-scope
+ * stores to pinned memory, the stores' acknowledgements, then the launch's tag.  The host enqueues a chunk of launches that ends with
+ * one of these and polls for its tag instead of a device-to-host copy and a stream synchronisation per chunk (and, without the HIP
+ * event pair, per solve).  Called by ONE thread: the one that wrote the control block (the tail), or thread 0 of workgroup 0 of a
+ * launch that found its phase not due (every earlier launch is over by then). */
+__device__ __forceinline__ void w3_mirror(const W3 &Wd, Ctrl *c, bool first, unsigned long long t_start) {
+    if (first) *reinterpret_cast<unsigned long long *>(&c->pad0) = t_start;      /* the solve's first launch: its start, kept in the control block (pad0, pad1) */
+    if (!Wd.hm) return;
+    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(c);
+    unsigned long long *dst = reinterpret_cast<unsigned long long *>(&Wd.hm->c);
+    for (int i = 0; i < (int)(sizeof(Ctrl) / 8); i++) __hip_atomic_store(dst + i, src[i], RLX, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&Wd.hm->t_end, (unsigned long long)wall_clock64(), RLX, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(&Wd.hm->seq, Wd.tag, RLX, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 
 #define SG_WAVES 4
 
@@ -136,7 +153,8 @@ __global__ void __launch_bounds__(SG_WAVES * WAVE) k_sg(Tree T, Data D, Opts O, 
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double part[2][SG_WAVES];
     Ctrl *c = D.ctrl;
-    if (mode == 1 && !phase_trial(c, h, t)) return;
+    const unsigned long long t_begin = wall_clock64();
+    if (mode == 1 && !phase_trial(c, h, t)) { if (blockIdx.x == 0 && threadIdx.x == 0) w3_mirror(Wd, c, false, 0ull); return; }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int k = blockIdx.x * SG_WAVES + wave;
     double *win = lds + (size_t)wave * Wd.lds_wave;
@@ -175,7 +193,13 @@ __global__ void __launch_bounds__(SG_WAVES * WAVE) k_sg(Tree T, Data D, Opts O, 
             c->err = err;
             if (err < O.tol) { c->done = 1; c->status = 0; }      /* TREEQP_OPTIMAL_SOLUTION_FOUND */
         }
+        w3_mirror(Wd, c, mode == 0, t_begin);
     }
+}
+
+/* the control block to the host, on its own (read_ctrl: the last launch enqueued is not one that posts) */
+__global__ void k_w3_post(Data D, W3 Wd) {
+    if (threadIdx.x == 0) w3_mirror(Wd, D.ctrl, false, 0ull);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -259,7 +283,8 @@ __global__ void __launch_bounds__(WT) k_sgp(Tree T, Data D, Opts O, W3 Wd, int m
     const bool fresh = mode == 0 && lam_src != nullptr;
     const int cur = fresh ? 0 : c->cur, ls_iter = c->ls_iter;
     const double step = c->tau - c->tauPrev;
-    if (mode == 1 && !phase_trial(c, h, t)) return;
+    const unsigned long long t_begin = wall_clock64();
+    if (mode == 1 && !phase_trial(c, h, t)) { if (blockIdx.x == 0 && tid == 0) w3_mirror(Wd, c, false, 0ull); return; }
     const int d = e[0], nxp = e[1], nup = e[2], nkp = e[3], k0 = e[4], nz = nxp + nup, xop = e[5], uop = e[6], ko = e[7];
     SGSTAMP(0);
     const bool save_s = mode == 1 && ls_iter == 1;      /* first trial of a line search: xUnc / uUnc still hold phase S of this iteration */
@@ -446,6 +471,7 @@ __global__ void __launch_bounds__(WT) k_sgp(Tree T, Data D, Opts O, W3 Wd, int m
             c->err = err;
             if (err < O.tol) { c->done = 1; c->status = 0; }      /* TREEQP_OPTIMAL_SOLUTION_FOUND */
         }
+        w3_mirror(Wd, c, mode == 0, t_begin);
     }
 }
 /* LDS of k_sgp: C, the four 64-entry vectors, the children's terms */
