@@ -2946,8 +2946,9 @@ extern "C" int tqgpu_solve_batch(tqgpu_solver **solvers, int n, const tqgpu_opts
         }
         for (int k = begun_from; k < begun_to; k++) {
             /* a member of the previous batch launch that goes out again on the same lead's stream is ordered behind it by that stream */
-            const bool same_lead = !pm.empty() && solvers[k]->settle_stream == solvers[pm[0]]->stream && std::find(pm.begin(), pm.end(), k) != pm.end();
-            if (same_lead) { if (k == pm[0]) solvers[k]->settle_stream = nullptr; }
+            const bool same_lead = (!pm.empty() && solvers[k]->settle_stream == solvers[pm[0]]->stream && std::find(pm.begin(), pm.end(), k) != pm.end()) ||
+                                   (lead && solvers[k]->settle_stream == lead->stream && std::find(gp_members.begin(), gp_members.end(), k) != gp_members.end());
+            if (same_lead) { if ((!pm.empty() && k == pm[0]) || (lead && k == gp_members[0])) solvers[k]->settle_stream = nullptr; }
             else SETTLE(solvers[k]);
         }
         unsigned pseq = 0;
@@ -2966,6 +2967,7 @@ extern "C" int tqgpu_solve_batch(tqgpu_solver **solvers, int n, const tqgpu_opts
             pseq = nn << 16;
         }
         size_t gi = 0, lds_batch = 0, pi = 0;
+        bool gp_launched = false;
         for (int k = begun_from; k < begun_to; k++) {
             const bool in_group = lead && gi < gp_members.size() && gp_members[gi] == k;
             if (pi < pm.size() && pm[pi] == k) { cx[(size_t)k].batch_seq = pseq; pi++; }
@@ -2978,18 +2980,18 @@ extern "C" int tqgpu_solve_batch(tqgpu_solver **solvers, int n, const tqgpu_opts
             hipStream_t st0 = lead->stream;
             /* inputs of the other members were uploaded on their own streams: order the launch behind them, and their
              * later work (solution export) behind the launch */
+            /* (round 3: no event traffic in the steady state -- a record and a wait per member before the launch and another wait after it
+             * were 1.5 ms of an 11.5 ms step with 256 trees.  What a member enqueued on its own stream since its last synchronisation
+             * (asynchronous uploads: stream_pending) is waited for here; the launch's end is waited for lazily, see settle().) */
             for (size_t m = 1; m < gi; m++) {
                 tqgpu_solver *sm = solvers[gp_members[m]];
-                if (!sm->batch_ev && hipEventCreateWithFlags(&sm->batch_ev, hipEventDisableTiming) != hipSuccess) return fail(TQGPU_ENODEVICE, "hipEventCreate failed");
-                HIP_TRY(hipEventRecord(sm->batch_ev, sm->stream));
-                HIP_TRY(hipStreamWaitEvent(st0, sm->batch_ev, 0));
+                if (sm->stream_pending) { HIP_TRY(hipStreamSynchronize(sm->stream)); sm->stream_pending = false; }
             }
             HIP_TRY(hipMemcpyAsync(lead->d_gitems, lead->h_gitems, gi * sizeof(GItem), hipMemcpyHostToDevice, st0));
             if (lds_batch > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(g_persist_batch), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_batch));
             hipLaunchKernelGGL(g_persist_batch, dim3((unsigned)gi), dim3(GP_WAVES * WAVE), lds_batch, st0, lead->d_gitems, cx[(size_t)gp_members[0]].O);
-            if (!lead->batch_ev && hipEventCreateWithFlags(&lead->batch_ev, hipEventDisableTiming) != hipSuccess) return fail(TQGPU_ENODEVICE, "hipEventCreate failed");
-            HIP_TRY(hipEventRecord(lead->batch_ev, st0));
-            for (size_t m = 1; m < gi; m++) HIP_TRY(hipStreamWaitEvent(solvers[gp_members[m]]->stream, lead->batch_ev, 0));
+            for (size_t m = 0; m < gi; m++) solvers[gp_members[m]]->batch_stream = st0;
+            gp_launched = true;
         }
         if (!pm.empty() && ok_to == begun_to) {
             tqgpu_solver *pl = solvers[pm[0]];
@@ -3042,6 +3044,10 @@ extern "C" int tqgpu_solve_batch(tqgpu_solver **solvers, int n, const tqgpu_opts
         if (!pm.empty() && ok_to == begun_to) {
             if (first_err != TQGPU_OK || getenv("TREEQP_AMD_BATCH_SYNC")) HIP_TRY(hipStreamSynchronize(solvers[pm[0]]->stream));
             else for (size_t m = 1; m < pm.size(); m++) solvers[pm[m]]->settle_stream = solvers[pm[0]]->stream;      /* see settle() */
+        }
+        if (gp_launched) {
+            if (first_err != TQGPU_OK || getenv("TREEQP_AMD_BATCH_SYNC")) HIP_TRY(hipStreamSynchronize(lead->stream));
+            else for (size_t m = 1; m < gi; m++) solvers[gp_members[m]]->settle_stream = lead->stream;
         }
         if (first_err != TQGPU_OK) break;
         i = j;
