@@ -2553,7 +2553,7 @@ int solve_begin(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, GItem *defer
     s->w3_mirror = w3_will && !o->profile && !no_mirror;
     s->w3_seen = false;
     if (s->w3_mirror) s->h_res->seq = 0;          /* (no launch of this mirror is in flight) */
-    cx.events = (s->ev_timing || (!cx.persist && !s->w3_mirror)) && !cx.batch_seq;
+    cx.events = (s->ev_timing || (!cx.persist && !s->w3_mirror)) && !cx.batch_seq && !defer;      /* (a member of a batch launch: the launch is on the lead's stream, an event pair on the member's own would time nothing) */
     s->ring_ok[(size_t)cx.ring] = cx.events ? 1 : 0;
     if (cx.events) HIP_TRY(hipEventRecord(cx.ev0, st));
     /* the three-launch family with k_sgp: the first launch of the solve takes the starting duals and resets the control block itself */

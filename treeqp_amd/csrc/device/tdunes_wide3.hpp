@@ -1083,10 +1083,17 @@ __global__ void __launch_bounds__(SG_WAVES * WAVE) k_fwd3(Tree T, Data D, W3 Wd,
             }
         }
         double a0 = 0.0, a1 = 0.0;
+        /* (groups of eight rows of M that do not exist are skipped: nx = 8 takes a quarter of the chain of broadcasts; the terms that
+         * are left out are exact zeros) */
 #pragma unroll
-        for (int i = 0; i < 32; i += 2) {
-            a0 = fma(i < nxi ? mrow[i] : 0.0, rdlane(val, i), a0);
-            a1 = fma(i + 1 < nxi ? mrow[i + 1] : 0.0, rdlane(val, i + 1), a1);
+        for (int i0 = 0; i0 < 32; i0 += 8) {
+            if (i0 < nxi) {
+#pragma unroll
+                for (int i = i0; i < i0 + 8; i += 2) {
+                    a0 = fma(i < nxi ? mrow[i] : 0.0, rdlane(val, i), a0);
+                    a1 = fma(i + 1 < nxi ? mrow[i + 1] : 0.0, rdlane(val, i + 1), a1);
+                }
+            }
         }
         const double mine = z0 - (a0 + a1);
         if (lane < d) {
