@@ -101,6 +101,12 @@ int tqgpu_set_lambda(tqgpu_solver *s, const double *lambda);   /* NULL = zeros *
 
 int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *opts, tqgpu_result *res);
 
+/* on != 0: tqgpu_solve enqueues the packing kernel and the download of the solution right behind a single persistent launch, while it
+ * runs; the tqgpu_get_solution that follows only waits for the copy.  For callers that fetch the solution after every solve (the
+ * drop-in front end, treeqp_tdunes_solve -> dual_Newton_tree.c:1235-1247); off by default (a caller that only wants the verdict pays
+ * for nothing).  Results are the same either way. */
+int tqgpu_set_export_ahead(tqgpu_solver *s, int on);
+
 /* any output pointer may be NULL */
 int tqgpu_get_solution(tqgpu_solver *s, double *x, double *u, double *lam, double *mu_x, double *mu_u, double *dlam);
 

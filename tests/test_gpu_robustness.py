@@ -508,3 +508,45 @@ def test_fused_sweeps_on_a_crowded_device(gpu, orc, monkeypatch):
     for k in ("x", "u", "lam"):
         assert np.array_equal(s0[k], s1[k])
     g.close()
+
+
+@pytest.mark.gpu
+def test_solution_download_enqueued_behind_the_solve(gpu, orc):
+    """tqgpu_set_export_ahead (what the drop-in front end switches on): the packing kernel and the download of the solution are
+    enqueued behind the persistent launch while it runs, the device picks the current dual buffer.  Same solutions, bit for bit, as
+    the download after the verdict: a converged solve, a solve cut off by the iteration limit (the export takes the unclipped values
+    of phase S then), changed data, a solve on a path without a single persistent launch (ignored there), a batch solve in between
+    (which invalidates what was fetched ahead)."""
+    p = P.linear_chain(2, 9, 9)
+    flat = product_qp_from_lti(gpu, p).flat()
+    a = gpu.TqGpu(flat["nk"], flat["nx"], flat["nu"]).upload(flat, p.lambda0)
+    b = gpu.TqGpu(flat["nk"], flat["nx"], flat["nu"]).upload(flat, p.lambda0)
+    assert a.path == 2
+    a.export_ahead(True)
+    def same(**kw):
+        ra, rb = a.solve(**kw), b.solve(**kw)
+        assert (ra["status"], ra["iter"], ra["ls_total"]) == (rb["status"], rb["iter"], rb["ls_total"])
+        sa, sb = a.solution(), b.solution()
+        for k in ("x", "u", "lam", "mu_x", "mu_u", "dlam"):
+            assert np.array_equal(sa[k], sb[k]), k
+        return ra
+    assert same()["status"] == 0
+    assert same()["status"] == 0
+    assert same(maxIter=1)["status"] == 1
+    f2 = dict(flat); f2["umin"] = np.full_like(flat["umin"], -0.3); f2["umax"] = np.full_like(flat["umax"], 0.3)
+    a.upload(f2, p.lambda0); b.upload(f2, p.lambda0)
+    assert same()["status"] == 0
+    sa = a.solution()                                  # a second fetch of the same solution
+    assert np.array_equal(sa["x"], b.solution()["x"])
+    gpu.solve_batch([a, b])                            # not through tqgpu_solve: nothing fetched ahead
+    for k in ("x", "u", "lam"):
+        assert np.array_equal(a.solution()[k], b.solution()[k])
+    a.close(); b.close()
+    f = P.pruned_chain_qp()
+    g = gpu.TqGpu(f.nk, f.nx, f.nu).upload(f.as_dict(), f.lambda0)
+    h = gpu.TqGpu(f.nk, f.nx, f.nu).upload(f.as_dict(), f.lambda0)
+    g.export_ahead(True)
+    rg, rh = g.solve(**f.opts), h.solve(**f.opts)
+    assert (rg["status"], rg["iter"]) == (rh["status"], rh["iter"]) and g.path == 0
+    assert np.array_equal(g.solution()["x"], h.solution()["x"])
+    g.close(); h.close()

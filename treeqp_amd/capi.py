@@ -541,6 +541,10 @@ class TqGpu:
             assert len(a) == self.sum_lam
         self._chk(lib().tqgpu_set_lambda(self.h, _dp(a)))
 
+    def export_ahead(self, on: bool) -> None:
+        """the solution's packing kernel and download go out behind the solve's launch (callers that fetch the solution after every solve)"""
+        self._chk(lib().tqgpu_set_export_ahead(self.h, int(bool(on))))
+
     def event_timing(self, on: bool) -> None:
         """Per-solve HIP event pairs on / off (off: device_times() gives NaN for single-launch solves)."""
         self._chk(lib().tqgpu_set_event_timing(self.h, int(bool(on))))

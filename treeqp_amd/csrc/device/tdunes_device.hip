@@ -1137,6 +1137,8 @@ struct tqgpu_solver {
     bool stream_pending = false;                                          /* something was enqueued on `stream` without a synchronisation after it (asynchronous uploads, constant packing): a batch launch on ANOTHER stream waits for it first */
     hipEvent_t batch_ev = nullptr;
     hipStream_t batch_stream = nullptr;                                   /* member of a batch launch in flight: the stream that launch is on (the lead's) */
+    bool export_ahead = false;          /* tqgpu_set_export_ahead: the packing kernel and the download of the solution are enqueued right behind a single persistent launch */
+    bool export_valid = false;          /* h_out holds (or is about to hold, stream-ordered) the solution of the last solve */
     hipStream_t settle_stream = nullptr;                                  /* member of a batch launch whose verdict is in but whose last workgroups may still write back:
                                                                            * the lead's stream, to be waited for before this mirror is touched through its own stream (settle) */
     size_t sync_words_bytes = 0, lds_persist = 0;
@@ -1912,7 +1914,10 @@ __global__ void k_export_all(int n_x, int n_u, int n_lam, int x_pad, int nx0, Da
         omx[i] = D.Qd[j] * fma(-1.0, D.x[j], (maxit ? D.xUncS : D.xUnc)[j]);      /* dense nodes: Qd = 0 (no bounds, no multipliers) */
     }
     if (i < n_u) { ou[i] = D.u[i]; omu[i] = D.Rd[i] * fma(-1.0, D.u[i], (maxit ? D.uUncS : D.uUnc)[i]); }
-    if (i < n_lam) { ol[i] = lamc[nx0 + i]; od[i] = D.dlam[nx0 + i]; }
+    if (i < n_lam) {
+        const double *lc = lamc ? lamc : (D.ctrl->cur ? D.lam1 : D.lam0);      /* (enqueued behind a solve that is still running: the device knows) */
+        ol[i] = lc[nx0 + i]; od[i] = D.dlam[nx0 + i];
+    }
 }
 
 }  // namespace
@@ -2508,6 +2513,7 @@ int solve_begin(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, GItem *defer
     cx.hp0 = HP_NOW();
 #endif
     HIP_TRY(hipSetDevice(s->device));
+    s->export_valid = false;
     Opts &O = cx.O;
     O.maxIter = o->maxIter; O.termCondition = o->termCondition; O.regType = o->regType;
     O.lsMaxIter = o->lineSearchMaxIter; O.lsRestartTrigger = o->lineSearchRestartTrigger; O.reuse = o->checkLastActiveSet == 2 ? 1 : 0;
@@ -2776,6 +2782,15 @@ static int solve_after_timeout(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_resul
     return solve_end(s, o, cx, res);
 }
 
+static int enqueue_export(tqgpu_solver *s, const double *lamc) {
+    const Data &D = s->D;
+    const int nxe = s->sum_nx - s->x_pad, nue = s->sum_nu, nl = s->sum_lam;
+    const int n = std::max(std::max(nxe, nue), std::max(nl, 1));
+    hipLaunchKernelGGL(k_export_all, dim3((n + 255) / 256), dim3(256), 0, s->stream, nxe, nue, nl, s->x_pad, s->nx0, D, lamc, s->d_out);
+    HIP_TRY(hipMemcpyAsync(s->h_out, s->d_out, sizeof(double) * std::max<size_t>(s->out_doubles, 1), hipMemcpyDeviceToHost, s->stream));
+    return TQGPU_OK;
+}
+
 extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *res) {
     SETTLE(s);
     if (!s || !o || !res) return fail(TQGPU_EINVAL, "tqgpu_solve: bad arguments");
@@ -2783,9 +2798,24 @@ extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *r
     SolveCtx cx;
     int rc = solve_begin(s, o, cx);
     if (rc != TQGPU_OK) return rc;
+    const int launches0 = cx.launches;
+    /* a caller that always fetches the solution (the drop-in front end): the packing kernel and the download go out behind the single
+     * persistent launch now, while it runs, instead of after its verdict has travelled to the host and back (a launch latency, the
+     * launch's write-back tail and a synchronisation off the caller's critical path); which dual buffer is current is the device's
+     * knowledge.  Valid if that one launch was the whole solve. */
+    const bool ahead = s->export_ahead && cx.persist && cx.prelaunched && !s->pshard && !s->sharded;
+    if (ahead && enqueue_export(s, nullptr) != TQGPU_OK) return TQGPU_ENODEVICE;
     rc = solve_end(s, o, cx, res);
     if (rc == TQGPU_ETIMEOUT) rc = solve_after_timeout(s, o, res);
+    else if (rc == TQGPU_OK && ahead && res->n_launches == launches0) s->export_valid = true;
     return rc;
+}
+
+extern "C" int tqgpu_set_export_ahead(tqgpu_solver *s, int on) {
+    if (!s) return fail(TQGPU_EINVAL, "null solver");
+    s->export_ahead = on != 0;
+    s->export_valid = false;
+    return TQGPU_OK;
 }
 
 /* n solves of the same problem from the same starting duals, one after the other (each waits for its verdict), as the reference's
@@ -3572,9 +3602,7 @@ extern "C" int tqgpu_get_solution(tqgpu_solver *s, double *x, double *u, double 
     /* one packing kernel, one download into pinned memory, one synchronisation (ordered behind the solve on the stream) */
     const double *lamc = s->h_ctrl->cur ? D.lam1 : D.lam0;
     const int nxe = s->sum_nx - s->x_pad, nue = s->sum_nu, nl = s->sum_lam;
-    const int n = std::max(std::max(nxe, nue), std::max(nl, 1));
-    hipLaunchKernelGGL(k_export_all, dim3((n + 255) / 256), dim3(256), 0, st, nxe, nue, nl, s->x_pad, s->nx0, D, lamc, s->d_out);
-    HIP_TRY(hipMemcpyAsync(s->h_out, s->d_out, sizeof(double) * std::max<size_t>(s->out_doubles, 1), hipMemcpyDeviceToHost, st));
+    if (!s->export_valid) { int rce = enqueue_export(s, lamc); if (rce != TQGPU_OK) return rce; }      /* (else: went out behind the solve, tqgpu_set_export_ahead) */
     HIP_TRY(hipStreamSynchronize(st));
     const double *ox = s->h_out, *ou = ox + nxe, *ol = ou + nue, *od = ol + nl, *omx = od + nl, *omu = omx + nxe;
     if (x && nxe > 0) memcpy(x, ox, sizeof(double) * (size_t)nxe);

@@ -235,6 +235,9 @@ void treeqp_tdunes_create(const tree_qp_in *qp_in, const treeqp_tdunes_opts_t *o
     int rc = tqgpu_create(&work->device, device, Nn, nk, qp_in->nx, qp_in->nu);
     free(nk);
     if (rc != TQGPU_OK) fatal("cannot create the MI355X device mirror for tdunes (no CPU fallback exists)", tqgpu_last_error());
+    /* this front end fetches the solution after every solve and times the solve with the host clock: the download goes out behind the
+     * solve's launch, and no HIP event pair is recorded around it (TREEQP_AMD_DROPIN_PLAIN=1: neither, for comparison) */
+    if (!getenv("TREEQP_AMD_DROPIN_PLAIN")) { (void)tqgpu_set_export_ahead(work->device, 1); (void)tqgpu_set_event_timing(work->device, 0); }
     track(work->device);
 }
 
