@@ -474,6 +474,16 @@ def test_batch_of_one_shape_is_one_launch_and_survives_changes(gpu, orc):
     r3 = ms[3].solve()
     assert (r3["status"], r3["iter"], r3["ls_total"]) == (singles[3][0]["status"], singles[3][0]["iter"], singles[3][0]["ls_total"])
     assert np.array_equal(ms[3].solution()["x"], singles[3][1]["x"])
+    # the lead is destroyed before a member is touched again (its stream is gone: the member must not wait for it)
+    trio = [gpu.TqGpu(*built[i][2]).upload(built[i][1], built[i][0].lambda0) for i in range(3)]
+    gpu.solve_batch(trio)
+    gpu.solve_batch(trio)
+    trio[0].close()
+    for i in (1, 2):
+        assert np.array_equal(trio[i].solution()["x"], singles[i][1]["x"])
+        r = trio[i].solve()
+        assert (r["status"], r["iter"]) == (singles[i][0]["status"], singles[i][0]["iter"])
+        trio[i].close()
     # as many trees as are co-resident (every CU but one carries two workgroups): the capacity figure is exact, no margin
     geo = ms[0].geometry()
     n_many = min(60, geo["capacity"] // geo["workgroups"])

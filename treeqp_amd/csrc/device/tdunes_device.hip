@@ -42,6 +42,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -1165,11 +1167,17 @@ extern "C" const char *tqgpu_last_error(void) { return g_err.c_str(); }
 /* A batch launch runs on its lead's stream; the other members' own streams are not ordered behind it.  Its end is waited for lazily:
  * a loop of batch solves on the same lead stays stream-ordered by itself and pays no synchronisation per step (10 - 15 us of a
  * 150 us step), anything else that touches a member comes through here first. */
+/* (the lead may have been destroyed in the meantime -- tqgpu_destroy synchronises its stream first, so there is nothing left to wait
+ * for, but the handle must not be used: the streams of live mirrors are kept in a set) */
+static std::mutex g_streams_mu;
+static std::set<hipStream_t> g_live_streams;
 static int settle(tqgpu_solver *s) {
     if (s && s->settle_stream) {
         hipStream_t t = s->settle_stream;
         s->settle_stream = nullptr;
-        if (t != s->stream) HIP_TRY(hipStreamSynchronize(t));
+        bool live;
+        { std::lock_guard<std::mutex> lk(g_streams_mu); live = g_live_streams.count(t) != 0; }
+        if (t != s->stream && live) HIP_TRY(hipStreamSynchronize(t));
     }
     return TQGPU_OK;
 }
@@ -1997,6 +2005,7 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
     if (hipMalloc(&s->slab, s->slab_bytes) != hipSuccess) { delete s; return fail(TQGPU_ENOMEM, "hipMalloc failed for the device mirror"); }
     if (hipMemset(s->slab, 0, s->slab_bytes) != hipSuccess) return cleanup_fail(fail(TQGPU_ENODEVICE, "hipMemset failed"));
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) return cleanup_fail(fail(TQGPU_ENODEVICE, "hipStreamCreate failed"));
+    { std::lock_guard<std::mutex> lk(g_streams_mu); g_live_streams.insert(s->stream); }
     s->ring_ev0.assign(EV_RING, nullptr); s->ring_ev1.assign(EV_RING, nullptr); s->ring_ok.assign(EV_RING, 0);
     for (int i = 0; i < EV_RING; i++)
         if (hipEventCreate(&s->ring_ev0[i]) != hipSuccess || hipEventCreate(&s->ring_ev1[i]) != hipSuccess) return cleanup_fail(fail(TQGPU_ENODEVICE, "hipEventCreate failed"));
@@ -2189,7 +2198,7 @@ extern "C" void tqgpu_destroy(tqgpu_solver *s) {
     if (s->sweep_ev1) (void)hipEventDestroy(s->sweep_ev1);
     for (auto &ev : s->ring_ev0) if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : s->ring_ev1) if (ev) (void)hipEventDestroy(ev);
-    if (s->stream) (void)hipStreamDestroy(s->stream);
+    if (s->stream) { { std::lock_guard<std::mutex> lk(g_streams_mu); g_live_streams.erase(s->stream); } (void)hipStreamDestroy(s->stream); }
     if (s->h_res) (void)hipHostFree(s->h_res);
     if (s->h_ls_log) (void)hipHostFree(s->h_ls_log);
     if (s->shard_slab) (void)hipFree(s->shard_slab);
