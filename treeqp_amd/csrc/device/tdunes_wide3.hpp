@@ -739,18 +739,22 @@ __global__ void __launch_bounds__(WT, TQ_W3_WPS) k_hf_w(Tree T, Data D, Opts O, 
             for (int m = 0; m < 4; m++)
 #pragma unroll
                 for (int t = 0; t < 3; t++) {
-                    const double a = Cs[16 * wJ[t] + r16 + (4 * m + g) * ldc] * pcs[m];
-                    const double b = Cs[16 * wI[t] + r16 + (4 * m + g) * ldc];
-                    wacc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, wacc[t], 0, 0, 0);
+                    if (wv[t]) {          /* (uniform: a wave's tile slots that hold no tile take no turn on the matrix pipe) */
+                        const double a = Cs[16 * wJ[t] + r16 + (4 * m + g) * ldc] * pcs[m];
+                        const double b = Cs[16 * wI[t] + r16 + (4 * m + g) * ldc];
+                        wacc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, wacc[t], 0, 0, 0);
+                    }
                 }
             if (nz > 16) {
 #pragma unroll
                 for (int m = 4; m < 8; m++)
 #pragma unroll
                     for (int t = 0; t < 3; t++) {
-                        const double a = Cs[16 * wJ[t] + r16 + (4 * m + g) * ldc] * pcs[m];
-                        const double b = Cs[16 * wI[t] + r16 + (4 * m + g) * ldc];
-                        wacc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, wacc[t], 0, 0, 0);
+                        if (wv[t]) {
+                            const double a = Cs[16 * wJ[t] + r16 + (4 * m + g) * ldc] * pcs[m];
+                            const double b = Cs[16 * wI[t] + r16 + (4 * m + g) * ldc];
+                            wacc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, wacc[t], 0, 0, 0);
+                        }
                     }
             }
 #pragma unroll
@@ -906,17 +910,21 @@ __global__ void __launch_bounds__(WT, TQ_W3_WPS) k_hf_w(Tree T, Data D, Opts O, 
                 }
             }
             if (wave >= 2 && p > 0 && ii > 0) {
-                /* G += Xt[:, panel p - 1] Xt[:, panel p - 1]' */
+                /* G += Xt[:, panel p - 1] Xt[:, panel p - 1]' (tiles that do not exist -- nx <= 15: one row tile, only (0,0) -- are left out:
+                 * their products would only take the matrix pipe from the trailing update) */
                 int I2[3], J2[3];
+                bool sv[3];
 #pragma unroll
-                for (int t = 0; t < 3; t++) if (!w3_schur_tile(wave, t, nt2, I2[t], J2[t])) { I2[t] = 0; J2[t] = 0; }
+                for (int t = 0; t < 3; t++) { sv[t] = w3_schur_tile(wave, t, nt2, I2[t], J2[t]); if (!sv[t]) { I2[t] = 0; J2[t] = 0; } }
 #pragma unroll
                 for (int s = 0; s < 16; s += 4)
 #pragma unroll
                     for (int t = 0; t < 3; t++) {
-                        const double a = Tm[dp + 16 * J2[t] + r16 + (kb - 16 + s + g) * ld];
-                        const double b = Tm[dp + 16 * I2[t] + r16 + (kb - 16 + s + g) * ld];
-                        gacc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, gacc[t], 0, 0, 0);
+                        if (sv[t]) {          /* (uniform) */
+                            const double a = Tm[dp + 16 * J2[t] + r16 + (kb - 16 + s + g) * ld];
+                            const double b = Tm[dp + 16 * I2[t] + r16 + (kb - 16 + s + g) * ld];
+                            gacc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, gacc[t], 0, 0, 0);
+                        }
                     }
             }
             W3_BARRIER();                   /* panel p is factorised (rows below the diagonal tile are in LDS), panel p - 1 is applied everywhere */
@@ -947,9 +955,11 @@ __global__ void __launch_bounds__(WT, TQ_W3_WPS) k_hf_w(Tree T, Data D, Opts O, 
             const bool kin = s < wlast;                  /* columns of the last panel that exist */
 #pragma unroll
             for (int t = 0; t < 3; t++) {
-                const double a = Tm[dp + 16 * J2[t] + r16 + (kl + s + g) * ld];
-                const double b = Tm[dp + 16 * I2[t] + r16 + (kl + s + g) * ld];
-                gacc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(kin ? a : 0.0, kin ? b : 0.0, gacc[t], 0, 0, 0);
+                if (kin && sv[t]) {                      /* (uniform; a product that is left out would add exact zeros) */
+                    const double a = Tm[dp + 16 * J2[t] + r16 + (kl + s + g) * ld];
+                    const double b = Tm[dp + 16 * I2[t] + r16 + (kl + s + g) * ld];
+                    gacc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, gacc[t], 0, 0, 0);
+                }
             }
         }
 #pragma unroll
