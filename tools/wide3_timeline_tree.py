@@ -30,10 +30,15 @@ L.tqgpu_debug_block_stamps(g.h, buf.ctypes.data_as(C.POINTER(C.c_ulonglong)), Np
 t = buf.reshape(Np, 4).astype(np.int64)
 us = (t - t[:, 0].min()) / 100.0
 print(f"{Nn} nodes, {Np} blocks, {level.max()} levels below the root; block dimensions {sorted(set(d.tolist()))}")
-print("level blocks | start | records in | posted | end   (min .. max, us after the first workgroup's start)")
+import os
+sgp = bool(os.environ.get("TQ_STAMPS_OF_SGP"))
+print("k_sgp: level blocks | start | C staged | stage done | gradient done" if sgp else "level blocks | start | records in | posted | end", "  (min .. max, us after the first workgroup's start)")
 for l in range(level[:Np].max(), -1, -1):
     s = us[level[:Np] == l]
     print(f"{l:5d} {len(s):6d} | {s[:,0].min():6.1f} {s[:,0].max():6.1f} | {s[:,1].min():6.1f} {s[:,1].max():6.1f} | {s[:,2].min():6.1f} {s[:,2].max():6.1f} | {s[:,3].min():6.1f} {s[:,3].max():6.1f}")
+if sgp:
+    print(f"last workgroup done {us[:, 3].max():.1f} us after the first one started; median lifetime {np.median(us[:, 3] - us[:, 0]):.1f} us, C staged after {np.median(us[:, 1] - us[:, 0]):.1f}, stage after {np.median(us[:, 2] - us[:, 0]):.1f}")
+    g.close(); sys.exit(0)
 own = us[:, 2] - us[:, 1]
 for dd in sorted(set(d.tolist())):
     m = d == dd
