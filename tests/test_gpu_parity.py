@@ -324,6 +324,35 @@ def test_three_launch_family_c4_launch_count(gpu, orc):
     g.close()
 
 
+def test_three_launch_family_forward_sweep_without_handovers(gpu, orc, monkeypatch):
+    """k_fwd3c (trees of small nodes: every wave recomputes its ancestors' slices of the step instead of waiting for them level by
+    level) against k_fwd3 (TREEQP_AMD_NO_FWD_CHAIN=1): the same sums in the same order, so verdicts, counts and solutions are
+    identical bit for bit.  Paths of up to 10 blocks (two rounds of path entries), blocks of 8 / 16 / 24 rows, nodes of 1 .. 8
+    states; a tree whose paths are longer than 16 blocks keeps k_fwd3 and still agrees with the oracle."""
+    cases = [P.pruned_chain_qp(), P.pruned_chain_qp(Nh=6, seed=5), P.random_shape_qp(11, depth=5, max_kids=3, nx_range=(1, 8), nu_range=(1, 3)),
+             P.random_shape_qp(12, depth=4, max_kids=2, nx_range=(3, 8), nu_range=(2, 4), ubound=0.2)]
+    for f in cases:
+        ref = orc.solve(f.as_dict(), orc.default_opts(**f.opts), lambda0=f.lambda0)
+        out = []
+        for chain in (True, False):
+            if chain:
+                monkeypatch.delenv("TREEQP_AMD_NO_FWD_CHAIN", raising=False)
+            else:
+                monkeypatch.setenv("TREEQP_AMD_NO_FWD_CHAIN", "1")
+            r, sol, _ = _solve_flat_tq(gpu, f.as_dict(), f.lambda0, "generic", **f.opts)
+            assert (r["status"], r["iter"], r["ls_total"]) == (ref["status"], ref["iter"], ref["ls_total"]), (f.name, chain, r)
+            assert_solution_close(sol, ref, TOL)
+            out.append((r, sol))
+        monkeypatch.delenv("TREEQP_AMD_NO_FWD_CHAIN", raising=False)
+        for k in ("x", "u", "lam", "mu_x", "mu_u", "dlam"):
+            assert np.array_equal(out[0][1][k], out[1][1][k]), (f.name, k)
+    deep = P.pruned_chain_qp(Nh=19, seed=3)                                        # 19 stages: paths of 18 blocks
+    ref = orc.solve(deep.as_dict(), orc.default_opts(**deep.opts), lambda0=deep.lambda0)
+    r, sol, _ = _solve_flat_tq(gpu, deep.as_dict(), deep.lambda0, "generic", **deep.opts)
+    assert (r["status"], r["iter"], r["ls_total"]) == (ref["status"], ref["iter"], ref["ls_total"])
+    assert_solution_close(sol, ref, TOL)
+
+
 def test_three_launch_family_verdict_through_the_result_block(gpu, orc, monkeypatch):
     """The last launch of what the host enqueues before it looks posts the control block to pinned host memory (w3_mirror) and the
     host polls for that launch's tag -- no device-to-host copy, no stream synchronisation per read, no HIP event pair per solve.

@@ -1054,6 +1054,7 @@ struct tqgpu_solver {
     size_t lds_hf_w = 0, lds_sgp = 0;
     int sgp_accs = 0;
     bool w3_sgp = false;                /* k_sgp (a workgroup per parent) instead of k_sg (a wave per node) */
+    int *d_anc = nullptr;               /* k_fwd3c: the path to the root of every block (tdunes_wide3.hpp); nullptr: the tree does not qualify */
     bool w3_mirror = false;             /* this solve: the launches of k_sg / k_sgp post the control block to h_res (w3_mirror in tdunes_wide3.hpp) */
     bool w3_tail_sg = false;            /* the last launch enqueued is one of them: its tag (w3_wait) is what the host polls for */
     unsigned w3_wait = 0;
@@ -1844,7 +1845,9 @@ void launch_generic_iteration(tqgpu_solver *s, const Opts &O, int h, int &launch
         if (T.Np > 1) {
             s->fw_epoch++;
             if (s->fw_epoch == 0) s->fw_epoch = 1;
-            hipLaunchKernelGGL(k_fwd3, dim3((T.Np - 1 + SG_WAVES - 1) / SG_WAVES), dim3(SG_WAVES * WAVE), 0, st, T, D, next_w3(s), s->fw_words, s->fw_epoch, h); launches++;
+            if (s->d_anc) hipLaunchKernelGGL(k_fwd3c, dim3((T.Np - 1 + SG_WAVES - 1) / SG_WAVES), dim3(SG_WAVES * WAVE), 0, st, T, D, next_w3(s), s->d_anc, h);
+            else hipLaunchKernelGGL(k_fwd3, dim3((T.Np - 1 + SG_WAVES - 1) / SG_WAVES), dim3(SG_WAVES * WAVE), 0, st, T, D, next_w3(s), s->fw_words, s->fw_epoch, h);
+            launches++;
         } else { hipLaunchKernelGGL(k_ls_begin, dim3(1), dim3(256), 0, st, T, D, h); launches++; }
         const int kpred = h < (int)s->ls_pred.size() ? std::min(s->ls_pred[(size_t)h], O.lsMaxIter) : 1;
         s->w3_post_next = last && kpred < 2;
@@ -2125,6 +2128,34 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
             for (int k = 0; k < s->Np; k++) s->sgp_accs = std::max(s->sgp_accs, std::min(s->nk[k], 8) * (s->nx[k] + s->nu[k]));      /* the children's terms in LDS: up to 8 children (more: taken by wave 0 on its own) */
             for (int k = 0; k < s->Np; k++) s->lds_sgp = std::max(s->lds_sgp, wide3_lds_sgp(s->bdim[k], s->nx[k] + s->nu[k], s->sgp_accs));
             s->w3_sgp = fits && s->lds_sgp <= 64 * 1024 && !getenv("TREEQP_AMD_NO_SGP");
+            /* forward sweep without hand-overs (k_fwd3c): small nodes, short paths, blocks whose region of CholW has room for the copy of z0
+             * beside the diagnostic stamps */
+            {
+                bool okc = s->Np > 1 && !getenv("TREEQP_AMD_NO_FWD_CHAIN");
+                for (int k = 0; k < Nn && okc; k++) okc = s->nx[k] <= 8;
+                for (int k = 0; k < s->Np && okc; k++) okc = s->bdim[k] >= 3 && s->bdim[k] <= 64;
+                std::vector<int> anc;
+                if (okc) {
+                    anc.assign((size_t)FWDC_INTS * s->Np, 0);
+                    for (int ii = 1; ii < s->Np && okc; ii++) {
+                        std::vector<int> path;                      /* ii, dad(ii), .., the root's child */
+                        for (int n = ii; n != 0; n = s->dad[n]) path.push_back(n);
+                        const int L = (int)path.size();
+                        if (L > 16) { okc = false; break; }
+                        int *a = &anc[(size_t)FWDC_INTS * ii];
+                        a[0] = L;
+                        for (int k = 0; k < L; k++) {
+                            const int node = path[(size_t)(L - 1 - k)], prev = s->dad[node], dp_ = s->bdim[prev];
+                            a[1 + 4 * k + 0] = s->woff[prev] + dp_ * dp_ - dp_ + s->pos[node];
+                            a[1 + 4 * k + 1] = s->utoff[prev] + s->pos[node];
+                            a[1 + 4 * k + 2] = dp_;
+                            a[1 + 4 * k + 3] = (prev == 0 ? 0 : s->nx[prev]) | (s->nx[node] << 8);
+                        }
+                    }
+                }
+                if (okc && (hipMalloc(&s->d_anc, anc.size() * sizeof(int)) != hipSuccess || hipMemcpy(s->d_anc, anc.data(), anc.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess))
+                    return cleanup_fail(fail(TQGPU_ENOMEM, "hipMalloc failed for the path table of the forward sweep"));
+            }
             s->w3_ok = true;
         }
     }
@@ -2218,6 +2249,7 @@ extern "C" void tqgpu_destroy(tqgpu_solver *s) {
     if (s->fuse_cnt) (void)hipFree(s->fuse_cnt);
     if (s->fw_words) (void)hipFree(s->fw_words);
     if (s->sch_words) (void)hipFree(s->sch_words);
+    if (s->d_anc) (void)hipFree(s->d_anc);
     if (s->d_gitems) (void)hipFree(s->d_gitems);
     if (s->h_gitems) (void)hipHostFree(s->h_gitems);
     if (s->batch_ev) (void)hipEventDestroy(s->batch_ev);

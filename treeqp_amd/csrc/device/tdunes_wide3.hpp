@@ -1037,7 +1037,11 @@ __global__ void __launch_bounds__(WT, TQ_W3_WPS) k_hf_w(Tree T, Data D, Opts O, 
                 const int j = 16 * p + g + 4 * q;
                 Tm[dp + 16 * a + r16 + j * ld] = out[q];
                 if (j < d) {
-                    if (c16 == 0) { D.dlam[bo + j] = out[q]; pd = fma(p == 0 ? resv[0][q] : p == 1 ? resv[1][q] : p == 2 ? resv[2][q] : resv[3][q], out[q], pd); }
+                    if (c16 == 0) {
+                        D.dlam[bo + j] = out[q];
+                        D.CholW[e[8] + d * d - d + j] = out[q];          /* a copy that no forward sweep overwrites (k_fwd3c reads its ancestors' z0) */
+                        pd = fma(p == 0 ? resv[0][q] : p == 1 ? resv[1][q] : p == 2 ? resv[2][q] : resv[3][q], out[q], pd);
+                    }
                     else if (c16 <= nxi) Mg[(size_t)(c16 - 1) * d + j] = out[q];
                 }
             }
@@ -1110,6 +1114,104 @@ __global__ void __launch_bounds__(SG_WAVES * WAVE) k_fwd3(Tree T, Data D, W3 Wd,
             st_tag(fw + (size_t)(bo + lane) * 2, mine, ftag);                 /* first: my children wait for it */
             D.dlam[bo + lane] = mine; pd = rv * mine;
         }
+        pd = wave_sum(pd);
+        if (lane == 0) D.part_dot[ii] = pd;
+    }
+    if (lane == 0) part[wave] = pd;
+    __syncthreads();
+    if (wave != 0) return;
+    if (lane == 0) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < SG_WAVES; w++) s += part[w];
+        st_tag(Wd.red + ((size_t)2 * blockIdx.x + 0) * 2, s, Wd.tag);
+    }
+    Fuse F; F.red = nullptr; F.cnt = Wd.cnt; F.tag = Wd.tag; F.on = 1;
+    if (!fuse_last(F, (int)gridDim.x, lane)) return;
+    const double s = w3_reduce<false>(Wd.red, 0, (int)gridDim.x, Wd.tag, lane) + D.part_dot[0];      /* + the root's, from k_hf_w */
+    if (lane == 0) {
+        const double dotp = -s;                                     /* :819 */
+        c->dot = dotp;
+        if (dotp > 1e-10 || !((dotp > 1e-10) || (dotp < 1e-10))) { c->done = 1; c->status = 2; }      /* :951, NaN included */
+        else { c->tau = 1.0; c->tauPrev = 0.0; c->ls_iter = 1; c->ls_pending = 1; }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* k_fwd3c: the forward sweep WITHOUT hand-overs, for trees of small nodes (nx <= 8 everywhere, at most 16 blocks on a path from the   */
+/* root).  A block's step is z0 - M' (its node's slice of its dad's step), and that slice is eight numbers that depend on the path to   */
+/* the root only: every wave recomputes the slices of its ancestors -- a chain of at most 16 eight-term sums by lane broadcasts, ~30     */
+/* instructions each -- instead of waiting for them level by level (k_fwd3: ten levels of a pruned tree = ten hand-overs, 13 us).       */
+/* Lane group g (eight lanes) of the wave holds path entry g (second round: 8 + g): the eight rows of M of that ancestor restricted to   */
+/* the columns of the path's node, and z0 of those columns (from the copies k_hf_w leaves in CholW: dlam itself is being overwritten   */
+/* by the ancestors' own waves).  Same sums in the same order as k_fwd3 (even / odd accumulators): bit-identical steps.                 */
+/* anc: per block 1 + 16 x 4 ints: path length L, then {z0 offset, M offset, d of that ancestor, nx of the ancestor's node (0: the root  */
+/* block, whose z0 is the step) | nx of the path's node << 8} from the root's block down to the block's dad.  Same tail as k_fwd3.      */
+/* ------------------------------------------------------------------------------------------ */
+#define FWDC_INTS 65
+__global__ void __launch_bounds__(SG_WAVES * WAVE) k_fwd3c(Tree T, Data D, W3 Wd, const int *anc, int h) {
+    __shared__ double part[SG_WAVES];
+    Ctrl *c = D.ctrl;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ii = 1 + (int)blockIdx.x * SG_WAVES + wave;
+    const bool have = ii < T.Np;
+    const int iic = have ? ii : 1;
+    int e[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) e[i] = T.desc[(size_t)DESC_INTS * iic + i];
+    const int *A = anc + (size_t)FWDC_INTS * iic;
+    const int L = A[0];
+    const int grp = lane >> 3, j8 = lane & 7;
+    int ent[2][4];
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) ent[r][q] = A[1 + 4 * (8 * r + grp) + q];          /* (entries beyond L are zero) */
+    if (!phase_main(c, h)) return;
+    double pd = 0.0;
+    if (have) {
+        const int d = e[0], nxi = e[1], bo = e[7];
+        const int lc = lane < d ? lane : 0;
+        const double *Mg = D.CholUt + e[9];
+        /* everything requested together: the path's rows of M and z0 (two rounds of eight entries), the block's own */
+        double m[2][8], z[2], mo[8];
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const bool on = 8 * r + grp < L;
+            const int nxa = ent[r][3] & 255, nxk = ent[r][3] >> 8, da = ent[r][2];
+            const bool act = on && j8 < nxk;
+            z[r] = D.CholW[act ? ent[r][0] + j8 : 0];
+#pragma unroll
+            for (int i = 0; i < 8; i++) m[r][i] = D.CholUt[(act && i < nxa) ? ent[r][1] + i * da + j8 : 0];
+            if (!act) z[r] = 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) if (!(act && i < nxa)) m[r][i] = 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) mo[i] = Mg[(size_t)(i < nxi ? i : 0) * d + lc];
+        const double z0 = D.CholW[e[8] + d * d - d + lc], rv = D.res[bo + lc];
+        LOADS_DONE();
+        double val = 0.0;
+        for (int k = 0; k < L; k++) {
+            const int r = k >> 3, g = k & 7, gp = 8 * ((k - 1) & 7);
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) {
+                a0 = fma(r ? m[1][i] : m[0][i], rdlane(val, gp + i), a0);
+                a1 = fma(r ? m[1][i + 1] : m[0][i + 1], rdlane(val, gp + i + 1), a1);
+            }
+            const double nv = (r ? z[1] : z[0]) - (a0 + a1);
+            val = grp == g ? nv : val;
+        }
+        const int gl = 8 * ((L - 1) & 7);
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            a0 = fma(i < nxi ? mo[i] : 0.0, rdlane(val, gl + i), a0);
+            a1 = fma(i + 1 < nxi ? mo[i + 1] : 0.0, rdlane(val, gl + i + 1), a1);
+        }
+        const double mine = z0 - (a0 + a1);
+        if (lane < d) { D.dlam[bo + lane] = mine; pd = rv * mine; }
         pd = wave_sum(pd);
         if (lane == 0) D.part_dot[ii] = pd;
     }
