@@ -326,26 +326,32 @@ def test_three_launch_family_c4_launch_count(gpu, orc):
 
 def test_three_launch_family_forward_sweep_without_handovers(gpu, orc, monkeypatch):
     """k_fwd3c (trees of small nodes: every wave recomputes its ancestors' slices of the step instead of waiting for them level by
-    level) against k_fwd3 (TREEQP_AMD_NO_FWD_CHAIN=1): the same sums in the same order, so verdicts, counts and solutions are
-    identical bit for bit.  Paths of up to 10 blocks (two rounds of path entries), blocks of 8 / 16 / 24 rows, nodes of 1 .. 8
+    level) against k_fwd3 (TREEQP_AMD_NO_FWD_CHAIN=1), and the same computation inside the launch of the first line-search trial
+    (k_sgp mode 2; TREEQP_AMD_NO_FWD_MERGE=1 keeps it a launch of its own): the same sums in the same order everywhere -- also the
+    reduction of res' dlam -- so verdicts, counts and solutions are identical bit for bit.  Paths of up to 10 blocks (two rounds of path entries), blocks of 8 / 16 / 24 rows, nodes of 1 .. 8
     states; a tree whose paths are longer than 16 blocks keeps k_fwd3 and still agrees with the oracle."""
     cases = [P.pruned_chain_qp(), P.pruned_chain_qp(Nh=6, seed=5), P.random_shape_qp(11, depth=5, max_kids=3, nx_range=(1, 8), nu_range=(1, 3)),
              P.random_shape_qp(12, depth=4, max_kids=2, nx_range=(3, 8), nu_range=(2, 4), ubound=0.2)]
     for f in cases:
         ref = orc.solve(f.as_dict(), orc.default_opts(**f.opts), lambda0=f.lambda0)
         out = []
-        for chain in (True, False):
-            if chain:
-                monkeypatch.delenv("TREEQP_AMD_NO_FWD_CHAIN", raising=False)
-            else:
-                monkeypatch.setenv("TREEQP_AMD_NO_FWD_CHAIN", "1")
+        # the forward sweep inside the first trial's launch (k_sgp mode 2: two launches per iteration), as a launch of its own without
+        # hand-overs (k_fwd3c), with hand-overs (k_fwd3)
+        for env in (None, "TREEQP_AMD_NO_FWD_MERGE", "TREEQP_AMD_NO_FWD_CHAIN"):
+            monkeypatch.delenv("TREEQP_AMD_NO_FWD_MERGE", raising=False)
+            monkeypatch.delenv("TREEQP_AMD_NO_FWD_CHAIN", raising=False)
+            if env:
+                monkeypatch.setenv(env, "1")
             r, sol, _ = _solve_flat_tq(gpu, f.as_dict(), f.lambda0, "generic", **f.opts)
-            assert (r["status"], r["iter"], r["ls_total"]) == (ref["status"], ref["iter"], ref["ls_total"]), (f.name, chain, r)
+            assert (r["status"], r["iter"], r["ls_total"]) == (ref["status"], ref["iter"], ref["ls_total"]), (f.name, env, r)
             assert_solution_close(sol, ref, TOL)
             out.append((r, sol))
         monkeypatch.delenv("TREEQP_AMD_NO_FWD_CHAIN", raising=False)
-        for k in ("x", "u", "lam", "mu_x", "mu_u", "dlam"):
-            assert np.array_equal(out[0][1][k], out[1][1][k]), (f.name, k)
+        for o in out[1:]:
+            for k in ("x", "u", "lam", "mu_x", "mu_u", "dlam"):
+                assert np.array_equal(out[0][1][k], o[1][k]), (f.name, k)
+        if out[1][0]["n_launches"] == out[2][0]["n_launches"] and len(f.nk) > 100:      # (the pruned trees: on the three-launch family)
+            assert out[0][0]["n_launches"] < out[1][0]["n_launches"]
     deep = P.pruned_chain_qp(Nh=19, seed=3)                                        # 19 stages: paths of 18 blocks
     ref = orc.solve(deep.as_dict(), orc.default_opts(**deep.opts), lambda0=deep.lambda0)
     r, sol, _ = _solve_flat_tq(gpu, deep.as_dict(), deep.lambda0, "generic", **deep.opts)

@@ -1054,6 +1054,8 @@ struct tqgpu_solver {
     size_t lds_hf_w = 0, lds_sgp = 0;
     int sgp_accs = 0;
     bool w3_sgp = false;                /* k_sgp (a workgroup per parent) instead of k_sg (a wave per node) */
+    unsigned long long *d_pdw = nullptr; /* k_sgp mode 2: the blocks' parts of res' dlam as tagged words */
+    bool w3_merge = false;              /* forward sweep and first trial in one launch (k_sgp mode 2) */
     int *d_anc = nullptr;               /* k_fwd3c: the path to the root of every block (tdunes_wide3.hpp); nullptr: the tree does not qualify */
     bool w3_mirror = false;             /* this solve: the launches of k_sg / k_sgp post the control block to h_res (w3_mirror in tdunes_wide3.hpp) */
     bool w3_tail_sg = false;            /* the last launch enqueued is one of them: its tag (w3_wait) is what the host polls for */
@@ -1585,7 +1587,11 @@ static void launch_sg(tqgpu_solver *s, const Opts &O, int mode, int h, int t, bo
      * where the host is going to look) */
     if (s->w3_mirror && s->w3_post_next) { w.hm = s->h_res; s->w3_wait = w.tag; s->w3_tail_sg = true; }
     s->w3_post_next = false;
-    if (s->w3_sgp) { hipLaunchKernelGGL(k_sgp, dim3(s->T.Np), dim3(WT), s->lds_sgp, s->stream, s->T, s->D, O, w, mode, h, t, s->sgp_accs, fresh ? s->d_lam_init : nullptr); return; }
+    if (s->w3_sgp) {
+        if (mode == 2) { SgpFwdYes fa; fa.anc = s->d_anc; fa.pdw = s->d_pdw; hipLaunchKernelGGL(k_sgp_t<true>, dim3(s->T.Np), dim3(WT), s->lds_sgp, s->stream, s->T, s->D, O, w, mode, h, t, s->sgp_accs, (const double *)nullptr, fa); }
+        else hipLaunchKernelGGL(k_sgp_t<false>, dim3(s->T.Np), dim3(WT), s->lds_sgp, s->stream, s->T, s->D, O, w, mode, h, t, s->sgp_accs, fresh ? (const double *)s->d_lam_init : (const double *)nullptr, SgpFwdNo());
+        return;
+    }
     const int grid = (s->T.Nn + SG_WAVES - 1) / SG_WAVES;
     hipLaunchKernelGGL(k_sg, dim3(grid), dim3(SG_WAVES * WAVE), SG_WAVES * ((s->lds_stage + 7) / 8) * 8, s->stream, s->T, s->D, O, w, mode, h, t);
 }
@@ -1842,6 +1848,14 @@ void launch_generic_iteration(tqgpu_solver *s, const Opts &O, int h, int &launch
         if (s->bw_epoch == 0) s->bw_epoch = 1;
         s->w3_tail_sg = false;
         hipLaunchKernelGGL(k_hf_w, dim3(T.Np), dim3(WT), s->lds_hf_w, st, T, D, O, s->sch_words, s->sch_rs, s->bw_epoch, h); launches++;
+        const int kpred0 = h < (int)s->ls_pred.size() ? std::min(s->ls_pred[(size_t)h], O.lsMaxIter) : 1;
+        if (T.Np > 1 && s->w3_merge) {
+            /* forward sweep + first trial: one launch */
+            s->w3_post_next = last && kpred0 < 2;
+            launch_sg(s, O, 2, h, 1); launches++;
+            for (int tt = 2; tt <= kpred0; tt++) { s->w3_post_next = last && tt == kpred0; launch_sg(s, O, 1, h, tt); launches++; }
+            return;
+        }
         if (T.Np > 1) {
             s->fw_epoch++;
             if (s->fw_epoch == 0) s->fw_epoch = 1;
@@ -2155,6 +2169,12 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
                 }
                 if (okc && (hipMalloc(&s->d_anc, anc.size() * sizeof(int)) != hipSuccess || hipMemcpy(s->d_anc, anc.data(), anc.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess))
                     return cleanup_fail(fail(TQGPU_ENOMEM, "hipMalloc failed for the path table of the forward sweep"));
+                if (okc && s->w3_sgp && !getenv("TREEQP_AMD_NO_FWD_MERGE")) {
+                    const size_t pb = sizeof(unsigned long long) * 2 * (size_t)s->Np;
+                    if (hipMalloc(&s->d_pdw, pb) != hipSuccess || hipMemset(s->d_pdw, 0, pb) != hipSuccess)
+                        return cleanup_fail(fail(TQGPU_ENOMEM, "hipMalloc failed for the forward sweep's partial sums"));
+                    s->w3_merge = true;
+                }
             }
             s->w3_ok = true;
         }
@@ -2250,6 +2270,7 @@ extern "C" void tqgpu_destroy(tqgpu_solver *s) {
     if (s->fw_words) (void)hipFree(s->fw_words);
     if (s->sch_words) (void)hipFree(s->sch_words);
     if (s->d_anc) (void)hipFree(s->d_anc);
+    if (s->d_pdw) (void)hipFree(s->d_pdw);
     if (s->d_gitems) (void)hipFree(s->d_gitems);
     if (s->h_gitems) (void)hipHostFree(s->h_gitems);
     if (s->batch_ev) (void)hipEventDestroy(s->batch_ev);

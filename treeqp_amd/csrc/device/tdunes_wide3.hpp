@@ -263,6 +263,93 @@ __device__ __forceinline__ double sgp_finish(const Data &D, const SgNode &n, dou
     return f;
 }
 
+
+/* The step of block `ii` without waiting for any other block (see k_fwd3c below): the slices of the ancestors' steps along the path
+ * from the root, recomputed by this wave.  A: the block's row of the path table.  Returns the block's step (lanes < d); `val` holds the
+ * slices (lane group g: path entry g, second round 8 + g), `gl` the first lane of the LAST slice = the step of the block's own node. */
+#define FWDC_INTS 65
+__device__ __forceinline__ double fwdc_block(const Data &D, const int *A, int d, int nxi, int woff, int utoff, int lane, double &val, int &gl) {
+    const int L = A[0];
+    const int grp = lane >> 3, j8 = lane & 7;
+    int ent[2][4];
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) ent[r][q] = A[1 + 4 * (8 * r + grp) + q];          /* (entries beyond L are zero) */
+    const int lc = lane < d ? lane : 0;
+    const double *Mg = D.CholUt + utoff;
+    /* everything requested together: the path's rows of M and z0 (two rounds of eight entries), the block's own */
+    double m[2][8], z[2], mo[8];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const bool on = 8 * r + grp < L;
+        const int nxa = ent[r][3] & 255, nxk = ent[r][3] >> 8, da = ent[r][2];
+        const bool act = on && j8 < nxk;
+        z[r] = D.CholW[act ? ent[r][0] + j8 : 0];
+#pragma unroll
+        for (int i = 0; i < 8; i++) m[r][i] = D.CholUt[(act && i < nxa) ? ent[r][1] + i * da + j8 : 0];
+        if (!act) z[r] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) if (!(act && i < nxa)) m[r][i] = 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) mo[i] = Mg[(size_t)(i < nxi ? i : 0) * d + lc];
+    const double z0 = D.CholW[woff + d * d - d + lc];
+    LOADS_DONE();
+    val = 0.0;
+    for (int k = 0; k < L; k++) {
+        const int r = k >> 3, g = k & 7, gp = 8 * ((k - 1) & 7);
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            a0 = fma(r ? m[1][i] : m[0][i], rdlane(val, gp + i), a0);
+            a1 = fma(r ? m[1][i + 1] : m[0][i + 1], rdlane(val, gp + i + 1), a1);
+        }
+        const double nv = (r ? z[1] : z[0]) - (a0 + a1);
+        val = grp == g ? nv : val;
+    }
+    gl = 8 * ((L - 1) & 7);
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        a0 = fma(i < nxi ? mo[i] : 0.0, rdlane(val, gl + i), a0);
+        a1 = fma(i + 1 < nxi ? mo[i + 1] : 0.0, rdlane(val, gl + i + 1), a1);
+    }
+    return z0 - (a0 + a1);
+}
+/* res' dlam over the blocks as k_fwd3c takes it (groups of SG_WAVES consecutive blocks summed in order, the groups' sums dealt over the
+ * lanes as in w3_reduce): the same number to the last bit whichever kernel ran the forward sweep.  pdw: tagged [block] */
+__device__ double fwdc_reduce_dot(const u64 *pdw, int Np, unsigned tag, int lane) {
+    const int n = (Np - 1 + SG_WAVES - 1) / SG_WAVES;
+    double acc = 0.0;
+    for (int b0 = 0; b0 < n; b0 += 8 * WAVE) {
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            const int b = b0 + m * WAVE + lane;
+            if (b < n) {
+                double sb = 0.0;
+                for (int w = 0; w < SG_WAVES; w++) {
+                    const int ii = 1 + b * SG_WAVES + w;
+                    double v = 0.0;
+                    if (ii < Np) {
+                        const unsigned long long t0 = wall_clock64();
+                        for (;;) {
+                            bool ok = true;
+                            v = ld_tag(pdw + (size_t)ii * 2, tag, ok);
+                            if (ok) break;
+                            if (wall_clock64() - t0 > 20000000ull) { v = __builtin_nan(""); break; }      /* cannot happen: posted before the workgroup counted itself off */
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                    }
+                    sb += v;
+                }
+                acc = acc + sb;
+            }
+        }
+    }
+    return wave_sum(acc);
+}
+
 #ifdef TQ_WIDE_STAMPS
 #define SGSTAMP(k_) do { if (tid == 0) reinterpret_cast<unsigned long long *>(D.W + e[8])[k_] = wall_clock64(); } while (0)
 #else
@@ -271,7 +358,24 @@ __device__ __forceinline__ double sgp_finish(const Data &D, const SgNode &n, dou
 /* mode 0 with lam_src != nullptr: the first sweep of a solve reads the starting duals from lam_src, copies them into the current buffer
  * (every node's own slice is written by the workgroup that stages the node) and its tail writes the WHOLE control block: no copy and
  * no memset in front of the launch */
-__global__ void __launch_bounds__(WT) k_sgp(Tree T, Data D, Opts O, W3 Wd, int mode, int h, int t, int accs_cap, const double *lam_src) {
+/* mode 2 (trees with a path table, see k_fwd3c): the FORWARD SWEEP and the first trial of the line search in one launch.  Wave 0 of
+ * workgroup p first takes the step of block p from its ancestors' data (fwdc_block: no other workgroup is waited for), writes it to
+ * dlam and posts the block's part of res' dlam; the trial point is lambda + dlam (tau = 1).  The launch's tail then does what k_fwd3c's
+ * tail and this kernel's mode-1 tail do one after the other: res' dlam (summed in k_fwd3c's order: the same number), the direction test
+ * (:944-954 -- as on the persistent paths the first trial has been evaluated speculatively by then; a direction that is not one of
+ * descent ends the solve before anything of it is used), the start of the line search, the Armijo test, the next termination test. */
+struct SgpFwdNo { };
+struct SgpFwdYes { const int *anc; u64 *pdw; };
+template <bool FWD> struct SgpFwd { using type = SgpFwdNo; };
+template <> struct SgpFwd<true> { using type = SgpFwdYes; };
+__device__ __forceinline__ const int *sgp_anc(const SgpFwdNo &) { return nullptr; }
+__device__ __forceinline__ const int *sgp_anc(const SgpFwdYes &a) { return a.anc; }
+__device__ __forceinline__ u64 *sgp_pdw(const SgpFwdNo &) { return nullptr; }
+__device__ __forceinline__ u64 *sgp_pdw(const SgpFwdYes &a) { return a.pdw; }
+template <bool FWD>      /* FWD: the instantiation that knows mode 2 (modes 0 and 1 keep the registers, the arguments and the code they had: 91 against 101 registers is 10 us per C4 solve) */
+__global__ void __launch_bounds__(WT) k_sgp_t(Tree T, Data D, Opts O, W3 Wd, int mode, int h, int t, int accs_cap, const double *lam_src, typename SgpFwd<FWD>::type fa) {
+    const int *anc = sgp_anc(fa);
+    u64 *pdw = sgp_pdw(fa);
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double part[2][WW];
     Ctrl *c = D.ctrl;
@@ -281,13 +385,14 @@ __global__ void __launch_bounds__(WT) k_sgp(Tree T, Data D, Opts O, W3 Wd, int m
 #pragma unroll
     for (int i = 0; i < 28; i++) e[i] = T.desc[(size_t)DESC_INTS * p + i];
     const bool fresh = mode == 0 && lam_src != nullptr;
-    const int cur = fresh ? 0 : c->cur, ls_iter = c->ls_iter;
-    const double step = c->tau - c->tauPrev;
+    const bool fwd = FWD && mode == 2, trial = mode >= 1;
+    const int cur = fresh ? 0 : c->cur, ls_iter = fwd ? 1 : c->ls_iter;
+    const double step = fwd ? 1.0 : c->tau - c->tauPrev;
     const unsigned long long t_begin = wall_clock64();
-    if (mode == 1 && !phase_trial(c, h, t)) { if (blockIdx.x == 0 && tid == 0) w3_mirror(Wd, c, false, 0ull); return; }
+    if ((mode == 1 && !phase_trial(c, h, t)) || (fwd && !phase_main(c, h))) { if (blockIdx.x == 0 && tid == 0) w3_mirror(Wd, c, false, 0ull); return; }
     const int d = e[0], nxp = e[1], nup = e[2], nkp = e[3], k0 = e[4], nz = nxp + nup, xop = e[5], uop = e[6], ko = e[7];
     SGSTAMP(0);
-    const bool save_s = mode == 1 && ls_iter == 1;      /* first trial of a line search: xUnc / uUnc still hold phase S of this iteration */
+    const bool save_s = trial && ls_iter == 1;          /* first trial of a line search: xUnc / uUnc still hold phase S of this iteration */
     const double *lamc = fresh ? lam_src : (cur ? D.lam1 : D.lam0);
     double *lamn = cur ? D.lam0 : D.lam1;
     const int ldc = d | 1;
@@ -296,7 +401,8 @@ __global__ void __launch_bounds__(WT) k_sgp(Tree T, Data D, Opts O, W3 Wd, int m
     lds_ptr bl = lkl + 64;                              /* b of the children */
     lds_ptr xpl = bl + 64;                              /* [x_p | u_p] */
     lds_ptr xkl = xpl + 64;                             /* x of the leaf children */
-    lds_ptr accs = xkl + 64;                            /* [child][entry of node p]: that child's term of C' lambda */
+    lds_ptr dkl = xkl + 64;                             /* mode 2: the step of block p */
+    lds_ptr accs = dkl + 64;                            /* [child][entry of node p]: that child's term of C' lambda */
     const bool kids_are_leaves = k0 >= T.Np;
 
     /* ---- everything a node needs from global memory, requested together ---- */
@@ -307,6 +413,24 @@ __global__ void __launch_bounds__(WT) k_sgp(Tree T, Data D, Opts O, W3 Wd, int m
         sgp_load(D, lamc, mode, save_s, p > 0, nxp, nup, xop, uop, lane, nd);
         const int tt = lane < d ? lane : 0;
         lamk = lamc[ko + tt]; dlk = D.dlam[ko + tt]; bk = D.b[ko + tt];
+        if (fwd) {
+            /* the step of block p (the root block's is what k_hf_w left in dlam) and of node p's own duals (the last slice of the path) */
+            const double rv = D.res[ko + tt];
+            if (p > 0) {
+                double val;
+                int gl;
+                dlk = fwdc_block(D, anc + (size_t)FWDC_INTS * p, d, nxp, e[8], e[9], lane, val, gl);
+                double own = 0.0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) { const double tv = rdlane(val, gl + i); own = lane == i ? tv : own; }
+                nd.dl = own;
+                if (lane < d) D.dlam[ko + lane] = dlk;
+                double pd = lane < d ? rv * dlk : 0.0;
+                pd = wave_sum(pd);
+                if (lane == 0) { D.part_dot[p] = pd; st_tag(pdw + (size_t)p * 2, pd, Wd.tag); }
+            }
+            if (lane < d) dkl[lane] = dlk;
+        }
     } else if (kids_are_leaves && wave - 1 < nkp) {
         ccl = wave - 1;
         const int kid = k0 + ccl;
@@ -344,7 +468,7 @@ __global__ void __launch_bounds__(WT) k_sgp(Tree T, Data D, Opts O, W3 Wd, int m
         }
         rowoff += nxc;
     }
-    if (wave == 0 && lane < d) { lkl[lane] = mode == 1 ? fma(step, dlk, lamk) : lamk; bl[lane] = bk; }
+    if (wave == 0 && lane < d) { lkl[lane] = trial ? fma(step, dlk, lamk) : lamk; bl[lane] = bk; }
     __syncthreads();
     SGSTAMP(1);
     /* ---- the children's terms of C' lambda: thread (child, entry), the products of a child in ascending row order ---- */
@@ -366,7 +490,7 @@ __global__ void __launch_bounds__(WT) k_sgp(Tree T, Data D, Opts O, W3 Wd, int m
         /* node p */
         const bool isx = lane < nxp, in = lane < nz;
         double lown = 0.0;
-        if (p > 0 && isx) { lown = mode == 1 ? fma(step, nd.dl, nd.lam) : nd.lam; if (mode == 1) lamn[xop + lane] = lown; else if (fresh) D.lam0[xop + lane] = lown; }
+        if (p > 0 && isx) { lown = trial ? fma(step, nd.dl, nd.lam) : nd.lam; if (trial) lamn[xop + lane] = lown; else if (fresh) D.lam0[xop + lane] = lown; }
         double v = isx ? fma(-1.0, nd.qv, lown) : -1.0 * nd.qv;
         if (in) {
             if (nkp * nz <= accs_cap) { for (int cc = 0; cc < nkp; cc++) v = fma(-1.0, accs[cc * nz + lane], v); }
@@ -400,7 +524,8 @@ __global__ void __launch_bounds__(WT) k_sgp(Tree T, Data D, Opts O, W3 Wd, int m
             }
             const bool isx = lane < nxl;
             double lown = 0.0;
-            if (isx) { lown = mode == 1 ? fma(step, nd.dl, nd.lam) : nd.lam; if (mode == 1) lamn[xol + lane] = lown; else if (fresh) D.lam0[xol + lane] = lown; }
+            if (fwd) nd.dl = dkl[rowl + (isx ? lane : 0)];                  /* (written by wave 0 before the barrier above) */
+            if (isx) { lown = trial ? fma(step, nd.dl, nd.lam) : nd.lam; if (trial) lamn[xol + lane] = lown; else if (fresh) D.lam0[xol + lane] = lown; }
             const double v = isx ? fma(-1.0, nd.qv, lown) : -1.0 * nd.qv;
             double xv;
             const double f = sgp_finish(D, nd, v, 0.0, save_s, nxl, nul, xol, uol, lane, xv);
@@ -459,11 +584,23 @@ __global__ void __launch_bounds__(WT) k_sgp(Tree T, Data D, Opts O, W3 Wd, int m
     if (!fuse_last(F, (int)gridDim.x, lane)) return;
     double f, err;
     w3_reduce2(Wd.red, (int)gridDim.x, Wd.tag, lane, mx, f, err);
+    double dots = 0.0;
+    if (fwd) dots = fwdc_reduce_dot(pdw, T.Np, Wd.tag, lane) + D.part_dot[0];      /* + the root's, from k_hf_w */
     if (lane == 0) {
         bool test = true;
         if (mode == 0) {
             if (fresh) { Ctrl z{}; *c = z; }          /* a new solve: the control block starts from zero (k_hf_w counts regularised blocks into it) */
             c->fval0 = f; c->fval = f;
+        }
+        else if (fwd) {
+            const double dotp = -dots;                                  /* :819 */
+            c->dot = dotp;
+            if (dotp > 1e-10 || !((dotp > 1e-10) || (dotp < 1e-10))) { c->done = 1; c->status = 2; test = false; }      /* :951, NaN included */
+            else {
+                c->tau = 1.0; c->tauPrev = 0.0; c->ls_iter = 1; c->ls_pending = 1;
+                ls_decide_tail(c, D, O, f);
+                test = !c->done && !c->ls_pending;
+            }
         }
         else { ls_decide_tail(c, D, O, f); test = !c->done && !c->ls_pending; }
         if (test) {
@@ -475,7 +612,7 @@ __global__ void __launch_bounds__(WT) k_sgp(Tree T, Data D, Opts O, W3 Wd, int m
     }
 }
 /* LDS of k_sgp: C, the four 64-entry vectors, the children's terms */
-static inline size_t wide3_lds_sgp(int d, int nz, int accs) { return ((size_t)(d | 1) * nz + 4 * 64 + accs) * sizeof(double); }
+static inline size_t wide3_lds_sgp(int d, int nz, int accs) { return ((size_t)(d | 1) * nz + 5 * 64 + accs) * sizeof(double); }
 
 /* ------------------------------------------------------------------------------------------ */
 /* k_hf_w: H + backward sweep + preparation of the forward sweep, one workgroup per block       */
@@ -1148,7 +1285,6 @@ __global__ void __launch_bounds__(SG_WAVES * WAVE) k_fwd3(Tree T, Data D, W3 Wd,
 /* anc: per block 1 + 16 x 4 ints: path length L, then {z0 offset, M offset, d of that ancestor, nx of the ancestor's node (0: the root  */
 /* block, whose z0 is the step) | nx of the path's node << 8} from the root's block down to the block's dad.  Same tail as k_fwd3.      */
 /* ------------------------------------------------------------------------------------------ */
-#define FWDC_INTS 65
 __global__ void __launch_bounds__(SG_WAVES * WAVE) k_fwd3c(Tree T, Data D, W3 Wd, const int *anc, int h) {
     __shared__ double part[SG_WAVES];
     Ctrl *c = D.ctrl;
@@ -1159,58 +1295,14 @@ __global__ void __launch_bounds__(SG_WAVES * WAVE) k_fwd3c(Tree T, Data D, W3 Wd
     int e[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) e[i] = T.desc[(size_t)DESC_INTS * iic + i];
-    const int *A = anc + (size_t)FWDC_INTS * iic;
-    const int L = A[0];
-    const int grp = lane >> 3, j8 = lane & 7;
-    int ent[2][4];
-#pragma unroll
-    for (int r = 0; r < 2; r++)
-#pragma unroll
-        for (int q = 0; q < 4; q++) ent[r][q] = A[1 + 4 * (8 * r + grp) + q];          /* (entries beyond L are zero) */
     if (!phase_main(c, h)) return;
     double pd = 0.0;
     if (have) {
-        const int d = e[0], nxi = e[1], bo = e[7];
-        const int lc = lane < d ? lane : 0;
-        const double *Mg = D.CholUt + e[9];
-        /* everything requested together: the path's rows of M and z0 (two rounds of eight entries), the block's own */
-        double m[2][8], z[2], mo[8];
-#pragma unroll
-        for (int r = 0; r < 2; r++) {
-            const bool on = 8 * r + grp < L;
-            const int nxa = ent[r][3] & 255, nxk = ent[r][3] >> 8, da = ent[r][2];
-            const bool act = on && j8 < nxk;
-            z[r] = D.CholW[act ? ent[r][0] + j8 : 0];
-#pragma unroll
-            for (int i = 0; i < 8; i++) m[r][i] = D.CholUt[(act && i < nxa) ? ent[r][1] + i * da + j8 : 0];
-            if (!act) z[r] = 0.0;
-#pragma unroll
-            for (int i = 0; i < 8; i++) if (!(act && i < nxa)) m[r][i] = 0.0;
-        }
-#pragma unroll
-        for (int i = 0; i < 8; i++) mo[i] = Mg[(size_t)(i < nxi ? i : 0) * d + lc];
-        const double z0 = D.CholW[e[8] + d * d - d + lc], rv = D.res[bo + lc];
-        LOADS_DONE();
-        double val = 0.0;
-        for (int k = 0; k < L; k++) {
-            const int r = k >> 3, g = k & 7, gp = 8 * ((k - 1) & 7);
-            double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-            for (int i = 0; i < 8; i += 2) {
-                a0 = fma(r ? m[1][i] : m[0][i], rdlane(val, gp + i), a0);
-                a1 = fma(r ? m[1][i + 1] : m[0][i + 1], rdlane(val, gp + i + 1), a1);
-            }
-            const double nv = (r ? z[1] : z[0]) - (a0 + a1);
-            val = grp == g ? nv : val;
-        }
-        const int gl = 8 * ((L - 1) & 7);
-        double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-        for (int i = 0; i < 8; i += 2) {
-            a0 = fma(i < nxi ? mo[i] : 0.0, rdlane(val, gl + i), a0);
-            a1 = fma(i + 1 < nxi ? mo[i + 1] : 0.0, rdlane(val, gl + i + 1), a1);
-        }
-        const double mine = z0 - (a0 + a1);
+        const int d = e[0], bo = e[7];
+        const double rv = D.res[bo + (lane < d ? lane : 0)];
+        double val;
+        int gl;
+        const double mine = fwdc_block(D, anc + (size_t)FWDC_INTS * ii, d, e[1], e[8], e[9], lane, val, gl);
         if (lane < d) { D.dlam[bo + lane] = mine; pd = rv * mine; }
         pd = wave_sum(pd);
         if (lane == 0) D.part_dot[ii] = pd;
