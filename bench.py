@@ -212,8 +212,26 @@ def pshard_child(steps: int):
     dist.barrier()
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    # the sharded solution against a single-device solve of the same tree on this rank's device (outside the timed region): a hand-over
+    # that is not seen in time ends in a time-out, one that is seen with stale data would only show here
+    packs = [None] * world
+    dist.all_gather_object(packs, m.pshard_pack())
+    for r in range(world):
+        if r != rank:
+            m.pshard_unpack(r, packs[r])
+    sol = m.solution()
+    ref_m = capi.TqGpu(f["nk"], f["nx"], f["nu"], device=dev).upload(f, c3[0]["lambda0"])
+    ref_r = ref_m.solve()
+    ref = ref_m.solution()
+    ref_m.close()
+    diff = max(float(np.max(np.abs(sol[k] - ref[k]))) for k in ("x", "u", "lam", "mu_x", "mu_u"))
+    same = (int(res["status"]), int(res["iter"]), int(res["ls_total"])) == (int(ref_r["status"]), int(ref_r["iter"]), int(ref_r["ls_total"]))
+    ok = torch.tensor([1.0 if (same and diff < 1e-11) else 0.0, diff], dtype=torch.float64)
+    okmin = ok.clone(); dist.all_reduce(okmin, op=dist.ReduceOp.MIN)
+    okmax = ok.clone(); dist.all_reduce(okmax, op=dist.ReduceOp.MAX)
     if rank == 0:
-        print(json.dumps({"iters": iters, "seconds": float(t.item()), "status": int(res["status"])}), flush=True)
+        print(json.dumps({"iters": iters, "seconds": float(t.item()), "status": int(res["status"]),
+                          "verified": bool(okmin[0].item() == 1.0), "max_abs_diff_vs_single_device": float(okmax[1].item())}), flush=True)
     m.close()
     dist.destroy_process_group()
 
@@ -537,6 +555,12 @@ def main():
             sharded = {"workload": f"C3: {c3desc}", "value": it3 / te, "unit": "newton_iter/s", "steps": ksteps, "ms_per_step": 1e3 * te / ksteps,
                        "scaling": "strong", "status": int(r3["status"]), "newton_iter_per_solve": it3 / ksteps, "kernel_family": family,
                        "parallelism": f"one tree, subtrees partitioned over {world} ranks", "persistent_path_error": err_p}
+            if flag.item() == 0 and rank == 0 and child is not None:
+                # the child compared the collected solution with a single-device solve of the same tree (outside its timed region)
+                sharded["verified_against_single_device"] = bool(child.get("verified", False))
+                sharded["max_abs_diff_vs_single_device"] = child.get("max_abs_diff_vs_single_device")
+                if not sharded["verified_against_single_device"]:
+                    sharded["error"] = "the sharded solve's solution or counts differ from the single-device solve"
         except Exception as e:          # the replica line must not be lost to a failure of the extra leg
             sharded = {"error": str(e)}
         leg_done.set()
