@@ -55,20 +55,68 @@ def product_library() -> Path:
     return LIBDIR / "libtreeqp_amd.so"
 
 
-def build_variant(name: str, defs) -> Path:
-    """Experiment build: the device code with extra -D flags, linked with the current host objects into
-    treeqp_amd/lib_var/<name>/libtreeqp_amd.so (loaded when TREEQP_AMD_LIB points at it; never the default)."""
+# The device path is ONE source file compiled once per part, all parts in parallel (csrc/device/tdunes_parts.hpp):
+# name -> (-DTQ_PARTS mask, extra defines).  The persistent family is sliced by shape (its kernels are most of the compile time).
+PERSIST_SLICES = 4
+DEVICE_PARTS = {
+    "host": ("TQP_HOST", []),
+    "gpersist": ("TQP_GP", []),
+    "wide": ("TQP_WIDE", []),
+    "wide3": ("TQP_W3", []),
+    "tiered": ("TQP_TIER", []),
+    **{f"persist{k}": ("TQP_PERSIST", [f"-DTQ_PERSIST_NSLICES={PERSIST_SLICES}", f"-DTQ_PERSIST_SLICE={k}"]) for k in range(PERSIST_SLICES)},
+    "shard": ("TQP_SHARD", []),
+    "batch": ("TQP_BATCH", []),
+}
+JOBS = max(1, min(len(DEVICE_PARTS), (os.cpu_count() or 4)))
+
+
+def _part_cmd(part: str, obj: Path, defs=()):
+    mask, extra = DEVICE_PARTS[part]
+    src = CSRC / "device" / DEVICE_SOURCES[0]
+    return [hipcc_path(), *HIP_FLAGS, f"-DTQ_PARTS={mask}", *extra, *defs, f"-I{INCLUDE}", f"-I{CSRC / 'device'}", "-c", src, "-o", obj]
+
+
+def _compile_parts(jobs):
+    """jobs: list of (part, obj, defs); run the compilers in parallel, longest parts first"""
+    import concurrent.futures as cf
+    import time
+    order = sorted(jobs, key=lambda j: (not j[0].startswith("persist"), j[0]))
+    t0 = time.time()
+
+    def one(job):
+        part, obj, defs = job
+        cmd = _part_cmd(part, obj, defs)
+        print("[build]", " ".join(str(c) for c in cmd), flush=True)
+        t1 = time.time()
+        r = subprocess.run([str(c) for c in cmd], capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stdout + r.stderr)
+            raise RuntimeError(f"hipcc failed for part {part}")
+        if r.stderr.strip():
+            sys.stderr.write(r.stderr)
+        print(f"[build] part {part}: {time.time() - t1:.0f} s", flush=True)
+
+    with cf.ThreadPoolExecutor(max_workers=JOBS) as ex:
+        list(ex.map(one, order))
+    print(f"[build] device parts: {time.time() - t0:.0f} s wall", flush=True)
+
+
+def build_variant(name: str, defs, parts=None) -> Path:
+    """Experiment build: the listed parts of the device code (default: all) with extra -D flags, linked with the product's other
+    objects into treeqp_amd/lib_var/<name>/libtreeqp_amd.so (loaded when TREEQP_AMD_LIB points at it; never the default)."""
     build_product()
     out = ROOT / "treeqp_amd" / "lib_var" / name
     out.mkdir(parents=True, exist_ok=True)
-    hipcc = hipcc_path()
+    parts = list(DEVICE_PARTS) if not parts else parts
+    for q in parts:
+        if q not in DEVICE_PARTS:
+            raise SystemExit(f"unknown part {q}; parts: {' '.join(DEVICE_PARTS)}")
     objs = [OBJDIR / (n + ".o") for n in HOST_SOURCES]
-    for n in DEVICE_SOURCES:
-        obj = out / (n + ".o")
-        _run([hipcc, *HIP_FLAGS, *defs, f"-I{INCLUDE}", f"-I{CSRC / 'device'}", "-c", CSRC / "device" / n, "-o", obj])
-        objs.append(obj)
+    _compile_parts([(q, out / f"device_{q}.o", list(defs)) for q in parts])
+    objs += [(out if q in parts else OBJDIR) / f"device_{q}.o" for q in DEVICE_PARTS]
     lib = out / "libtreeqp_amd.so"
-    _run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", *objs, "-o", lib, "-lm"])
+    _run([hipcc_path(), "-shared", "-fPIC", "--offload-arch=gfx950", *objs, "-o", lib, "-lm"])
     return lib
 
 
@@ -84,13 +132,15 @@ def build_product(force: bool = False) -> Path:
             _run(["gcc", *HOST_CFLAGS, f"-I{INCLUDE}", "-c", src, "-o", obj])
         objs.append(obj)
     hipcc = hipcc_path()
-    for name in DEVICE_SOURCES:
-        src = CSRC / "device" / name
-        obj = OBJDIR / (name + ".o")
-        extra = list((CSRC / "device").glob("*.h")) + list((CSRC / "device").glob("*.hpp"))
-        if force or _newer(obj, [src] + headers + extra):
-            _run([hipcc, *HIP_FLAGS, f"-I{INCLUDE}", f"-I{CSRC / 'device'}", "-c", src, "-o", obj])
+    dev_src = [CSRC / "device" / n for n in DEVICE_SOURCES] + list((CSRC / "device").glob("*.h")) + list((CSRC / "device").glob("*.hpp"))
+    jobs = []
+    for part in DEVICE_PARTS:
+        obj = OBJDIR / f"device_{part}.o"
+        if force or _newer(obj, dev_src + headers):
+            jobs.append((part, obj, []))
         objs.append(obj)
+    if jobs:
+        _compile_parts(jobs)
     lib = product_library()
     if force or _newer(lib, objs):
         _run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", *objs, "-o", lib, "-lm"])
@@ -159,9 +209,15 @@ def build_all(force: bool = False):
 
 
 if __name__ == "__main__":
-    if "--variant" in sys.argv:          # python treeqp_amd/build.py --variant NAME -DFOO -DBAR=1
+    if "--variant" in sys.argv:          # python treeqp_amd/build.py --variant NAME [--parts persist0,shard] -DFOO -DBAR=1
         i = sys.argv.index("--variant")
-        print("[build] variant:", build_variant(sys.argv[i + 1], sys.argv[i + 2:]))
+        rest = sys.argv[i + 2:]
+        parts = None
+        if "--parts" in rest:
+            k = rest.index("--parts")
+            parts = rest[k + 1].split(",")
+            rest = rest[:k] + rest[k + 2:]
+        print("[build] variant:", build_variant(sys.argv[i + 1], rest, parts))
         sys.exit(0)
     out = build_all(force="--force" in sys.argv)
     print("[build] done:", *out[:2], *out[2])

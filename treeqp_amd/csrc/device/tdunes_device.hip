@@ -50,12 +50,13 @@
 #include "treeqp_amd.h"
 
 #define WAVE 64
+#include "tdunes_parts.hpp"
 
-namespace {
+namespace tqd {
 
-thread_local std::string g_err;
+int fail(int code, const std::string &msg);      /* defined in the host part */
 
-int fail(int code, const std::string &msg) { g_err = msg; return code; }
+
 
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \
@@ -219,11 +220,13 @@ __device__ __forceinline__ double wave_max(double v) { return wmax(v); }
 /* ------------------------------------------------------------------------------------------ */
 /* k_init: Qinv = 1/Qd, Rinv = 1/Rd  (stage_qp_clipping_init, clipping.c:163-170)             */
 /* ------------------------------------------------------------------------------------------ */
+#if TQ_HAS(TQP_HOST)
 __global__ void k_init(int n_x, int n_u, Data D) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_x) D.Qinv[i] = 1.0 / D.Qd[i];
     if (i < n_u) D.Rinv[i] = 1.0 / D.Rd[i];
 }
+#endif
 
 /* ------------------------------------------------------------------------------------------ */
 /* k_dense_init: one wave per node: P = H^-1 through the Cholesky factor of H (stage_qp_qpoases */
@@ -231,6 +234,7 @@ __global__ void k_init(int n_x, int n_u, Data D) {
 /* z = H^-1 h and the elimination matrix is P = H^-1).  H in LDS, column by column; then lane j  */
 /* solves L L' p_j = e_j.                                                                       */
 /* ------------------------------------------------------------------------------------------ */
+#if TQ_HAS(TQP_HOST)
 __global__ void __launch_bounds__(WAVE) k_dense_init(Tree T, Data D) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int k = blockIdx.x, lane = threadIdx.x;
@@ -270,6 +274,7 @@ __global__ void __launch_bounds__(WAVE) k_dense_init(Tree T, Data D) {
         }
     }
 }
+#endif
 
 /* acc + sum_{i < n} a[i * sa] * b[i * sb], terms added in ascending order (the reference's order), but the loads go out DOT_BATCH
  * AT A TIME: a runtime-bounded `for (i) acc = fma(a[i], b[i], acc)` makes one memory round trip per trip of the loop (the
@@ -430,11 +435,13 @@ __device__ void stage_body(const Tree &T, const Data &D, int mode, int k, int la
     }
 }
 
+#if TQ_HAS(TQP_HOST)
 __global__ void __launch_bounds__(WAVE) k_stage(Tree T, Data D, int mode, int h, int t) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     if (mode == 1 && !phase_trial(D.ctrl, h, t)) return;
     stage_body(T, D, mode, blockIdx.x, threadIdx.x, lds);
 }
+#endif
 
 /* ------------------------------------------------------------------------------------------ */
 /* block reductions (one workgroup of 256 threads, fixed pairwise order => deterministic)      */
@@ -462,11 +469,13 @@ __device__ double block_reduce(const double *v, int n, double *sh) {
 }
 
 /* first sweep of a solve: fval0 = sum of the node terms */
+#if TQ_HAS(TQP_HOST)
 __global__ void __launch_bounds__(256) k_fval_init(Tree T, Data D) {
     __shared__ double sh[256];
     const double f = block_reduce<false>(D.fval, T.Nn, sh);
     if (threadIdx.x == 0) { D.ctrl->fval0 = f; D.ctrl->fval = f; }
 }
+#endif
 
 /* ------------------------------------------------------------------------------------------ */
 /* The small reductions as the TAIL of the sweep that produces their input (trees of <= FUSE_MAX nodes).  A reduction kernel of
@@ -546,12 +555,15 @@ __device__ void grad_body(const Tree &T, const Data &D, int termCondition, int k
     if (lane == 0) D.part_err[k] = part;
 }
 
+#if TQ_HAS(TQP_HOST)
 __global__ void __launch_bounds__(WAVE) k_grad(Tree T, Data D, int termCondition, int h) {
     if (!phase_main(D.ctrl, h)) return;
     grad_body(T, D, termCondition, blockIdx.x + 1, threadIdx.x);
 }
+#endif
 
 /* termination test; also the top-of-loop bookkeeping of the Newton iteration */
+#if TQ_HAS(TQP_HOST)
 __global__ void __launch_bounds__(256) k_check(Tree T, Data D, Opts O, int h) {
     __shared__ double sh[256];
     Ctrl *c = D.ctrl;
@@ -564,8 +576,10 @@ __global__ void __launch_bounds__(256) k_check(Tree T, Data D, Opts O, int h) {
         if (err < O.tol) { c->done = 1; c->status = 0; }      /* TREEQP_OPTIMAL_SOLUTION_FOUND */
     }
 }
+#endif
 
 /* k_grad with k_check as its tail (small trees) */
+#if TQ_HAS(TQP_HOST)
 __global__ void __launch_bounds__(WAVE) k_grad_f(Tree T, Data D, Opts O, Fuse F, int h) {
     Ctrl *c = D.ctrl;
     if (!phase_main(c, h)) return;
@@ -580,6 +594,7 @@ __global__ void __launch_bounds__(WAVE) k_grad_f(Tree T, Data D, Opts O, Fuse F,
         if (err < O.tol) { c->done = 1; c->status = 0; }      /* TREEQP_OPTIMAL_SOLUTION_FOUND */
     }
 }
+#endif
 
 /* ------------------------------------------------------------------------------------------ */
 /* k_hess: one wave per parent block p.                                                        */
@@ -652,11 +667,13 @@ __device__ void hess_body(const Tree &T, const Data &D, int p, int lane, double 
     }
 }
 
+#if TQ_HAS(TQP_HOST)
 __global__ void __launch_bounds__(WAVE) k_hess(Tree T, Data D, int h) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     if (!phase_main(D.ctrl, h)) return;
     hess_body(T, D, blockIdx.x, threadIdx.x, lds);
 }
+#endif
 
 /* ------------------------------------------------------------------------------------------ */
 /* k_factor: one wave per block of one tree level (blocks first .. first+count-1).             */
@@ -798,17 +815,21 @@ __device__ void factor_body(const Tree &T, const Data &D, const Opts &O, int ii,
     }
 }
 
+#if TQ_HAS(TQP_HOST)
 __global__ void __launch_bounds__(WAVE) k_factor(Tree T, Data D, Opts O, int first, int h) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     if (!phase_main(D.ctrl, h)) return;
     factor_body(T, D, O, first + blockIdx.x, threadIdx.x, lds);
 }
+#endif
 /* all levels in one launch: workgroup b takes block Np - 1 - b, so that the children a block waits for were started before it */
+#if TQ_HAS(TQP_HOST)
 __global__ void __launch_bounds__(WAVE) k_factor_all(Tree T, Data D, Opts O, u64 *sch, int rs, unsigned tag, int h) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     if (!phase_main(D.ctrl, h)) return;
     factor_body(T, D, O, T.Np - 1 - (int)blockIdx.x, threadIdx.x, lds, sch, rs, tag);
 }
+#endif
 
 /* ------------------------------------------------------------------------------------------ */
 /* k_forward: one wave per block of one level:                                                 */
@@ -862,11 +883,13 @@ __device__ void forward_body(const Tree &T, const Data &D, int ii, int lane, dou
     if (lane == 0) D.part_dot[ii] = pd;
 }
 
+#if TQ_HAS(TQP_HOST)
 __global__ void __launch_bounds__(WAVE) k_forward(Tree T, Data D, int first, int h) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     if (!phase_main(D.ctrl, h)) return;
     forward_body(T, D, first + blockIdx.x, threadIdx.x, lds);
 }
+#endif
 /* all levels below the root in one launch, blocks in BFS order: a block's parent was started before it */
 /* the tail of a fused forward sweep (small trees): the direction test and the start of the line search (k_ls_begin) */
 __device__ __forceinline__ void fuse_ls_begin(const Tree &T, const Data &D, const Fuse &F, int ii, int lane) {
@@ -881,16 +904,19 @@ __device__ __forceinline__ void fuse_ls_begin(const Tree &T, const Data &D, cons
         else { c->tau = 1.0; c->tauPrev = 0.0; c->ls_iter = 1; c->ls_pending = 1; }
     }
 }
+#if TQ_HAS(TQP_HOST)
 __global__ void __launch_bounds__(WAVE) k_forward_all(Tree T, Data D, u64 *fw, unsigned tag, int h, Fuse F) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     if (!phase_main(D.ctrl, h)) return;
     forward_body(T, D, 1 + (int)blockIdx.x, threadIdx.x, lds, fw, tag);
     if (F.on) fuse_ls_begin(T, D, F, 1 + (int)blockIdx.x, threadIdx.x);
 }
+#endif
 
 /* ------------------------------------------------------------------------------------------ */
 /* line-search control (line_search, dual_Newton_tree.c:922-1019)                              */
 /* ------------------------------------------------------------------------------------------ */
+#if TQ_HAS(TQP_HOST)
 __global__ void __launch_bounds__(256) k_ls_begin(Tree T, Data D, int h) {
     __shared__ double sh[256];
     Ctrl *c = D.ctrl;
@@ -906,6 +932,7 @@ __global__ void __launch_bounds__(256) k_ls_begin(Tree T, Data D, int h) {
         }
     }
 }
+#endif
 
 /* Armijo test and iteration bookkeeping for the trial whose dual value is f (line_search :973-1000) */
 __device__ void ls_decide_tail(Ctrl *c, int *ls_log, int ls_log_cap, const Opts &O, double f) {
@@ -942,6 +969,7 @@ __device__ bool ls_not_descent(Ctrl *c, double dotp) {
     return bad;
 }
 
+#if TQ_HAS(TQP_HOST)
 __global__ void __launch_bounds__(256) k_ls_decide(Tree T, Data D, Opts O, int h, int t, int with_descent_check) {
     __shared__ double sh[256];
     __shared__ int bail;
@@ -957,8 +985,10 @@ __global__ void __launch_bounds__(256) k_ls_decide(Tree T, Data D, Opts O, int h
     const double f = block_reduce<false>(D.fval, T.Nn, sh);
     if (threadIdx.x == 0) ls_decide_tail(c, D, O, f);
 }
+#endif
 
 /* k_stage with k_fval_init (mode 0) or k_ls_decide (mode 1) as its tail (small trees) */
+#if TQ_HAS(TQP_HOST)
 __global__ void __launch_bounds__(WAVE) k_stage_f(Tree T, Data D, Opts O, Fuse F, int mode, int h, int t) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     Ctrl *c = D.ctrl;
@@ -973,16 +1003,20 @@ __global__ void __launch_bounds__(WAVE) k_stage_f(Tree T, Data D, Opts O, Fuse F
         else ls_decide_tail(c, D, O, f);
     }
 }
+#endif
 
 /* ---- sharded mode (one tree over several devices): rank-local partials and the decision from the
  * gathered per-rank records; sums run in rank order so that every rank takes the same decision ---- */
+#if TQ_HAS(TQP_HOST)
 __global__ void __launch_bounds__(256) k_shard_pack1(Data D, int nlocal, double *xerr, int rank, int termCondition, int h) {
     __shared__ double sh[256];
     if (!phase_main(D.ctrl, h)) return;
     const double e = (termCondition == 2) ? block_reduce<true>(D.part_err, nlocal, sh) : block_reduce<false>(D.part_err, nlocal, sh);
     if (threadIdx.x == 0) xerr[rank] = e;
 }
+#endif
 
+#if TQ_HAS(TQP_HOST)
 __global__ void __launch_bounds__(WAVE) k_shard_pack2(Data D, const int *nodes, int n_nodes, const int *blocks, int n_blocks,
                                                      double *xs, int rank, int b0, int bn, int own0, int ownn, int h, int t) {
     const Ctrl *c = D.ctrl;
@@ -1004,7 +1038,9 @@ __global__ void __launch_bounds__(WAVE) k_shard_pack2(Data D, const int *nodes, 
     f = wave_sum(f); d = wave_sum(d);
     if (threadIdx.x == 0) { xs[2 * rank] = f; xs[2 * rank + 1] = d; }
 }
+#endif
 
+#if TQ_HAS(TQP_HOST)
 __global__ void __launch_bounds__(WAVE) k_ls_decide_parts(Data D, Opts O, const double *xs, int nranks, int h, int t, int with_descent_check) {
     Ctrl *c = D.ctrl;
     if (!phase_trial(c, h, t)) return;
@@ -1014,6 +1050,7 @@ __global__ void __launch_bounds__(WAVE) k_ls_decide_parts(Data D, Opts O, const 
     if (with_descent_check && ls_not_descent(c, -d)) return;
     ls_decide_tail(c, D, O, f);
 }
+#endif
 
 #include "tdunes_fast.hpp"
 #include "tdunes_persist.hpp"
@@ -1021,7 +1058,14 @@ __global__ void __launch_bounds__(WAVE) k_ls_decide_parts(Data D, Opts O, const 
 #include "tdunes_wide3.hpp"
 #include "tdunes_gpersist.hpp"
 
-}  // namespace
+}  // namespace tqd
+using namespace tqd;
+
+#if TQ_HAS(TQP_HOST)
+namespace tqd {
+thread_local std::string g_err;
+int fail(int code, const std::string &msg) { g_err = msg; return code; }
+}  // namespace tqd
 
 /* ============================================================================================ */
 /* host side of the C-ABI                                                                       */
@@ -1288,21 +1332,7 @@ int allow_lds(K kernel, size_t bytes) {
 }
 
 
-/* (NX, NU, MD) instantiations of the fused path */
-/* instantiated (index, nx, nu, md): nx * md <= 16 and a multiple of 4, nx + nu <= 16 */
-#ifdef TQ_SMALL_TABLE   /* experiment builds (tools/variants.sh): only the BASELINE shapes, a fifth of the compile time */
-#define FAST_TABLE(X) X(0, 8, 3, 2) X(2, 4, 1, 3)
-#else
-#define FAST_TABLE(X) X(0, 8, 3, 2) X(1, 4, 1, 2) X(2, 4, 1, 3) X(3, 2, 1, 2) X(4, 8, 2, 2) X(5, 6, 2, 2) X(6, 4, 1, 4) \
-    X(7, 8, 1, 2) X(8, 8, 4, 2) X(9, 4, 2, 2) X(10, 4, 3, 2) X(11, 4, 2, 3) X(12, 4, 2, 4) X(13, 6, 1, 2) X(14, 6, 3, 2) X(15, 2, 1, 4) X(16, 2, 2, 2)
-#endif
 
-/* shapes with a sharded instantiation of the persistent kernel (f_persist_sh; one table line per shape) */
-#ifdef TQ_SMALL_TABLE
-#define SHARD_TABLE(X) X(0, 8, 3, 2)
-#else
-#define SHARD_TABLE(X) X(0, 8, 3, 2) X(1, 4, 1, 2) X(4, 8, 2, 2) X(5, 6, 2, 2)
-#endif
 bool shard_instantiated(int idx) {
 #define X(i, nx, nu, md) if (idx == i) return true;
     SHARD_TABLE(X)
@@ -1323,15 +1353,6 @@ void fast_geometry(int idx, int &TH, size_t &tier_lds, size_t &stage_lds) {
 #undef X
 }
 
-/* (NX, NU, MD) instantiations of the multistage persistent kernel: the chain part works on blocks of NX rows,
- * which the MFMA Schur tile wants to be a multiple of 4 */
-/* multistage trees: the chain part's MFMA tile needs nx % 4 == 0 */
-#ifdef TQ_SMALL_TABLE
-#define MSTAGE_TABLE(X) X(0, 8, 3, 2) X(2, 4, 1, 3)
-#else
-#define MSTAGE_TABLE(X) X(0, 8, 3, 2) X(1, 4, 1, 2) X(2, 4, 1, 3) X(4, 8, 2, 2) X(6, 4, 1, 4) \
-    X(7, 8, 1, 2) X(8, 8, 4, 2) X(9, 4, 2, 2) X(10, 4, 3, 2) X(11, 4, 2, 3) X(12, 4, 2, 4)
-#endif
 
 /* multistage tree?  (setup_multistage_tree(md, Nr, Nh) with 1 <= Nr < Nh: every node above stage Nr has md
  * children, every parent from stage Nr on has one; uniform nx, nu) */
@@ -2944,10 +2965,6 @@ extern "C" int tqgpu_geometry(const tqgpu_solver *s, int *levels, int *tiers, in
 /* diagnostic: how often a persistent launch of this mirror timed out and the solve was redone on another path */
 extern "C" int tqgpu_timeouts(const tqgpu_solver *s) { return s ? s->n_timeouts : 0; }
 
-/* shapes with a batch kernel (f_persist_batch: one launch for a batch of trees of one shape); the BASELINE shapes and a few neighbours -- any other
- * (nx, nu, md) of FAST_TABLE / MSTAGE_TABLE is one line away and costs its compile time; without a line the members of a batch
- * are launched one by one as before */
-#define BATCH_TABLE(X) X(0, 8, 3, 2, false) X(1, 4, 1, 3, true) X(2, 8, 3, 2, true) X(3, 4, 1, 2, false) X(4, 4, 1, 2, true) X(5, 8, 2, 2, false)
 static int batch_kernel_index(const tqgpu_solver *s) {
 #define X(idx, nx, nu, md, ms) if (s->fNX == nx && s->fNU == nu && s->fMD == md && s->mstage == ms) return idx;
     BATCH_TABLE(X)
@@ -3773,3 +3790,4 @@ extern "C" int tqgpu_iteration_cost(const tqgpu_solver *s, int n_ls, double *byt
     if (flops) *flops = Sf + Gf + Hf + Ff + sweeps * Lf;
     return TQGPU_OK;
 }
+#endif  /* TQ_HAS(TQP_HOST) */

@@ -456,7 +456,11 @@ struct Shard {
  * first != 0: this is the first kernel of the iteration: G+H (and norm partials) before the sweep.
  * check != 0: this is the second kernel of the iteration: termination test first. */
 template <int NX, int NU, int MD>
-__global__ void __launch_bounds__(FW * WAVE) f_back(Tree T, Data Dt, Opts O, Shard Sh, int l0, int l1, int first, int check, int nparts, int kern, int h) {
+__global__ void __launch_bounds__(FW * WAVE) f_back(Tree T, Data Dt, Opts O, Shard Sh, int l0, int l1, int first, int check, int nparts, int kern, int h)
+#if !TQ_HAS(TQP_TIER)
+;
+#else
+{
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D;
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
@@ -522,11 +526,16 @@ __global__ void __launch_bounds__(FW * WAVE) f_back(Tree T, Data Dt, Opts O, Sha
         stamp(Dt, O, kern, sl++);
     }
 }
+#endif
 
 /* f_top: single workgroup, block levels [0, l1): (G+H if it is the only tier) termination test,
  * backward sweep, root, forward sweep of its levels; arms the line search. */
 template <int NX, int NU, int MD>
-__global__ void __launch_bounds__(FW * WAVE) f_top(Tree T, Data Dt, Opts O, Shard Sh, int l1, int first, int check, int nparts, int kern, int h) {
+__global__ void __launch_bounds__(FW * WAVE) f_top(Tree T, Data Dt, Opts O, Shard Sh, int l1, int first, int check, int nparts, int kern, int h)
+#if !TQ_HAS(TQP_TIER)
+;
+#else
+{
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D;
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
@@ -593,10 +602,15 @@ __global__ void __launch_bounds__(FW * WAVE) f_top(Tree T, Data Dt, Opts O, Shar
     }
     if (threadIdx.x == 0) { c->tau = 1.0; c->tauPrev = 0.0; c->ls_iter = 1; c->ls_pending = 1; }
 }
+#endif
 
 /* f_fwd: one workgroup per subtree of block levels [l0, l1): forward sweep top-down */
 template <int NX, int NU, int MD>
-__global__ void __launch_bounds__(FW * WAVE) f_fwd(Tree T, Data Dt, Opts O, Shard Sh, int l0, int l1, int kern, int h) {
+__global__ void __launch_bounds__(FW * WAVE) f_fwd(Tree T, Data Dt, Opts O, Shard Sh, int l0, int l1, int kern, int h)
+#if !TQ_HAS(TQP_TIER)
+;
+#else
+{
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D;
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
@@ -623,12 +637,17 @@ __global__ void __launch_bounds__(FW * WAVE) f_fwd(Tree T, Data Dt, Opts O, Shar
         stamp(Dt, O, kern, sl++);
     }
 }
+#endif
 
 /* f_stage: trial point lam_cur + (tau - tauPrev) dlam for every node, one wave per node: stage QP by
  * clipping, elimination vectors, dual-function term; writes lam_next.  All loads are issued before
  * the first dependent use. */
 template <int NX, int NU, int MD>
-__global__ void __launch_bounds__(FW * WAVE) f_stage(Tree T, Data Dt, Opts O, const int *node_list, int n_nodes, int kern, int h, int trial) {
+__global__ void __launch_bounds__(FW * WAVE) f_stage(Tree T, Data Dt, Opts O, const int *node_list, int n_nodes, int kern, int h, int trial)
+#if !TQ_HAS(TQP_TIER)
+;
+#else
+{
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D;
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
@@ -712,3 +731,15 @@ __global__ void __launch_bounds__(FW * WAVE) f_stage(Tree T, Data Dt, Opts O, co
     }
     stamp(Dt, O, kern, 1);
 }
+#endif
+
+/* the part that owns the family instantiates it (tdunes_parts.hpp) */
+#if TQ_HAS(TQP_TIER)
+#define X(idx, nx, nu, md) \
+    template __global__ void f_back<nx, nu, md>(Tree, Data, Opts, Shard, int, int, int, int, int, int, int); \
+    template __global__ void f_top<nx, nu, md>(Tree, Data, Opts, Shard, int, int, int, int, int, int); \
+    template __global__ void f_fwd<nx, nu, md>(Tree, Data, Opts, Shard, int, int, int, int); \
+    template __global__ void f_stage<nx, nu, md>(Tree, Data, Opts, const int *, int, int, int, int);
+FAST_TABLE(X)
+#undef X
+#endif

@@ -334,13 +334,23 @@ __device__ __forceinline__ void g_persist_body(Tree T_in, Data D_in, Opts O, GPa
     }
 }
 
-__global__ void __launch_bounds__(GP_WAVES * WAVE) g_persist(Tree T_in, Data D_in, Opts O, GParams G) { g_persist_body(T_in, D_in, O, G); }
+__global__ void __launch_bounds__(GP_WAVES * WAVE) g_persist(Tree T_in, Data D_in, Opts O, GParams G)
+#if !TQ_HAS(TQP_GP)
+;
+#else
+{ g_persist_body(T_in, D_in, O, G); }
+#endif
 
 /* a batch of independent small trees (fault_tolerance.c keeps one QP per spring configuration, :486-530): ONE launch, one
  * workgroup per tree, each working from its own descriptors.  (One launch per tree on its own stream only overlaps as
  * many trees as the runtime has hardware queues -- four.) */
 struct GItem { Tree T; Data D; GParams G; };
-__global__ void __launch_bounds__(GP_WAVES * WAVE) g_persist_batch(const GItem *items, Opts O) {
+__global__ void __launch_bounds__(GP_WAVES * WAVE) g_persist_batch(const GItem *items, Opts O)
+#if !TQ_HAS(TQP_GP)
+;
+#else
+{
     const GItem *it = items + blockIdx.x;
     g_persist_body(it->T, it->D, O, it->G);
 }
+#endif

@@ -1620,17 +1620,27 @@ __device__ __forceinline__ void persist_entry(const PConst &C, const Opts &O, co
 }
 
 template <int NX, int NU, int MD, bool RU>
-__global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_persist(PConst C, Opts O, PGeom Gm, PSync Sy, int prologue) {
+__global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_persist(PConst C, Opts O, PGeom Gm, PSync Sy, int prologue)
+#if !TQ_HAS(TQP_PERSIST)
+;
+#else
+{
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     Sy.npeer = 1; Sy.relay_wg = -1;          /* one device: a compile-time fact here, so that the stores to peer slabs and the verdict relay fold away (left as run-time tests they cost 18 us per C2 solve: scalar registers) */
     persist_entry<NX, NU, MD, RU>(C, O, Gm, Sy, prologue, (int)blockIdx.x, lds_all);
 }
+#endif
 /* the same launch as one rank's share of a sharded solve (tqgpu_pshard_*): hand-over words go to every rank's slab */
 template <int NX, int NU, int MD>
-__global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_persist_sh(PConst C, Opts O, PGeom Gm, PSync Sy, int prologue) {
+__global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_persist_sh(PConst C, Opts O, PGeom Gm, PSync Sy, int prologue)
+#if !TQ_HAS(TQP_SHARD)
+;
+#else
+{
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     persist_entry<NX, NU, MD, false>(C, O, Gm, Sy, prologue, (int)blockIdx.x, lds_all);
 }
+#endif
 
 /* multistage trees (branching for Nr stages, then one child per node -- the reference's setup_multistage_tree
  * with Nr < Nh, its standard robust-horizon shape): the tiers of the branching part run as above, every scenario
@@ -1655,11 +1665,16 @@ __device__ __forceinline__ void mpersist_entry(const PConst &C, const Opts &O, c
 }
 
 template <int NX, int NU, int MD, bool RU>
-__global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_mpersist(PConst C, Opts O, PGeom Gm, PSync Sy, int prologue) {
+__global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_mpersist(PConst C, Opts O, PGeom Gm, PSync Sy, int prologue)
+#if !TQ_HAS(TQP_PERSIST)
+;
+#else
+{
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     Sy.npeer = 1; Sy.relay_wg = -1;
     mpersist_entry<NX, NU, MD, RU>(C, O, Gm, Sy, prologue, (int)blockIdx.x, lds_all);
 }
+#endif
 
 /* A BATCH of independent trees of one shape as ONE launch (tqgpu_solve_batch): workgroups [t G, (t + 1) G) are tree t's, which
  * works from its own descriptors (constants, geometry, hand-over buffers, result block) in device memory and never looks at
@@ -1668,7 +1683,11 @@ __global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_mpersist(PConst C, Opts O
  * (its tags only have to be unique in the tree's own buffers).  Fresh solves only (prologue). */
 struct PItem { PConst C; PGeom Gm; PSync Sy; };
 template <int NX, int NU, int MD, bool MSTAGE>
-__global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_persist_batch(const PItem *items, Opts O, int G, unsigned seq, int nap) {
+__global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_persist_batch(const PItem *items, Opts O, int G, unsigned seq, int nap)
+#if !TQ_HAS(TQP_BATCH)
+;
+#else
+{
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     const int tree = (int)blockIdx.x / G, b = (int)blockIdx.x - tree * G;
     const PItem *it = items + tree;
@@ -1681,9 +1700,11 @@ __global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_persist_batch(const PItem
     if (MSTAGE) mpersist_entry<NX, NU, MD, false>(C, O, Gm, Sy, 1, b, lds_all);
     else persist_entry<NX, NU, MD, false>(C, O, Gm, Sy, 1, b, lds_all);
 }
+#endif
 
 /* packed constants of the persistent path (run whenever the QP data changed): [A | B] per edge and
  * {linear term, 1/weight, weight, lower, upper} per node entry */
+#if TQ_HAS(TQP_HOST)
 __global__ void k_pack_persist(int Nn, int Np, int NX, int NU, Data D, double *AB, double *cst) {
     const int NZ = NX + NU;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1700,3 +1721,28 @@ __global__ void k_pack_persist(int Nn, int Np, int NX, int NU, Data D, double *A
         AB[i] = col < NX ? D.A[(size_t)edge * NX * NX + (size_t)col * NX + r] : D.B[(size_t)edge * NX * NU + (size_t)(col - NX) * NX + r];
     }
 }
+#endif
+
+/* the parts that own these families instantiate them (tdunes_parts.hpp; the persistent family in slices by table index) */
+#if TQ_HAS(TQP_PERSIST)
+#define X(idx, nx, nu, md) TQ_SL(idx, \
+    template __global__ void f_persist<nx, nu, md, false>(PConst, Opts, PGeom, PSync, int); \
+    template __global__ void f_persist<nx, nu, md, true>(PConst, Opts, PGeom, PSync, int);)
+FAST_TABLE(X)
+#undef X
+#define X(idx, nx, nu, md) TQ_SL(idx, \
+    template __global__ void f_mpersist<nx, nu, md, false>(PConst, Opts, PGeom, PSync, int); \
+    template __global__ void f_mpersist<nx, nu, md, true>(PConst, Opts, PGeom, PSync, int);)
+MSTAGE_TABLE(X)
+#undef X
+#endif
+#if TQ_HAS(TQP_SHARD)
+#define X(idx, nx, nu, md) template __global__ void f_persist_sh<nx, nu, md>(PConst, Opts, PGeom, PSync, int);
+SHARD_TABLE(X)
+#undef X
+#endif
+#if TQ_HAS(TQP_BATCH)
+#define X(idx, nx, nu, md, ms) template __global__ void f_persist_batch<nx, nu, md, ms>(const PItem *, Opts, int, unsigned, int);
+BATCH_TABLE(X)
+#undef X
+#endif

@@ -82,7 +82,11 @@ __device__ __forceinline__ double wide_backsolve(lds_cptr L, int ld, int d, int 
 /* ------------------------------------------------------------------------------------------ */
 /* H                                                                                          */
 /* ------------------------------------------------------------------------------------------ */
-__global__ void __launch_bounds__(WT) k_hess_w(Tree T, Data D, int h) {
+__global__ void __launch_bounds__(WT) k_hess_w(Tree T, Data D, int h)
+#if !TQ_HAS(TQP_WIDE)
+;
+#else
+{
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int p = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int e[28];
@@ -171,6 +175,7 @@ __global__ void __launch_bounds__(WT) k_hess_w(Tree T, Data D, int h) {
         }
     }
 }
+#endif
 
 /* ------------------------------------------------------------------------------------------ */
 /* F: tall Cholesky of [W ; resMod' ; Ut], Schur complement into the parent, root solve        */
@@ -414,21 +419,35 @@ __device__ __forceinline__ void factor_w_body(const Tree &T, const Data &D, cons
     WSTAMP(15);
 }
 
-__global__ void __launch_bounds__(WT) k_factor_w(Tree T, Data D, Opts O, int first, int h) {
+__global__ void __launch_bounds__(WT) k_factor_w(Tree T, Data D, Opts O, int first, int h)
+#if !TQ_HAS(TQP_WIDE)
+;
+#else
+{
     factor_w_body<false>(T, D, O, first + blockIdx.x, first, h, nullptr, 0, 0u);
 }
+#endif
 /* the backward sweep of ALL levels as one launch: workgroup b takes block Np - 1 - b */
 #ifndef TQ_WIDE_WPS
 #define TQ_WIDE_WPS 2
 #endif
-__global__ void __launch_bounds__(WT, TQ_WIDE_WPS) k_factor_all_w(Tree T, Data D, Opts O, u64 *sch, int rs, unsigned tag, int h) {
+__global__ void __launch_bounds__(WT, TQ_WIDE_WPS) k_factor_all_w(Tree T, Data D, Opts O, u64 *sch, int rs, unsigned tag, int h)
+#if !TQ_HAS(TQP_WIDE)
+;
+#else
+{
     factor_w_body<true>(T, D, O, T.Np - 1 - (int)blockIdx.x, T.Np - 1 - (int)blockIdx.x, h, sch, rs, tag);
 }
+#endif
 
 /* ------------------------------------------------------------------------------------------ */
 /* forward substitution of one level:  dlam_ii = L^-T ( y_ii - CholUt_ii' * dlam_dad[pos..] )  */
 /* ------------------------------------------------------------------------------------------ */
-__global__ void __launch_bounds__(WT) k_forward_w(Tree T, Data D, int first, int h) {
+__global__ void __launch_bounds__(WT) k_forward_w(Tree T, Data D, int first, int h)
+#if !TQ_HAS(TQP_WIDE)
+;
+#else
+{
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int ii = first + blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int e[10];
@@ -472,6 +491,7 @@ __global__ void __launch_bounds__(WT) k_forward_w(Tree T, Data D, int first, int
     pd = wave_sum(pd);
     if (lane == 0) D.part_dot[ii] = pd;
 }
+#endif
 
 /* ------------------------------------------------------------------------------------------ */
 /* the forward sweep of ALL levels as one launch                                               */
@@ -484,7 +504,11 @@ __global__ void __launch_bounds__(WT) k_forward_w(Tree T, Data D, int first, int
  * and the hardware starts them in order, so a waiting workgroup's parent is always running or done: no deadlock whatever
  * part of the grid is resident.  Children of the root read the root's step from D.dlam (k_factor_w wrote it in an earlier
  * launch).  A wait that never ends (it cannot) gives up after 0.5 s and ends the solve with UNKNOWN_ERROR. */
-__global__ void __launch_bounds__(WT) k_forward_all_w(Tree T, Data D, u64 *fw, unsigned tag, int h, Fuse F) {
+__global__ void __launch_bounds__(WT) k_forward_all_w(Tree T, Data D, u64 *fw, unsigned tag, int h, Fuse F)
+#if !TQ_HAS(TQP_WIDE)
+;
+#else
+{
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int ii = 1 + blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int e[12];
@@ -557,6 +581,7 @@ __global__ void __launch_bounds__(WT) k_forward_all_w(Tree T, Data D, u64 *fw, u
     if (lane == 0) D.part_dot[ii] = pd;
     if (F.on) fuse_ls_begin(T, D, F, ii, lane);          /* small trees: k_ls_begin as the tail of the sweep (wave 0 is the one left here) */
 }
+#endif
 
 /* LDS a block of dimension d (tall matrix of R rows, nz parent columns) needs in the wide kernels */
 static inline size_t wide_lds_hess(int d, int nz) { const int dp = (d + 15) & ~15, kz = (nz + 3) & ~3; return (size_t)(dp | 16) * kz * sizeof(double); }

@@ -149,7 +149,11 @@ __device__ void w3_reduce2(const u64 *red, int n, unsigned tag, int lane, bool m
 /* ------------------------------------------------------------------------------------------ */
 /* k_sg: stage sweep + gradient + dual value / Armijo test + termination test                  */
 /* ------------------------------------------------------------------------------------------ */
-__global__ void __launch_bounds__(SG_WAVES * WAVE) k_sg(Tree T, Data D, Opts O, W3 Wd, int mode, int h, int t) {
+__global__ void __launch_bounds__(SG_WAVES * WAVE) k_sg(Tree T, Data D, Opts O, W3 Wd, int mode, int h, int t)
+#if !TQ_HAS(TQP_W3)
+;
+#else
+{
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double part[2][SG_WAVES];
     Ctrl *c = D.ctrl;
@@ -196,11 +200,17 @@ __global__ void __launch_bounds__(SG_WAVES * WAVE) k_sg(Tree T, Data D, Opts O, 
         w3_mirror(Wd, c, mode == 0, t_begin);
     }
 }
+#endif
 
 /* the control block to the host, on its own (read_ctrl: the last launch enqueued is not one that posts) */
-__global__ void k_w3_post(Data D, W3 Wd) {
+__global__ void k_w3_post(Data D, W3 Wd)
+#if !TQ_HAS(TQP_W3)
+;
+#else
+{
     if (threadIdx.x == 0) w3_mirror(Wd, D.ctrl, false, 0ull);
 }
+#endif
 
 /* ------------------------------------------------------------------------------------------ */
 /* k_sgp: k_sg with one workgroup per PARENT.  The children's [A | B] (the matrix C of the dual Hessian block) is fetched once,     */
@@ -373,7 +383,11 @@ __device__ __forceinline__ const int *sgp_anc(const SgpFwdYes &a) { return a.anc
 __device__ __forceinline__ u64 *sgp_pdw(const SgpFwdNo &) { return nullptr; }
 __device__ __forceinline__ u64 *sgp_pdw(const SgpFwdYes &a) { return a.pdw; }
 template <bool FWD>      /* FWD: the instantiation that knows mode 2 (modes 0 and 1 keep the registers, the arguments and the code they had: 91 against 101 registers is 10 us per C4 solve) */
-__global__ void __launch_bounds__(WT) k_sgp_t(Tree T, Data D, Opts O, W3 Wd, int mode, int h, int t, int accs_cap, const double *lam_src, typename SgpFwd<FWD>::type fa) {
+__global__ void __launch_bounds__(WT) k_sgp_t(Tree T, Data D, Opts O, W3 Wd, int mode, int h, int t, int accs_cap, const double *lam_src, typename SgpFwd<FWD>::type fa)
+#if !TQ_HAS(TQP_W3)
+;
+#else
+{
     const int *anc = sgp_anc(fa);
     u64 *pdw = sgp_pdw(fa);
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -611,6 +625,7 @@ __global__ void __launch_bounds__(WT) k_sgp_t(Tree T, Data D, Opts O, W3 Wd, int
         w3_mirror(Wd, c, mode == 0, t_begin);
     }
 }
+#endif
 /* LDS of k_sgp: C, the four 64-entry vectors, the children's terms */
 static inline size_t wide3_lds_sgp(int d, int nz, int accs) { return ((size_t)(d | 1) * nz + 5 * 64 + accs) * sizeof(double); }
 
@@ -732,7 +747,11 @@ __device__ __forceinline__ bool w3_schur_tile(int wave, int slot, int nt2, int &
 #else
 #define W3_BARRIER() lds_barrier()
 #endif
-__global__ void __launch_bounds__(WT, TQ_W3_WPS) k_hf_w(Tree T, Data D, Opts O, u64 *sch, int rs, unsigned tag, int h) {
+__global__ void __launch_bounds__(WT, TQ_W3_WPS) k_hf_w(Tree T, Data D, Opts O, u64 *sch, int rs, unsigned tag, int h)
+#if !TQ_HAS(TQP_W3)
+;
+#else
+{
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ int small_flag;
     __shared__ int simd_of[WW];
@@ -1191,12 +1210,17 @@ __global__ void __launch_bounds__(WT, TQ_W3_WPS) k_hf_w(Tree T, Data D, Opts O, 
         W3BSTAMP(3);
     }
 }
+#endif
 
 /* ------------------------------------------------------------------------------------------ */
 /* k_fwd3: forward sweep with the prepared [z0 | M], one wave per block, parents first;         */
 /* tail: res' dlam, direction test, start of the line search                                   */
 /* ------------------------------------------------------------------------------------------ */
-__global__ void __launch_bounds__(SG_WAVES * WAVE) k_fwd3(Tree T, Data D, W3 Wd, u64 *fw, unsigned ftag, int h) {
+__global__ void __launch_bounds__(SG_WAVES * WAVE) k_fwd3(Tree T, Data D, W3 Wd, u64 *fw, unsigned ftag, int h)
+#if !TQ_HAS(TQP_W3)
+;
+#else
+{
     __shared__ double part[SG_WAVES];
     Ctrl *c = D.ctrl;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1273,6 +1297,7 @@ __global__ void __launch_bounds__(SG_WAVES * WAVE) k_fwd3(Tree T, Data D, W3 Wd,
         else { c->tau = 1.0; c->tauPrev = 0.0; c->ls_iter = 1; c->ls_pending = 1; }
     }
 }
+#endif
 
 /* ------------------------------------------------------------------------------------------ */
 /* k_fwd3c: the forward sweep WITHOUT hand-overs, for trees of small nodes (nx <= 8 everywhere, at most 16 blocks on a path from the   */
@@ -1285,7 +1310,11 @@ __global__ void __launch_bounds__(SG_WAVES * WAVE) k_fwd3(Tree T, Data D, W3 Wd,
 /* anc: per block 1 + 16 x 4 ints: path length L, then {z0 offset, M offset, d of that ancestor, nx of the ancestor's node (0: the root  */
 /* block, whose z0 is the step) | nx of the path's node << 8} from the root's block down to the block's dad.  Same tail as k_fwd3.      */
 /* ------------------------------------------------------------------------------------------ */
-__global__ void __launch_bounds__(SG_WAVES * WAVE) k_fwd3c(Tree T, Data D, W3 Wd, const int *anc, int h) {
+__global__ void __launch_bounds__(SG_WAVES * WAVE) k_fwd3c(Tree T, Data D, W3 Wd, const int *anc, int h)
+#if !TQ_HAS(TQP_W3)
+;
+#else
+{
     __shared__ double part[SG_WAVES];
     Ctrl *c = D.ctrl;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1326,6 +1355,7 @@ __global__ void __launch_bounds__(SG_WAVES * WAVE) k_fwd3c(Tree T, Data D, W3 Wd
         else { c->tau = 1.0; c->tauPrev = 0.0; c->ls_iter = 1; c->ls_pending = 1; }
     }
 }
+#endif
 
 /* LDS of k_hf_w for a block of dimension d under a parent of nz = nx + nu columns */
 static inline size_t wide3_lds(int d, int nxi, int nz) {
@@ -1333,3 +1363,8 @@ static inline size_t wide3_lds(int d, int nxi, int nz) {
     (void)nz; (void)kz;                        /* C (dp x kz, kz <= 32 <= dp) is staged inside the image */
     return ((size_t)wide_ldf(wide_rows(d, nxi)) * dp + (dp < 64 ? (size_t)256 * (dp >> 4) : 0)) * sizeof(double);
 }
+
+#if TQ_HAS(TQP_W3)
+template __global__ void k_sgp_t<false>(Tree, Data, Opts, W3, int, int, int, int, const double *, SgpFwdNo);
+template __global__ void k_sgp_t<true>(Tree, Data, Opts, W3, int, int, int, int, const double *, SgpFwdYes);
+#endif
