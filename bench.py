@@ -249,6 +249,8 @@ def main():
     ap.add_argument("--no-batched", action="store_true", help="skip the batched-throughput sweep and the critical-path leg (profiling runs: only the timed launches in the kernel statistics)")
     ap.add_argument("--mode", choices=["batch", "shard"], default="batch", help="N > 1: independent trees (weak) or one sharded tree (strong) as the headline")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--strict-sharded", action="store_true", help="N > 1: exit with code 3 (after the JSON line has been printed) when the sharded leg failed; by default the exit code is 0 "
+                                                                    "because the replicas' line is complete and valid -- `sharded_ok` at the top level of the line is the field to read")
     ap.add_argument("--trees", type=int, default=1, help="independent trees per GPU solved by one batched call per step (throughput mode; default 1 = the latency metric)")
     args = ap.parse_args()
 
@@ -493,7 +495,7 @@ def main():
                 out["sharded"] = {"error": f"the sharded leg did not finish within {deadline:.0f} s; abandoned"}
                 out["sharded_ok"] = False
                 print(dumps(out), flush=True)
-            os._exit(0)                       # the main thread is stuck in a collective: no orderly teardown possible
+            os._exit(3 if args.strict_sharded else 0)      # the main thread is stuck in a collective: no orderly teardown possible
 
         threading.Thread(target=watchdog, daemon=True).start()
         try:
@@ -571,7 +573,7 @@ def main():
             out["sharded_ok"] = "error" not in sharded          # top level: a failed sharded leg must not read as success
         print(dumps(out), flush=True)
     if sharded is not None and "error" in sharded:
-        os._exit(0)          # the other ranks may be stuck in a collective of the failed leg (their deadline ends them): no orderly teardown with them
+        os._exit(3 if args.strict_sharded else 0)          # the other ranks may be stuck in a collective of the failed leg (their deadline ends them): no orderly teardown with them
     for m in mirrors:
         m.close()
     if dist is not None:

@@ -57,7 +57,7 @@ def product_library() -> Path:
 
 # The device path is ONE source file compiled once per part, all parts in parallel (csrc/device/tdunes_parts.hpp):
 # name -> (-DTQ_PARTS mask, extra defines).  The persistent family is sliced by shape (its kernels are most of the compile time).
-PERSIST_SLICES = 4
+PERSIST_SLICES = 9
 DEVICE_PARTS = {
     "host": ("TQP_HOST", []),
     "gpersist": ("TQP_GP", []),
@@ -65,7 +65,8 @@ DEVICE_PARTS = {
     "wide3": ("TQP_W3", []),
     "tiered": ("TQP_TIER", []),
     **{f"persist{k}": ("TQP_PERSIST", [f"-DTQ_PERSIST_NSLICES={PERSIST_SLICES}", f"-DTQ_PERSIST_SLICE={k}"]) for k in range(PERSIST_SLICES)},
-    "shard": ("TQP_SHARD", []),
+    "shard": ("TQP_SHARD", ["-DTQ_LD_SCOPE=__HIP_MEMORY_SCOPE_SYSTEM"]),
+    "shard_ag": ("TQP_SHARD_AG", []),
     "batch": ("TQP_BATCH", []),
 }
 JOBS = max(1, min(len(DEVICE_PARTS), (os.cpu_count() or 4)))

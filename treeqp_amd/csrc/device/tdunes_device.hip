@@ -140,8 +140,13 @@ __device__ __forceinline__ void st_tag(u64 *p, double v, unsigned tag) {
     __hip_atomic_store(p, t | (unsigned)__double2loint(v), RLX, AGENT);
     __hip_atomic_store(p + 1, t | (unsigned)__double2hiint(v), RLX, AGENT);
 }
+/* TQ_LD_SCOPE: the scope of the POLLS of hand-over words.  Agent scope everywhere but in the part that holds the sharded persistent kernel
+ * (tdunes_parts.hpp, treeqp_amd/build.py): there the slab is written by peer devices over xGMI and the polls are system-scope loads. */
+#ifndef TQ_LD_SCOPE
+#define TQ_LD_SCOPE __HIP_MEMORY_SCOPE_AGENT
+#endif
 __device__ __forceinline__ double ld_tag(const u64 *p, unsigned tag, bool &ok) {
-    const u64 a = __hip_atomic_load(p, RLX, AGENT), b = __hip_atomic_load(p + 1, RLX, AGENT);
+    const u64 a = __hip_atomic_load(p, RLX, TQ_LD_SCOPE), b = __hip_atomic_load(p + 1, RLX, TQ_LD_SCOPE);
     ok = ok && (unsigned)(a >> 32) == tag && (unsigned)(b >> 32) == tag;
     return __hiloint2double((int)(unsigned)b, (int)(unsigned)a);
 }
@@ -1193,6 +1198,8 @@ struct tqgpu_solver {
     size_t sync_words_bytes = 0, lds_persist = 0;
     /* ONE tree over several devices INSIDE the persistent launch (tqgpu_pshard_*): this rank's share of the workgroups */
     bool pshard = false;
+    bool ps_sys = true;             /* the sharded launch polls its slab with system-scope loads (f_persist_sh<.., 1>); TREEQP_AMD_PSHARD_AGENT=1: agent scope, as on one device */
+    bool ps_fine = false;           /* the hand-over slab was re-allocated as fine-grained memory (tqgpu_pshard_init; TREEQP_AMD_PSHARD_COARSE=1 keeps plain hipMalloc memory) */
     int *ps_wg_map = nullptr;       /* blockIdx.x -> workgroup id, this rank's workgroups (bottom tier first) */
     int ps_G = 0;
     void *ps_ipc[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      /* peer slabs opened through IPC handles (closed by tqgpu_destroy) */
@@ -1827,7 +1834,8 @@ int launch_persist(tqgpu_solver *s, const Opts &O, int &launches, int prologue, 
         PGeom Gm = s->geom;
         Gm.wg_of_block = s->ps_wg_map;
         switch (s->fast) {
-#define X(idx, nx, nu, md) case idx: hipLaunchKernelGGL((f_persist_sh<nx, nu, md>), dim3(s->ps_G), dim3(FW * WAVE), s->lds_persist, st, s->pconst, O, Gm, s->psync, prologue); break;
+#define X(idx, nx, nu, md) case idx: if (s->ps_sys) hipLaunchKernelGGL((f_persist_sh<nx, nu, md, 1>), dim3(s->ps_G), dim3(FW * WAVE), s->lds_persist, st, s->pconst, O, Gm, s->psync, prologue); \
+                                    else hipLaunchKernelGGL((f_persist_sh<nx, nu, md, 0>), dim3(s->ps_G), dim3(FW * WAVE), s->lds_persist, st, s->pconst, O, Gm, s->psync, prologue); break;
             SHARD_TABLE(X)
 #undef X
             default: return fail(TQGPU_EUNSUPPORTED, "the sharded persistent kernel is not instantiated for this shape");
@@ -2327,6 +2335,7 @@ extern "C" int tqgpu_uses_fused_path(const tqgpu_solver *s) {
 extern "C" int tqgpu_debug_block_stamps(tqgpu_solver *s, unsigned long long *out, int cap_blocks) {
     SETTLE(s);
     if (!s || !out) return fail(TQGPU_EINVAL, "bad arguments");
+    HIP_TRY(hipStreamSynchronize(s->stream));          /* (the copy below is on the null stream, which the solver's non-blocking stream does not order) */
     std::vector<double> tmp((size_t)std::max(s->sum_W, 1));
     HIP_TRY(hipMemcpy(tmp.data(), getenv("TQ_STAMPS_OF_SGP") ? s->D.W : s->D.CholW, sizeof(double) * (size_t)s->sum_W, hipMemcpyDeviceToHost));
     const int n = std::min(cap_blocks, s->Np);
@@ -2337,6 +2346,7 @@ extern "C" int tqgpu_debug_block_stamps(tqgpu_solver *s, unsigned long long *out
 extern "C" int tqgpu_get_stamps(tqgpu_solver *s, unsigned long long *out, int cap) {
     SETTLE(s);
     if (!s || !out) return fail(TQGPU_EINVAL, "bad arguments");
+    HIP_TRY(hipStreamSynchronize(s->stream));
     const int n = std::min(cap, 8 * 32 * 2 + 1024);
     HIP_TRY(hipMemcpy(out, s->D.stamps, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToHost));
     return TQGPU_OK;
@@ -2877,6 +2887,9 @@ static int enqueue_export(tqgpu_solver *s, const double *lamc) {
 extern "C" int tqgpu_solve(tqgpu_solver *s, const tqgpu_opts *o, tqgpu_result *res) {
     SETTLE(s);
     if (!s || !o || !res) return fail(TQGPU_EINVAL, "tqgpu_solve: bad arguments");
+    /* a mirror that is one rank's share of a sharded solve launches only that share: on its own it would time out, and its launch number
+     * would fall out of step with its peers' */
+    if (s->pshard && s->nranks > 1) return fail(TQGPU_EINVAL, "tqgpu_solve: this mirror is rank " + std::to_string(s->rank) + " of a sharded solve (tqgpu_pshard_init): use tqgpu_pshard_begin / _end");
     if (s->persist_backoff > 0 && --s->persist_backoff == 0) s->use_persist = s->use_persist_orig;
     SolveCtx cx;
     int rc = solve_begin(s, o, cx);
@@ -2995,6 +3008,7 @@ static int launch_persist_batch(tqgpu_solver *lead, int kidx, const PItem *items
 extern "C" int tqgpu_solve_batch(tqgpu_solver **solvers, int n, const tqgpu_opts *o, tqgpu_result *results) {
     if (!solvers || n < 1 || !o || !results) return fail(TQGPU_EINVAL, "tqgpu_solve_batch: bad arguments");
     for (int i = 0; i < n; i++) if (!solvers[i]) return fail(TQGPU_EINVAL, "tqgpu_solve_batch: null mirror");
+    for (int i = 0; i < n; i++) if (solvers[i]->pshard && solvers[i]->nranks > 1) return fail(TQGPU_EINVAL, "tqgpu_solve_batch: a member is one rank of a sharded solve (tqgpu_pshard_init)");
     std::vector<SolveCtx> cx((size_t)n);
     int first_err = TQGPU_OK;
     std::string first_msg;
@@ -3317,6 +3331,7 @@ extern "C" int tqgpu_shard_init(tqgpu_solver *s, int rank, int nranks, const voi
     if (nranks == 1 && !id128) { s->nranks = 1; s->rank = 0; s->sharded = false; return TQGPU_OK; }
     if (s->fast < 0 || !s->use_fast || s->mstage) return fail(TQGPU_EUNSUPPORTED, "sharding needs the fused uniform-tree path");
     s->nranks = nranks; s->rank = rank; s->sharded = true;
+    s->export_valid = false;
     int rc = shard_build_lists(s);
     if (rc) { s->nranks = 1; s->rank = 0; s->sharded = false; return rc; }
     if (id128) {
@@ -3363,7 +3378,7 @@ extern "C" int tqgpu_pshard_init(tqgpu_solver *s, int rank, int nranks) {
     if (!s->persist_ok || s->mstage || s->fast < 0 || !s->use_fast || !s->use_persist) return fail(TQGPU_EUNSUPPORTED, "sharding inside the persistent launch needs the persistent path of a uniform complete tree");
     if (!shard_instantiated(s->fast)) return fail(TQGPU_EUNSUPPORTED, "the sharded persistent kernel is not instantiated for this shape (SHARD_TABLE)");
     switch (s->fast) {
-#define X(idx, nx, nu, md) case idx: { int rca = allow_lds(f_persist_sh<nx, nu, md>, s->lds_persist); if (rca) return rca; } break;
+#define X(idx, nx, nu, md) case idx: { int rca = allow_lds(f_persist_sh<nx, nu, md, 1>, s->lds_persist); if (!rca) rca = allow_lds(f_persist_sh<nx, nu, md, 0>, s->lds_persist); if (rca) return rca; } break;
         SHARD_TABLE(X)
 #undef X
         default: break;
@@ -3379,6 +3394,27 @@ extern "C" int tqgpu_pshard_init(tqgpu_solver *s, int rank, int nranks) {
     HIP_TRY(hipMalloc(&s->ps_wg_map, sizeof(int) * std::max<size_t>(map.size(), 1)));
     HIP_TRY(hipMemcpy(s->ps_wg_map, map.data(), sizeof(int) * map.size(), hipMemcpyHostToDevice));
     s->ps_G = (int)map.size();
+    /* First contact with real xGMI is somebody else's run, so the two things a peer's writes depend on are settled by construction:
+     * (a) the slab the peers write into is FINE-GRAINED memory (coarse-grained hipMalloc memory is only guaranteed coherent across
+     *     devices at kernel boundaries; this kernel polls it while the peers write), and
+     * (b) the polls are system-scope loads (ps_sys: f_persist_sh<.., 1>, compiled with TQ_LD_SCOPE = system).
+     * TREEQP_AMD_PSHARD_COARSE=1 / TREEQP_AMD_PSHARD_AGENT=1 restore the single-device combination for an A/B on a node. */
+    s->ps_sys = !getenv("TREEQP_AMD_PSHARD_AGENT");
+    if (!s->ps_fine && !getenv("TREEQP_AMD_PSHARD_COARSE")) {
+        void *fresh = nullptr;
+        hipError_t ef = hipExtMallocWithFlags(&fresh, s->sync_bytes, hipDeviceMallocFinegrained);
+        if (ef != hipSuccess) return fail(TQGPU_ENODEVICE, std::string("hipExtMallocWithFlags(fine-grained hand-over slab): ") + hipGetErrorString(ef));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        char *ob = static_cast<char *>(s->sync_slab), *nb = static_cast<char *>(fresh);
+        auto mv = [&](auto *&q) { if (q) q = reinterpret_cast<std::remove_reference_t<decltype(q)>>(nb + (reinterpret_cast<char *>(q) - ob)); };
+        PSync &Y = s->psync;
+        mv(Y.sch); mv(Y.dlt); mv(Y.ndt); mv(Y.parts); mv(Y.errs); mv(Y.cmd); mv(Y.vrd); mv(Y.bparts); mv(Y.sgt); mv(Y.rfl); mv(Y.halt); mv(Y.timeout); mv(Y.base); mv(Y.verdict);
+        (void)hipFree(s->sync_slab);
+        s->sync_slab = fresh;
+        s->ps_fine = true;
+        s->pitems_key.clear();                                             /* (a cached batch descriptor would hold the old slab) */
+    }
+    s->export_valid = false;
     s->pshard = true; s->rank = rank; s->nranks = nranks; s->part_top = nranks > 1 ? top : -1;
     s->psync.npeer = nranks;
     s->psync.relay_wg = (rank > 0 && !map.empty()) ? map[0] : -1;          /* ranks without the top workgroup: their first workgroup passes the verdict on to the host */
@@ -3450,6 +3486,7 @@ extern "C" int tqgpu_pshard_begin(tqgpu_solver *s, const tqgpu_opts *o) {
     memset(s->h_res, 0, sizeof(HostRes));
     int launches = 0;
     s->solve_no++;
+    s->export_valid = false;
     return launch_persist(s, O, launches, 1);
 }
 /* launch numbers back to zero and the slab wiped; peers stay connected.  EVERY rank, with no sharded solve in flight anywhere (a barrier
@@ -3556,6 +3593,9 @@ extern "C" int tqgpu_pshard_pack(tqgpu_solver *s, double *out, long cap) {
     SETTLE(s);
     if (!s || !out || !s->pshard) return fail(TQGPU_EINVAL, "tqgpu_pshard_pack: bad arguments");
     HIP_TRY(hipSetDevice(s->device));
+    /* tqgpu_pshard_end returns on the verdict word while the workgroups still write their state back, and the copies below run on the
+     * null stream, which the solver's non-blocking stream does not order: wait for the launch first */
+    HIP_TRY(hipStreamSynchronize(s->stream));
     size_t o = 0;
     for (auto &rg : pshard_owned_ranges(s, s->rank)) {
         if ((long)(o + rg.n) > cap) return fail(TQGPU_EINVAL, "tqgpu_pshard_pack: buffer too small");
@@ -3568,6 +3608,7 @@ extern "C" int tqgpu_pshard_unpack(tqgpu_solver *s, int src_rank, const double *
     SETTLE(s);
     if (!s || !in || !s->pshard || src_rank < 0 || src_rank >= s->nranks) return fail(TQGPU_EINVAL, "tqgpu_pshard_unpack: bad arguments");
     HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));          /* (as tqgpu_pshard_pack: this rank's own write-back must not land on top of the peers' shares) */
     size_t o = 0;
     for (auto &rg : pshard_owned_ranges(s, src_rank)) {
         if ((long)(o + rg.n) > n_in) return fail(TQGPU_EINVAL, "tqgpu_pshard_unpack: buffer too small");

@@ -16,9 +16,10 @@
 #define TQP_W3      0x008   /* k_sg, k_sgp_t, k_hf_w, k_fwd3(c) (tdunes_wide3.hpp) */
 #define TQP_TIER    0x010   /* f_back, f_top, f_fwd, f_stage (tdunes_fast.hpp) */
 #define TQP_PERSIST 0x020   /* f_persist, f_mpersist; sliced by shape: TQ_PERSIST_SLICE of TQ_PERSIST_NSLICES */
-#define TQP_SHARD   0x040   /* f_persist_sh */
+#define TQP_SHARD   0x040   /* f_persist_sh<.., 1>: compiled with -DTQ_LD_SCOPE=__HIP_MEMORY_SCOPE_SYSTEM (polls of a slab that peers write over xGMI) */
 #define TQP_BATCH   0x080   /* f_persist_batch */
-#define TQP_ALL     0x0FF
+#define TQP_SHARD_AG 0x100  /* f_persist_sh<.., 0>: the same kernel with agent-scope polls (A/B on a node) */
+#define TQP_ALL     0x1FF
 
 #ifndef TQ_PARTS
 #define TQ_PARTS TQP_ALL

@@ -151,8 +151,8 @@ __device__ __forceinline__ void pst_word(const PSync &Sy, unsigned *p, unsigned 
 struct PollGuard {
     unsigned h, tmo, cm;
     __device__ __forceinline__ void load(const PSync &Sy) {
-        h = __hip_atomic_load(Sy.halt, RLX, AGENT); tmo = __hip_atomic_load(Sy.timeout, RLX, AGENT);
-        cm = (unsigned)(__hip_atomic_load(Sy.cmd + 1, RLX, AGENT) >> 32);
+        h = __hip_atomic_load(Sy.halt, RLX, TQ_LD_SCOPE); tmo = __hip_atomic_load(Sy.timeout, RLX, TQ_LD_SCOPE);
+        cm = (unsigned)(__hip_atomic_load(Sy.cmd + 1, RLX, TQ_LD_SCOPE) >> 32);
     }
     /* call right after the poll loop: the three guard words are only looked at when the payload is not there yet, so on the
      * usual exit their loads are still in flight as far as the compiler knows; it then waits for them -- with a vmcnt(0)
@@ -172,8 +172,8 @@ struct PollGuard {
 /* why a poll gave up: 1 = the launch is over (halt / timeout), 2 = the top workgroup rejected the trial this pass
  * was built on (the pass is dropped, another trial follows) */
 __device__ __forceinline__ int p_abort_code(const PSync &Sy) {
-    const unsigned h = __hip_atomic_load(Sy.halt, RLX, AGENT), tmo = __hip_atomic_load(Sy.timeout, RLX, AGENT);
-    const unsigned cm = (unsigned)(__hip_atomic_load(Sy.cmd + 1, RLX, AGENT) >> 32);
+    const unsigned h = __hip_atomic_load(Sy.halt, RLX, TQ_LD_SCOPE), tmo = __hip_atomic_load(Sy.timeout, RLX, TQ_LD_SCOPE);
+    const unsigned cm = (unsigned)(__hip_atomic_load(Sy.cmd + 1, RLX, TQ_LD_SCOPE) >> 32);
     return (h == Sy.seq || tmo || cm != Sy.trip) ? 1 : 2;
 }
 /* a tagged record of n doubles posted by the top workgroup (bounded spin; false = the launch is over) */
@@ -185,7 +185,7 @@ __device__ __forceinline__ bool p_read_top(const PSync &Sy, const u64 *src, unsi
         ok = true;
 #pragma unroll
         for (int i = 0; i < N; i++) v[i] = ld_tag(src + 2 * i, tag, ok);
-        const unsigned h = __hip_atomic_load(Sy.halt, RLX, AGENT), tmo = __hip_atomic_load(Sy.timeout, RLX, AGENT);
+        const unsigned h = __hip_atomic_load(Sy.halt, RLX, TQ_LD_SCOPE), tmo = __hip_atomic_load(Sy.timeout, RLX, TQ_LD_SCOPE);
         asm volatile("" :: "v"(h), "v"(tmo));            /* as PollGuard::settle */
         if (ok || h == Sy.seq || tmo) break;
         if (wall_clock64() - t0 > 50000000ull) { pst_word(Sy, Sy.timeout, 1u); break; }
@@ -1050,7 +1050,7 @@ __device__ __forceinline__ bool p_gather_batch(const PSync &Sy, PLds<NX, NU, MD>
                 ok = true;
 #pragma unroll
                 for (int k = 0; k < 8; k++) if (k < K) f[k] = ld_tag(pp + 2 * k, tag, ok);
-                const unsigned h = __hip_atomic_load(Sy.halt, RLX, AGENT), tmo = __hip_atomic_load(Sy.timeout, RLX, AGENT);
+                const unsigned h = __hip_atomic_load(Sy.halt, RLX, TQ_LD_SCOPE), tmo = __hip_atomic_load(Sy.timeout, RLX, TQ_LD_SCOPE);
                 asm volatile("" :: "v"(h), "v"(tmo));    /* as PollGuard::settle */
                 if (ok || h == Sy.seq || tmo) break;
                 if (wall_clock64() - t0 > 50000000ull) { pst_word(Sy, Sy.timeout, 1u); break; }
@@ -1556,14 +1556,14 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
              * workgroups passes it on to the rank's own host, which polls its result block as on a single device */
             const u64 t0v = wall_clock64();
             bool got = true;
-            while ((unsigned)__hip_atomic_load(Sy.verdict + 15, RLX, AGENT) != Sy.seq) {
+            while ((unsigned)__hip_atomic_load(Sy.verdict + 15, RLX, TQ_LD_SCOPE) != Sy.seq) {
                 if (wall_clock64() - t0v > 50000000ull) { got = false; break; }      /* 0.5 s: the top workgroup's rank is gone */
                 __builtin_amdgcn_s_sleep(4);
             }
             if (got) {
                 HostRes *hr = dp->hres;
                 unsigned long long *dst = reinterpret_cast<unsigned long long *>(&hr->c);
-                for (int i = 0; i < (int)(sizeof(Ctrl) / 8); i++) { const u64 wv = __hip_atomic_load(Sy.verdict + i, RLX, AGENT); __hip_atomic_store(dst + i, wv, RLX, SYS); reinterpret_cast<unsigned long long *>(C.ctrl)[i] = wv; }
+                for (int i = 0; i < (int)(sizeof(Ctrl) / 8); i++) { const u64 wv = __hip_atomic_load(Sy.verdict + i, RLX, TQ_LD_SCOPE); __hip_atomic_store(dst + i, wv, RLX, SYS); reinterpret_cast<unsigned long long *>(C.ctrl)[i] = wv; }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __hip_atomic_store(&hr->seq, Sy.seq, RLX, SYS);
             }
@@ -1631,9 +1631,11 @@ __global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_persist(PConst C, Opts O,
 }
 #endif
 /* the same launch as one rank's share of a sharded solve (tqgpu_pshard_*): hand-over words go to every rank's slab */
-template <int NX, int NU, int MD>
+/* SC only tells two builds of the same body apart: 1 = compiled in the part whose polls of the slab are system-scope loads (TQ_LD_SCOPE, tdunes_parts.hpp:
+ * the slab is written by peers over xGMI), 0 = agent-scope polls as on one device (kept for A/B runs on a node: TREEQP_AMD_PSHARD_AGENT=1) */
+template <int NX, int NU, int MD, int SC>
 __global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_persist_sh(PConst C, Opts O, PGeom Gm, PSync Sy, int prologue)
-#if !TQ_HAS(TQP_SHARD)
+#if !TQ_HAS(TQP_SHARD | TQP_SHARD_AG)
 ;
 #else
 {
@@ -1737,7 +1739,12 @@ MSTAGE_TABLE(X)
 #undef X
 #endif
 #if TQ_HAS(TQP_SHARD)
-#define X(idx, nx, nu, md) template __global__ void f_persist_sh<nx, nu, md>(PConst, Opts, PGeom, PSync, int);
+#define X(idx, nx, nu, md) template __global__ void f_persist_sh<nx, nu, md, 1>(PConst, Opts, PGeom, PSync, int);
+SHARD_TABLE(X)
+#undef X
+#endif
+#if TQ_HAS(TQP_SHARD_AG)
+#define X(idx, nx, nu, md) template __global__ void f_persist_sh<nx, nu, md, 0>(PConst, Opts, PGeom, PSync, int);
 SHARD_TABLE(X)
 #undef X
 #endif
