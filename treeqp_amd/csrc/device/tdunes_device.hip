@@ -1732,7 +1732,8 @@ int setup_persist(tqgpu_solver *s, int device) {
     const size_t n_bparts = (size_t)G.G * 16;
     const size_t n_sgt = (size_t)s->Nn * 2, n_rfl = (size_t)s->Nn * 2;      /* active-set signature / reuse flag of a tier subtree root (one tagged double each) */
     const size_t n_verdict = 16;
-    const size_t bytes = (n_sch + n_dlt + n_ndt + n_parts + n_errs + 32 + n_bparts + n_sgt + n_rfl + n_verdict) * sizeof(unsigned long long);
+    const size_t n_anc = (size_t)s->Np * (size_t)(nx0 * s->fMD) * (nx0 + 1) * 2;      /* forward records [z0 | M] of the blocks, for the bottom tier's walk down its path (tdunes_persist.hpp, p_forward_tier) */
+    const size_t bytes = (n_sch + n_dlt + n_ndt + n_parts + n_errs + 32 + n_bparts + n_sgt + n_rfl + n_verdict + n_anc) * sizeof(unsigned long long);
     HIP_TRY(hipMalloc(&s->sync_slab, bytes));
     HIP_TRY(hipMemset(s->sync_slab, 0, bytes));
     HIP_TRY(hipDeviceSynchronize());          /* (a device memset may return before it has happened, and the solver's non-blocking stream does not wait for the null stream) */
@@ -1747,6 +1748,7 @@ int setup_persist(tqgpu_solver *s, int device) {
     s->psync.bparts = s->psync.errs + n_errs + 32;
     s->psync.sgt = s->psync.bparts + n_bparts; s->psync.rfl = s->psync.sgt + n_sgt;
     s->psync.verdict = s->psync.rfl + n_rfl;
+    s->psync.anc = s->psync.verdict + n_verdict;
     s->psync.base = w; s->psync.npeer = 1; s->psync.relay_wg = -1;
     HIP_TRY(hipMalloc(&s->d_peers, 8 * sizeof(unsigned long long *)));
     for (int r = 0; r < 8; r++) s->h_peers[r] = w;
@@ -3408,7 +3410,7 @@ extern "C" int tqgpu_pshard_init(tqgpu_solver *s, int rank, int nranks) {
         char *ob = static_cast<char *>(s->sync_slab), *nb = static_cast<char *>(fresh);
         auto mv = [&](auto *&q) { if (q) q = reinterpret_cast<std::remove_reference_t<decltype(q)>>(nb + (reinterpret_cast<char *>(q) - ob)); };
         PSync &Y = s->psync;
-        mv(Y.sch); mv(Y.dlt); mv(Y.ndt); mv(Y.parts); mv(Y.errs); mv(Y.cmd); mv(Y.vrd); mv(Y.bparts); mv(Y.sgt); mv(Y.rfl); mv(Y.halt); mv(Y.timeout); mv(Y.base); mv(Y.verdict);
+        mv(Y.sch); mv(Y.dlt); mv(Y.ndt); mv(Y.parts); mv(Y.errs); mv(Y.cmd); mv(Y.vrd); mv(Y.bparts); mv(Y.sgt); mv(Y.rfl); mv(Y.halt); mv(Y.timeout); mv(Y.base); mv(Y.verdict); mv(Y.anc);
         (void)hipFree(s->sync_slab);
         s->sync_slab = fresh;
         s->ps_fine = true;

@@ -117,6 +117,7 @@ struct PSync {
                                dynamically indexed member keeps the whole struct in scratch memory -- 18 us per C2 solve.) */
     int npeer;
     u64 *verdict;           /* [16] in the slab: the control block as the top workgroup left it + seq, for the ranks that do not run the top workgroup */
+    u64 *anc;               /* [blocks][D][NX + 1][2]  forward records [z0 | M] of the blocks of tier 1, for the bottom tier's walk down its path (p_forward_tier; tag: pass) */
     int relay_wg;           /* sharded launch without the top workgroup: the workgroup (global number) that passes the verdict on to THIS rank's host, else -1 */
 };
 #define SYS __HIP_MEMORY_SCOPE_SYSTEM
@@ -597,9 +598,16 @@ __device__ __forceinline__ void p_prep_forward(const PLds<NX, NU, MD> &L, int lo
  * from_parent: the step of the subtree root's owner node comes from the parent workgroup (tagged words, polled); otherwise
  * (top workgroup, t0 = 1) the root block's solution is in L.dl already.  to_children: the last level's blocks hand their
  * solution to the tier below as tagged words.  Returns the per-lane terms of res' * dlam of the blocks this wave owns. */
-template <int NX, int NU, int MD>
+/* anc_up > 0 (bottom tier of a tree of three tiers or more, uniform trees): the step of my subtree root is NOT taken from the parent
+ * workgroup.  The tier above has published the forward records [z0 | M] of its blocks (Sy.anc, long before they are needed: right
+ * after its own backward sweep), and this workgroup walks the path through that tier itself, from the step of the tier's subtree
+ * root (which the tier above THAT one posts): anc_up blocks of NX multiply-adds per lane instead of a forward sweep in the parent
+ * workgroup followed by a hand-over -- the hand-over that involves the most workgroups (C2: 64 waiting for 8) and costs ~1.8 us
+ * of a 27 us pass.  Same operands, same order of operations as the parent workgroup's own sweep (which it still runs for its own
+ * stage sweep): the step is bit-identical to the one it would have handed down. */
+template <int NX, int NU, int MD, bool ANC = false>
 __device__ __forceinline__ double p_forward_tier(const PConst &C, const PSync &Sy, const PLds<NX, NU, MD> &L, int l0, int s, int th, int t0, int wave, int lane,
-                                                 bool from_parent, bool to_children, unsigned tag) {
+                                                 bool from_parent, bool to_children, unsigned tag, int anc_up = 0) {
     using U = Uni<NX, NU, MD>;
     constexpr int D = U::D, LDM = PLds<NX, NU, MD>::LDM;
     const int li = lane < D ? lane : 0;
@@ -609,7 +617,50 @@ __device__ __forceinline__ double p_forward_tier(const PConst &C, const PSync &S
     double dv[NX];
     bool ok = true;
     if (from_parent) {
-        const int ii = p_slot_node<NX, NU, MD>(0, l0, s, C);
+        int ii = p_slot_node<NX, NU, MD>(0, l0, s, C);
+        constexpr int AROW = NX * LDM;                   /* one block's slice on my path: NX rows of [z0 | M] */
+        if constexpr (ANC) if (anc_up > 0) {
+            static_assert(U::TH * AROW <= U::WAVE_LDS, "the path through the tier above must fit the wave's scratch");
+            /* the records of my ancestors in the tier above, nearest first: rows cj NX .. of block aj, cj = my path's child ordinal there.
+             * Every wave fetches them into its own scratch (no barrier); they were posted ~8 us ago, the first look finds them. */
+            constexpr int NE = (U::TH * AROW + WAVE - 1) / WAVE;
+            const u64 *rsrc[NE];
+#pragma unroll
+            for (int i = 0; i < NE; i++) {
+                const int e0 = lane + i * WAVE, e = e0 < anc_up * AROW ? e0 : 0;
+                const int j = e / AROW, wq = e - j * AROW;        /* j-th ancestor above my root */
+                int a = ii, cj = 0;
+                for (int q = 0; q <= j; q++) { cj = (a - 1) % MD; a = (a - 1) / MD; }
+                rsrc[i] = Sy.anc + ((size_t)a * D * LDM + (size_t)cj * AROW + wq) * 2;
+            }
+            double rv[NE];
+            const u64 t0a = wall_clock64();
+            if (Sy.nap > 0) {
+                for (;;) {
+                    PollGuard pg;
+                    ok = true;
+#pragma unroll
+                    for (int i = 0; i < NE; i++) rv[i] = ld_tag(rsrc[i], tag, ok);
+                    pg.load(Sy);
+                    if (ok || !pg.go_on(Sy, t0a)) { pg.settle(); break; }
+                    __builtin_amdgcn_s_sleep(31);
+                }
+            } else {
+                for (;;) {
+                    PollGuard pg;
+                    ok = true;
+#pragma unroll
+                    for (int i = 0; i < NE; i++) rv[i] = ld_tag(rsrc[i], tag, ok);
+                    pg.load(Sy);
+                    if (ok || !pg.go_on(Sy, t0a)) { pg.settle(); break; }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NE; i++) { const int e0 = lane + i * WAVE; if (e0 < anc_up * AROW) L.wave[e0] = rv[i]; }
+            lds_fence();
+            for (int q = 0; q < anc_up; q++) ii = (ii - 1) / MD;          /* the subtree root of the tier above: its step is what arrives */
+        }
+        const bool ok_rec = ok;                                          /* (a poll that gave up: the launch is over or the pass is dropped) */
         const u64 *src = Sy.dlt + (size_t)NX * ii * 2;
         /* This wait is most of a pass for the lower tiers (the step comes down only after the whole backward sweep above), and every
          * look of every waiting workgroup is memory traffic in the way of the ones at work.  In a launch of more than ~128
@@ -641,7 +692,20 @@ __device__ __forceinline__ double p_forward_tier(const PConst &C, const PSync &S
                 if (ok || !pg.go_on(Sy, t0c)) { pg.settle(); break; }
             }
         }
-        ok = __all(ok);
+        ok = __all(ok && ok_rec);
+        if constexpr (ANC) if (anc_up > 0) {
+            /* down the path through the tier above: block j's rows of my slice are lanes 0 .. NX - 1 (p_forward_tier's own formula) */
+            const int lr = lane < NX ? lane : 0;
+            for (int j = anc_up - 1; j >= 0; j--) {
+                lds_cptr mr = L.wave + j * AROW + lr * LDM;
+                double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+                for (int r = 0; r < NX; r += 2) { acc0 = fma(mr[1 + r], dv[r], acc0); if (r + 1 < NX) acc1 = fma(mr[2 + r], dv[r + 1], acc1); }
+                const double mine = fma(-1.0, acc0 + acc1, mr[0]);
+#pragma unroll
+                for (int r = 0; r < NX; r++) dv[r] = rdlane(mine, r);
+            }
+        }
         if (!ok) { if (lane == 0) *L.abort = p_abort_code(Sy); }      /* the launch is over or the pass is dropped: nothing below may leave the workgroup */
         else if (wave == 0 && lane == 0) {                           /* the subtree root's own step: the stage sweep reads it from LDS */
 #pragma unroll
@@ -818,7 +882,7 @@ __device__ __forceinline__ bool p_sub_children_tagged(const PSync &Sy, const u64
     const bool vrow = lane == D, need = lane <= D;
     const int lc = lane < D ? lane / NX : 0;
     const int r = lane < D ? lane - lc * NX : 0;
-    const int off = vrow ? NX * NX : r, stride = vrow ? 1 : NX;
+    const int off = vrow ? NX * NX : r, stride = vrow ? 1 : NX;      /* (per load instruction the 16 lanes read 16 consecutive tagged doubles: two lines; the transposed read -- one line per LANE -- measured 5 % slower per C2 solve) */
     double v[MD][NX];
     const u64 t0 = wall_clock64();
     bool ok;
@@ -1080,7 +1144,8 @@ __device__ __forceinline__ bool p_gather_batch(const PSync &Sy, PLds<NX, NU, MD>
 }
 
 /* the life of one workgroup = one tier subtree: tier `tier`, subtree (complete part) or scenario (chain part) `s` */
-template <int NX, int NU, int MD, bool RU, int ROLE = 0, bool FULLTH = false>      /* ROLE: 0 found at run time; 1 bottom tier, 2 a tier in between, 3 top tier (of two or more tiers); FULLTH: the tier has Uni::TH levels */
+template <int NX, int NU, int MD, bool RU, int ROLE = 0, bool FULLTH = false, bool ANC = false>      /* ROLE: 0 found at run time; 1 bottom tier, 2 a tier in between, 3 top tier (of two or more tiers); FULLTH: the tier has Uni::TH levels;
+                                                                                                       * ANC: uniform tree -- with three tiers or more the bottom tier walks down its path through tier 1 itself (p_forward_tier) */
 __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeom &Gm, const PSync &Sy_in, int prologue, int wg, int tier, int s, double *lds_all) {
     using U = Uni<NX, NU, MD>;
     PSync Sy = Sy_in;
@@ -1096,6 +1161,9 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
     Ctrl *c = reinterpret_cast<Ctrl *>((double *)L.ctl);
     const int l0 = Gm.l0[tier], th = FULLTH ? U::TH : Gm.l1[tier] - l0;
     const bool is_top = ROLE == 0 ? tier == Gm.n_tiers - 1 : ROLE == 3, is_bottom = ROLE == 0 ? tier == 0 : ROLE == 1;
+    const bool anc_on = ANC && !RU && Gm.n_tiers >= 3;                 /* tier 1 publishes its forward records, tier 0 walks down its path through them */
+    const bool anc_pub = anc_on && ROLE == 2 && tier == 1;
+    const int anc_up = (anc_on && ROLE == 1) ? U::TH : 0;
     const int nbt = U::first(th);                                      /* my blocks */
     const int nown = nbt + (is_bottom ? U::width(th) : 0);             /* nodes I own */
     const int root_blk = p_slot_node<NX, NU, MD>(0, l0, s, C);         /* subtree root block (= node) */
@@ -1420,11 +1488,20 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
                 if (lane == 0) *L.fvalid = 1;
             }
             lds_barrier();
+            if (anc_pub && !gone) {
+                /* my blocks' forward records to the tier below (it walks down its path through them itself, see p_forward_tier): off the
+                 * critical path -- the tiers above me have their whole backward sweep to do before my step arrives */
+                constexpr int REC = D * PLds<NX, NU, MD>::LDM;
+                for (int i = threadIdx.x; i < nbt * REC; i += FW * WAVE) {
+                    const int loc = i / REC, wq = i - loc * REC;
+                    pst_tag(Sy, Sy.anc + ((size_t)p_slot_node<NX, NU, MD>(loc, l0, s, C) * REC + wq) * 2, L.mz_(loc)[wq], tag_e);
+                }
+            }
         }
 
         /* ---- forward sweep of my subtree, one barrier at its end (the subtree root first waits for the parent workgroup's step) ---- */
         if (verdict != 2) {
-            dotp += p_forward_tier<NX, NU, MD>(C, Sy, L, l0, s, th, is_top ? 1 : 0, wave, lane, !is_top, !is_bottom, tag_e);
+            dotp += p_forward_tier<NX, NU, MD, ANC && !RU>(C, Sy, L, l0, s, th, is_top ? 1 : 0, wave, lane, !is_top, !is_bottom && !anc_pub, tag_e, anc_up);
             lds_barrier();
             if (!is_top && *L.abort) gone = true;                          /* the parent never delivered: the launch is over, or the pass is dropped */
             pstamp(C, O, e, tier, s, sl++);
@@ -1611,9 +1688,9 @@ __device__ __forceinline__ void persist_entry(const PConst &C, const Opts &O, co
      * register limit with ~210 spilled scalars; per role the C2 solve is 10 % faster).  Bottom and middle tiers of a uniform tree
      * always have Uni::TH levels. */
     if (!RU && Gm.n_tiers > 1) {
-        if (tier == 0) p_run<NX, NU, MD, RU, 1, true>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
+        if (tier == 0) p_run<NX, NU, MD, RU, 1, true, true>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
         else if (tier == Gm.n_tiers - 1) p_run<NX, NU, MD, RU, 3>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
-        else p_run<NX, NU, MD, RU, 2, true>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
+        else p_run<NX, NU, MD, RU, 2, true, true>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
         return;
     }
     p_run<NX, NU, MD, RU>(C, O, Gm, Sy, prologue, wg, tier, wg - Gm.wg0[tier], lds_all);
