@@ -2559,11 +2559,25 @@ int read_ctrl(tqgpu_solver *s) {
 
 /* persistent launch: wait for the result block the top workgroup writes into pinned host memory (the
  * kernel may still be writing the state back -- everything else the host does is stream-ordered behind it) */
+/* the block as tagged words (HostRes::tg, posted by the persistent launches): complete when every word carries `want`; unpacked into the fields */
+bool take_tagged_block(HostRes *hr, unsigned want) {
+    volatile unsigned long long *tg = hr->tg;
+    unsigned long long w[HOSTRES_WORDS];
+    for (int i = 0; i < HOSTRES_WORDS; i++) { w[i] = tg[i]; if ((unsigned)(w[i] >> 32) != want) return false; }
+    unsigned *dst = reinterpret_cast<unsigned *>(&hr->c);
+    for (int i = 0; i < 24; i++) dst[i] = (unsigned)w[i];
+    hr->t_start = (w[24] & 0xFFFFFFFFull) | (w[25] << 32);
+    hr->t_end = (w[26] & 0xFFFFFFFFull) | (w[27] << 32);
+    hr->seq = want;
+    return true;
+}
+
 int wait_result_block(tqgpu_solver *s) {
     volatile unsigned *seq = &s->h_res->seq;
     const unsigned want = s->psync.seq;
     const auto t0 = std::chrono::steady_clock::now();
     for (long spins = 0; *seq != want; spins++) {
+        if (take_tagged_block(s->h_res, want)) break;
         __builtin_ia32_pause();
         if ((spins & 0xFFFF) == 0xFFFF && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
             /* no verdict (a wait inside the kernel timed out, or the launch failed): fall back to the stream.  A member of a
@@ -3517,6 +3531,7 @@ extern "C" int tqgpu_pshard_end(tqgpu_solver *s, tqgpu_result *res) {
         volatile unsigned *seq = &s->h_res->seq;
         const auto t0 = std::chrono::steady_clock::now();
         for (long spins = 0; *seq != s->psync.seq; spins++) {
+            if (take_tagged_block(s->h_res, s->psync.seq)) break;          /* (rank 0: the top workgroup's tagged words; the other ranks' relay workgroups post the plain block) */
             __builtin_ia32_pause();
             if ((spins & 0xFFFF) == 0xFFFF && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
         }

@@ -57,10 +57,17 @@
  * holds ONE pointer during the loop (scalar register pressure) */
 /* result block in pinned host memory: the top workgroup writes it the moment the launch is decided, the
  * host polls `seq` -- it does not wait for the other workgroups to leave nor for a stream synchronisation */
+#define HOSTRES_WORDS 28            /* 24 halves of the 12 quadwords of Ctrl, 2 + 2 of t_start, t_end */
 struct HostRes {
     Ctrl c;
     unsigned long long t_start, t_end;      /* 100 MHz wall clock of the top workgroup: launch start, verdict */
     unsigned seq;                           /* == PSync.seq of the launch when the block is complete */
+    unsigned pad;
+    /* The persistent launch posts the block as TAGGED WORDS, the way workgroups talk to each other: word i = (seq << 32) | 32-bit piece i of
+     * {c, t_start, t_end}; the host polls until every word carries the launch's seq and unpacks them into the fields above
+     * (wait_result_block).  One store instruction and its flight instead of: the stores, the wait for their acknowledgements from host
+     * memory (~1.5 us on the verdict's way) and the sequence word behind them. */
+    unsigned long long tg[HOSTRES_WORDS];
 };
 
 struct PDump {
@@ -1600,14 +1607,27 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
     pstamp(C, O, (unsigned)O.stamps, tier, s, 28);                     /* 28: left the loop */
     {
         const PDump *dp = C.dump;
-        if (is_top && threadIdx.x == 0) {
-            /* the verdict goes straight to the host (system-scope stores to pinned memory, then the sequence word) */
+        if (is_top && wave == 0) {
+            /* the verdict goes straight to the host: the control block (it lives in LDS) and the two clock readings as tagged words in
+             * pinned memory, one store per lane, nothing to wait for (see HostRes) */
+            static_assert(sizeof(Ctrl) == 96, "HostRes::tg holds the 24 halves of the control block");
             HostRes *hr = dp->hres;
-            c->n_reg = __hip_atomic_load(&cg->n_reg, RLX, AGENT);
 #ifdef TQ_REUSE_DEBUG
-            c->ls_last = c->pad0;
+            if (lane == 0) c->ls_last = c->pad0;
+            lds_fence();
 #endif
-            *cg = *c;                                                         /* for the next launch and for the stream-ordered readers */
+            const unsigned long long t_end = wall_clock64();
+            const int li = lane < 24 ? lane : 0;
+            unsigned piece = reinterpret_cast<const unsigned *>(c)[li];
+            if (lane == 24) piece = (unsigned)t_start;
+            if (lane == 25) piece = (unsigned)(t_start >> 32);
+            if (lane == 26) piece = (unsigned)t_end;
+            if (lane == 27) piece = (unsigned)(t_end >> 32);
+            if (lane < HOSTRES_WORDS) __hip_atomic_store(hr->tg + lane, ((unsigned long long)Sy.seq << 32) | piece, RLX, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (is_top && threadIdx.x == 0) {
+            /* for the next launch and for the stream-ordered readers (n_reg is counted in global memory by whoever regularises a block: it stays) */
+            { const int keep = __hip_atomic_load(&cg->n_reg, RLX, AGENT); c->n_reg = keep; *cg = *c; }
             const unsigned long long *src = reinterpret_cast<const unsigned long long *>(c);
             if (Sy.npeer > 1) {
                 /* sharded launch: the ranks that do not run this workgroup read the verdict from their own slab once their launch has ended */
@@ -1619,14 +1639,7 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 for (int r = 0; r < Sy.npeer; r++) __hip_atomic_store(Sy.peers[r] + voff + 15, (u64)Sy.seq, RLX, SYS);
             }
-            unsigned long long *dst = reinterpret_cast<unsigned long long *>(&hr->c);
-            for (int i = 0; i < (int)(sizeof(Ctrl) / 8); i++) __hip_atomic_store(dst + i, src[i], RLX, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&hr->t_start, t_start, RLX, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&hr->t_end, (unsigned long long)wall_clock64(), RLX, __HIP_MEMORY_SCOPE_SYSTEM);
-            /* the block is complete once every store above has left the chip: wait for their acknowledgements, then the sequence word.
-             * (NOT a system-scope release: that writes back the whole L2 of this XCD first -- 6 us measured, on the host's critical path) */
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(&hr->seq, Sy.seq, RLX, __HIP_MEMORY_SCOPE_SYSTEM);
+            (void)src;
         }
         if (Sy.npeer > 1 && wg == Sy.relay_wg && threadIdx.x == 0) {
             /* a rank that does not run the top workgroup: the verdict arrives in this rank's slab (pushed by the top workgroup); one of its
