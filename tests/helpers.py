@@ -76,3 +76,36 @@ def flat_to_json(flat: dict, options: dict | None = None) -> dict:
     if options is not None:
         out["options"] = options
     return out
+
+
+def fuzz_case(seed, s0=20000):
+    """Problem and options of case `seed` of the parity campaign `python tools/fuzz_parity.py N s0` (the campaign draws its parameters
+    from ONE generator seeded with s0, case after case: replayed here without building the cases before `seed`)."""
+    import numpy as np
+    from treeqp_amd import problems as P
+    rng = np.random.Generator(np.random.PCG64(s0))
+    for c in range(seed - s0 + 1):
+        sd = s0 + c
+        kind = c % 4
+        last = sd == seed
+        if kind == 0:
+            a = dict(depth=int(rng.integers(2, 6)), max_kids=int(rng.integers(2, 5)), nx_range=(1, int(rng.integers(2, 9))), nu_range=(1, int(rng.integers(1, 5))), ubound=float(rng.choice([0.1, 0.3, 1.0])))
+            f = P.random_shape_qp(sd, **a) if last else None
+        elif kind == 1:
+            nh = int(rng.integers(4, 11))
+            f = P.pruned_chain_qp(Nh=nh, seed=sd) if last else None
+        elif kind == 2:
+            md = int(rng.integers(1, 4)); Nr = int(rng.integers(1, 5)); Nh = Nr + int(rng.integers(0, 4))
+            a = dict(nx=int(rng.choice([2, 4, 8])), nu=int(rng.integers(1, 4)), md=md, Nr=Nr, Nh=Nh, ubound=float(rng.choice([0.2, 0.4, 2.0])))
+            f = P.random_uniform_tree_qp(sd, **a) if last else None
+        else:
+            a = dict(depth=int(rng.integers(2, 4)), max_kids=3, nx_range=(6, 14), nu_range=(2, 6), ubound=float(rng.choice([0.2, 0.5])))
+            f = P.random_shape_qp(sd, **a) if last else None
+        tc, rt = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+    opts = dict(f.opts) if getattr(f, "opts", None) else {}
+    opts.update(termCondition=tc, regType=rt)
+    if tc == 0:
+        opts["stationarityTolerance"] = 1e-12
+    if rt == 1:
+        opts["regValue"] = 1e-8
+    return f, opts

@@ -113,6 +113,7 @@ struct Data {            /* device pointers, passed by value */
     int ls_log_cap;
     /* dense unconstrained stage solver (generic path only; dual_Newton_tree_qpoases.c restricted to no bounds):
      * per node the stage Hessian H = [Q S'; S R] ((nx+nu)^2, column major) and its inverse P = H^-1 */
+    int strict;               /* TREEQP_AMD_STRICT_SUM=1: sums that feed decisions are taken in the reference's order (node by node, block by block), see strict_* below */
     int dense;                /* some nodes use the dense unconstrained stage solver */
     const int *kind;          /* [Nn] per node: 0 clipping, 1 dense unconstrained (read only when dense != 0) */
     const double *Hd;
@@ -431,6 +432,29 @@ __device__ void stage_body(const Tree &T, const Data &D, int mode, int k, int la
     double p_c = 0.0;
     for (int t = lane; t < d; t += WAVE) p_c = fma(D.b[ko + t], lk[t], p_c);
     p_qx = wave_sum(p_qx); p_hx = wave_sum(p_hx); p_ru = wave_sum(p_ru); p_hu = wave_sum(p_hu); p_c = wave_sum(p_c);
+    if (D.strict && nxk + nuk <= WAVE) {
+        /* the node's term from sequential dot products, as eval_dual_term takes them (clipping.c:374-381): lane t holds entry t of
+         * [x | u] (read back from where this wave has just put it), every lane takes the same sums */
+        WSYNC();
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+        const int t = lane < nxk + nuk ? lane : 0;
+        const bool isx = t < nxk;
+        const int j = isx ? t : t - nxk;
+        const double val = isx ? D.x[xo + j] : D.u[uo + j], hm = isx ? D.qmod[xo + j] : D.rmod[uo + j];
+        const double wv = (isx ? D.Qd[xo + j] : D.Rd[uo + j]) * val;
+        double a_qx = 0.0, a_hx = 0.0, a_ru = 0.0, a_hu = 0.0, cm = 0.0;
+        for (int i = 0; i < nxk; i++) { const double vi = __shfl(val, i), wi = __shfl(wv, i), hi = __shfl(hm, i); a_qx = fma(wi, vi, a_qx); a_hx = fma(hi, vi, a_hx); }
+        for (int i = nxk; i < nxk + nuk; i++) { const double vi = __shfl(val, i), wi = __shfl(wv, i), hi = __shfl(hm, i); a_ru = fma(wi, vi, a_ru); a_hu = fma(hi, vi, a_hu); }
+        int off = 0;
+        for (int cc = 0; cc < nkid; cc++) {                 /* cmod += ddot(b_kid, lambda_kid), child after child (dual_Newton_tree.c:892) */
+            const int nxc = T.nx[T.kid0[k] + cc];
+            double acc = 0.0;
+            for (int i = 0; i < nxc; i++) acc = fma(D.b[ko + off + i], lk[off + i], acc);
+            cm += acc;
+            off += nxc;
+        }
+        p_qx = a_qx; p_hx = a_hx; p_ru = a_ru; p_hu = a_hu; p_c = cm;
+    }
     if (lane == 0) {
         double f = -0.5 * p_qx - p_c;       /* clipping.c:375 */
         f += p_hx;                          /* :376 */
@@ -451,6 +475,37 @@ __global__ void __launch_bounds__(WAVE) k_stage(Tree T, Data D, int mode, int h,
 /* ------------------------------------------------------------------------------------------ */
 /* block reductions (one workgroup of 256 threads, fixed pairwise order => deterministic)      */
 /* ------------------------------------------------------------------------------------------ */
+/* Reference-order sums (opt-in: TREEQP_AMD_STRICT_SUM=1, Data::strict).  The reference adds the nodes' dual-function terms one after the other
+ * (evaluate_dual_function, dual_Newton_tree.c:915), takes res' dlam and the squared residual norm as one ddot per dual block, blocks in order
+ * (gradient_trans_times_direction :808-820, calculate_error_in_residuals :412-442), and a node's own term from sequential dot products
+ * (eval_dual_term, dual_Newton_tree_clipping.c:359-382).  The default kernels take all of these as fixed trees (deterministic, but another
+ * order): near the optimum two dual values may then differ in their last bit and an Armijo or termination test goes the other way
+ * (0.6 % of a random campaign).  With the switch on, one thread takes the sums in the reference's order -- slow, for parity work. */
+__device__ double strict_sum(const double *v, int n) {
+    double acc = 0.0;
+    for (int i = 0; i < n; i++) acc += v[i];
+    return acc;
+}
+__device__ double strict_block_dots(const Tree &T, const double *a, const double *b) {
+    double ans = 0.0;
+    for (int p = 0; p < T.Np; p++) {
+        const int o = T.xoff[T.kid0[p]], d = T.bdim[p];
+        double acc = 0.0;
+        for (int i = 0; i < d; i++) acc = fma(a[o + i], b[o + i], acc);
+        ans += acc;
+    }
+    return ans;
+}
+/* a value computed by thread 0 to every thread of the workgroup */
+__device__ double bcast0(double v, double *sh) {
+    __syncthreads();
+    if (threadIdx.x == 0) sh[0] = v;
+    __syncthreads();
+    const double r = sh[0];
+    __syncthreads();
+    return r;
+}
+
 template <bool IS_MAX>
 __device__ double block_reduce(const double *v, int n, double *sh) {
     /* strided per-thread partials, wave shuffle tree, then the (<= 16) wave results in order */
@@ -477,7 +532,7 @@ __device__ double block_reduce(const double *v, int n, double *sh) {
 #if TQ_HAS(TQP_HOST)
 __global__ void __launch_bounds__(256) k_fval_init(Tree T, Data D) {
     __shared__ double sh[256];
-    const double f = block_reduce<false>(D.fval, T.Nn, sh);
+    const double f = D.strict ? bcast0(threadIdx.x == 0 ? strict_sum(D.fval, T.Nn) : 0.0, sh) : block_reduce<false>(D.fval, T.Nn, sh);
     if (threadIdx.x == 0) { D.ctrl->fval0 = f; D.ctrl->fval = f; }
 }
 #endif
@@ -574,7 +629,7 @@ __global__ void __launch_bounds__(256) k_check(Tree T, Data D, Opts O, int h) {
     Ctrl *c = D.ctrl;
     if (!phase_main(c, h)) return;
     double err = (O.termCondition == 2) ? block_reduce<true>(D.part_err + 1, T.Nn - 1, sh)
-                                        : block_reduce<false>(D.part_err + 1, T.Nn - 1, sh);
+                                        : (D.strict ? bcast0(threadIdx.x == 0 ? strict_block_dots(T, D.res, D.res) : 0.0, sh) : block_reduce<false>(D.part_err + 1, T.Nn - 1, sh));
     if (threadIdx.x == 0) {
         if (O.termCondition == 1) err = sqrt(err);
         c->err = err;
@@ -926,7 +981,7 @@ __global__ void __launch_bounds__(256) k_ls_begin(Tree T, Data D, int h) {
     __shared__ double sh[256];
     Ctrl *c = D.ctrl;
     if (!phase_main(c, h)) return;
-    const double s = block_reduce<false>(D.part_dot, T.Np, sh);
+    const double s = D.strict ? bcast0(threadIdx.x == 0 ? strict_block_dots(T, D.res, D.dlam) : 0.0, sh) : block_reduce<false>(D.part_dot, T.Np, sh);
     if (threadIdx.x == 0) {
         const double dotp = -s;                                     /* :819 */
         c->dot = dotp;
@@ -982,12 +1037,12 @@ __global__ void __launch_bounds__(256) k_ls_decide(Tree T, Data D, Opts O, int h
     if (!phase_trial(c, h, t)) return;
     if (with_descent_check) {
         /* fused path: the first trial was evaluated speculatively; test the direction now */
-        const double s = block_reduce<false>(D.part_dot, T.Np, sh);
+        const double s = D.strict ? bcast0(threadIdx.x == 0 ? strict_block_dots(T, D.res, D.dlam) : 0.0, sh) : block_reduce<false>(D.part_dot, T.Np, sh);
         if (threadIdx.x == 0) bail = ls_not_descent(c, -s);
         __syncthreads();
         if (bail) return;
     }
-    const double f = block_reduce<false>(D.fval, T.Nn, sh);
+    const double f = D.strict ? bcast0(threadIdx.x == 0 ? strict_sum(D.fval, T.Nn) : 0.0, sh) : block_reduce<false>(D.fval, T.Nn, sh);
     if (threadIdx.x == 0) ls_decide_tail(c, D, O, f);
 }
 #endif
@@ -1197,6 +1252,7 @@ struct tqgpu_solver {
                                                                            * the lead's stream, to be waited for before this mirror is touched through its own stream (settle) */
     size_t sync_words_bytes = 0, lds_persist = 0;
     /* ONE tree over several devices INSIDE the persistent launch (tqgpu_pshard_*): this rank's share of the workgroups */
+    bool strict_sum = false;        /* TREEQP_AMD_STRICT_SUM=1 (Data::strict) */
     bool pshard = false;
     bool ps_sys = true;             /* the sharded launch polls its slab with system-scope loads (f_persist_sh<.., 1>); TREEQP_AMD_PSHARD_AGENT=1: agent scope, as on one device */
     bool ps_fine = false;           /* the hand-over slab was re-allocated as fine-grained memory (tqgpu_pshard_init; TREEQP_AMD_PSHARD_COARSE=1 keeps plain hipMalloc memory) */
@@ -2012,6 +2068,11 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
         const char *env = getenv("TREEQP_AMD_PATH");
         if (env && strcmp(env, "generic") == 0) { s->use_fast = 0; s->use_gpersist = 0; }
         if (env && strcmp(env, "tiered") == 0) s->use_persist = 0;
+        /* reference-order sums (strict_sum / strict_block_dots): the launch-per-phase kernels and the single-workgroup kernel carry them;
+         * the fused tails, the three-launch family and the persistent / tiered kernels (their partial sums are per workgroup by
+         * construction) stand aside */
+        s->strict_sum = getenv("TREEQP_AMD_STRICT_SUM") && atoi(getenv("TREEQP_AMD_STRICT_SUM")) != 0;
+        if (s->strict_sum) { s->use_fast = 0; s->wide = false; }          /* (the MFMA kernels of the wide-block class sum in tile order) */
         s->use_persist_orig = s->use_persist;
         const char *ch = getenv("TREEQP_AMD_CHUNK");
         if (ch && atoi(ch) > 0) s->chunk = atoi(ch);
@@ -2105,6 +2166,7 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
     D.Sbuf = at<double>(base, o_sbuf); D.ybuf = at<double>(base, o_ybuf);
     D.stamps = at<unsigned long long>(base, o_stamps);
     D.ctrl = at<Ctrl>(base, o_ctrl); D.ls_log = at<int>(base, o_log); D.ls_log_cap = s->ls_log_cap;
+    D.strict = s->strict_sum ? 1 : 0;
     D.dense = 0; s->d_kind = at<int>(base, o_kind); D.kind = s->d_kind; s->d_Hd = at<double>(base, o_Hd); D.Hd = s->d_Hd; D.Pd = at<double>(base, o_Pd); D.poff = at<int>(base, o_poff);
     s->use_fast_orig = s->use_fast;
     s->d_mu_x = at<double>(base, o_mux); s->d_mu_u = at<double>(base, o_muu);
@@ -2138,7 +2200,7 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
         if (hipMalloc(&s->fw_words, bytes) != hipSuccess || hipMemset(s->fw_words, 0, bytes) != hipSuccess)
             return cleanup_fail(fail(TQGPU_ENOMEM, "hipMalloc failed for the forward hand-over words"));
         const char *m = getenv("TREEQP_AMD_FWD");              /* =levels: one launch per tree level (the round-1 protocol) */
-        s->fw_fused = !(m && strcmp(m, "levels") == 0);
+        s->fw_fused = !(m && strcmp(m, "levels") == 0) && !s->strict_sum;      /* (strict: the reference's launch-per-level order of operations) */
         int nxmax = 0;
         for (int k = 0; k < s->Nn; k++) nxmax = std::max(nxmax, s->nx[k]);
         s->sch_rs = (nxmax + 1) * (nxmax + 1);
@@ -2146,8 +2208,8 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
         if (hipMalloc(&s->sch_words, sbytes) != hipSuccess || hipMemset(s->sch_words, 0, sbytes) != hipSuccess)
             return cleanup_fail(fail(TQGPU_ENOMEM, "hipMalloc failed for the Schur hand-over words"));
         m = getenv("TREEQP_AMD_BWD");
-        s->bw_fused = !(m && strcmp(m, "levels") == 0);
-        if (s->Nn <= FUSE_MAX && s->Nn >= 2 && !getenv("TREEQP_AMD_NO_FUSE")) {
+        s->bw_fused = !(m && strcmp(m, "levels") == 0) && !s->strict_sum;      /* (a fused sweep subtracts a child's Schur record AFTER an ALWAYS shift of the diagonal, the reference before it) */
+        if (s->Nn <= FUSE_MAX && s->Nn >= 2 && !getenv("TREEQP_AMD_NO_FUSE") && !s->strict_sum) {
             const size_t rb = sizeof(unsigned long long) * 2 * (size_t)s->Nn;
             if (hipMalloc(&s->fuse_red, rb) != hipSuccess || hipMemset(s->fuse_red, 0, rb) != hipSuccess ||
                 hipMalloc(&s->fuse_cnt, 4 * sizeof(int)) != hipSuccess || hipMemset(s->fuse_cnt, 0, 4 * sizeof(int)) != hipSuccess)
@@ -2155,7 +2217,7 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
             s->fuse_ok = true;
         }
     }
-    if (s->wide && s->fw_fused && s->bw_fused && !getenv("TREEQP_AMD_NO_WIDE3")) {      /* (TREEQP_AMD_FWD / BWD = levels ask for the launch-per-level kernels) */
+    if (s->wide && s->fw_fused && s->bw_fused && !getenv("TREEQP_AMD_NO_WIDE3") && !s->strict_sum) {      /* (TREEQP_AMD_FWD / BWD = levels ask for the launch-per-level kernels) */
         /* the three-launch family of the wide-block class (tdunes_wide3.hpp) */
         int nxmax = 0;
         for (int k = 0; k < Nn; k++) { nxmax = std::max(nxmax, s->nx[k]); if (k < s->Np) s->lds_hf_w = std::max(s->lds_hf_w, wide3_lds(s->bdim[k], k > 0 ? s->nx[k] : 0, s->nx[k] + s->nu[k])); }
@@ -2224,7 +2286,7 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
             bool ok16 = !s->dense && !getenv("TREEQP_AMD_NO_STAGE16");
             for (int k = 0; k < Nn && ok16; k++) ok16 = s->nx[k] + s->nu[k] <= 16 && (size_t)(s->bdim[k] + s->nx[k]) <= per_wave / 4;
             s->gp_small16 = ok16;
-            bool ok8 = !getenv("TREEQP_AMD_NO_STAGE16");          /* eight nodes per wave in the gradient sweep: nx <= 8 everywhere */
+            bool ok8 = !getenv("TREEQP_AMD_NO_STAGE16") && !s->strict_sum;          /* eight nodes per wave in the gradient sweep: nx <= 8 everywhere */
             for (int k = 0; k < Nn && ok8; k++) ok8 = s->nx[k] <= 8;
             s->gp_small8 = ok8;
         }

@@ -230,13 +230,13 @@ __device__ __forceinline__ void g_persist_body(Tree T_in, Data D_in, Opts O, GPa
     /* first sweep at lambda0 (phase S of iteration 0) and fval0 */
     const int win16 = G.lds_wave / 4;           /* LDS per row of 16 lanes in stage_body16 */
     auto stage_sweep = [&](int mode) {
-        if (G.small16) { for (int k0 = 4 * wave; k0 < Nn; k0 += 4 * GP_WAVES) stage_body16(sT, sD, mode, k0, min(4, Nn - k0), lane, lds, win16, !G.const_in_lds); }
+        if (G.small16 && !sD.strict) { for (int k0 = 4 * wave; k0 < Nn; k0 += 4 * GP_WAVES) stage_body16(sT, sD, mode, k0, min(4, Nn - k0), lane, lds, win16, !G.const_in_lds); }
         else for (int k = wave; k < Nn; k += GP_WAVES) stage_body(sT, sD, mode, k, lane, lds, !G.const_in_lds);
     };
     stage_sweep(0);
     __syncthreads();
     {
-        const double f = block_reduce<false>(sD.fval, Nn, sh);
+        const double f = sD.strict ? bcast0(threadIdx.x == 0 ? strict_sum(sD.fval, Nn) : 0.0, sh) : block_reduce<false>(sD.fval, Nn, sh);
         if (threadIdx.x == 0) { c->fval0 = f; c->fval = f; }
     }
     __syncthreads();
@@ -248,7 +248,8 @@ __device__ __forceinline__ void g_persist_body(Tree T_in, Data D_in, Opts O, GPa
         else for (int k = 1 + wave; k < Nn; k += GP_WAVES) grad_body(sT, sD, O.termCondition, k, lane, !G.const_in_lds);
         __syncthreads();
         {
-            double err = (O.termCondition == 2) ? block_reduce<true>(sD.part_err + 1, Nn - 1, sh) : block_reduce<false>(sD.part_err + 1, Nn - 1, sh);
+            double err = (O.termCondition == 2) ? block_reduce<true>(sD.part_err + 1, Nn - 1, sh)
+                                                : (sD.strict ? bcast0(threadIdx.x == 0 ? strict_block_dots(sT, sD.res, sD.res) : 0.0, sh) : block_reduce<false>(sD.part_err + 1, Nn - 1, sh));
             if (threadIdx.x == 0) {
                 if (O.termCondition == 1) err = sqrt(err);
                 c->err = err;
@@ -282,7 +283,7 @@ __device__ __forceinline__ void g_persist_body(Tree T_in, Data D_in, Opts O, GPa
 
         /* ---- L: direction test, then Armijo backtracking; every trial is a full stage sweep (:922-1019) ---- */
         {
-            const double s = block_reduce<false>(sD.part_dot, Np, sh);
+            const double s = sD.strict ? bcast0(threadIdx.x == 0 ? strict_block_dots(sT, sD.res, sD.dlam) : 0.0, sh) : block_reduce<false>(sD.part_dot, Np, sh);
             if (threadIdx.x == 0) {
                 const double dotp = -s;
                 c->dot = dotp;
@@ -296,7 +297,7 @@ __device__ __forceinline__ void g_persist_body(Tree T_in, Data D_in, Opts O, GPa
         for (;;) {
             stage_sweep(1);
             __syncthreads();
-            const double f = block_reduce<false>(sD.fval, Nn, sh);
+            const double f = sD.strict ? bcast0(threadIdx.x == 0 ? strict_sum(sD.fval, Nn) : 0.0, sh) : block_reduce<false>(sD.fval, Nn, sh);
             if (threadIdx.x == 0) { ls_decide_tail(c, sD, O, f); flag = c->ls_pending; }
             __syncthreads();
             if (!flag) break;
