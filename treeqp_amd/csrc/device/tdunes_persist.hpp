@@ -623,6 +623,18 @@ __device__ __forceinline__ double p_forward_tier(const PConst &C, const PSync &S
     const int w = active ? wave : 0;
     double dv[NX];
     bool ok = true;
+#ifndef TQ_POLL_ALL_WAVES
+    if (from_parent && wave != 0) {
+        /* only wave 0 looks for the step; the others take it from LDS behind a barrier.  Every look of every waiting wave goes to the memory
+         * side and is in the way of the words the working workgroups post: with a quarter of the looks a C2 solve went from 99.1 to
+         * 95.5 us, C3 from 131.5 to 123.1 (two looks in flight per wave instead -- samples half a round trip apart -- measured 2.5 %
+         * SLOWER) */
+        lds_barrier();
+        ok = *L.abort == 0;
+#pragma unroll
+        for (int r = 0; r < NX; r++) dv[r] = L.droot[r];
+    } else
+#endif
     if (from_parent) {
         int ii = p_slot_node<NX, NU, MD>(0, l0, s, C);
         constexpr int AROW = NX * LDM;                   /* one block's slice on my path: NX rows of [z0 | M] */
@@ -718,6 +730,9 @@ __device__ __forceinline__ double p_forward_tier(const PConst &C, const PSync &S
 #pragma unroll
             for (int r = 0; r < NX; r++) L.droot[r] = dv[r];
         }
+#ifndef TQ_POLL_ALL_WAVES
+        lds_barrier();
+#endif
     } else if (t0 < th) {
         /* top workgroup: parent of my level-t0 block is the block above it (level t0 - 1), solved already */
         const int bpar = w / U::width(th - t0), cpar = (w / U::width(th - 1 - t0)) % MD;     /* parent's number on its level, my ordinal among its children */
