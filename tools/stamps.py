@@ -14,7 +14,7 @@ os.environ.setdefault("TREEQP_AMD_STAMPS", "2")      # persistent path: the laun
 from treeqp_amd import capi, problems as P
 
 Nr = int(sys.argv[1]) if len(sys.argv) > 1 else 9
-p = P.linear_chain(2, Nr, Nr)
+p = P.spring_mass() if os.environ.get("STAMPS_CASE") == "C1" else P.linear_chain(2, Nr, Nr)
 nk = p.nk()
 nx = np.full(p.Nn, p.nx, dtype=np.int32)
 nu = np.where(nk > 0, p.nu, 0).astype(np.int32)
