@@ -139,10 +139,13 @@ def critical_path(g, p_levels: int, n_tiers: int, reps: int = 60, floors_apply: 
            "note": "pass = G+H, backward sweep (one dependent block factorisation per level), forward sweep, trial sweep; "
                    "fixed = launch, state load, first sweep, last verdict, write-back"}
     if back and floors_apply:
-        floor = (p_levels * back + n_tiers * (fwd or 0.0) + sg) / (CLOCK_GHZ * 1e3) + 2 * (n_tiers - 1) * handover_us
+        # hand-overs per pass: one per tier boundary on the way up; on the way down the bottom tier of a tree of three tiers or more
+        # walks through tier 1 itself (round 4: tdunes_persist.hpp, p_forward_tier), i.e. one boundary less
+        handovers = 2 * (n_tiers - 1) - (1 if n_tiers >= 3 else 0)
+        floor = (p_levels * back + n_tiers * (fwd or 0.0) + sg) / (CLOCK_GHZ * 1e3) + handovers * handover_us
         out.update({"floor_us": floor, "achieved_over_floor": (t2 - t1) / floor,
                     "floor_terms": {"backward_level_cycles": back, "forward_tier_cycles": fwd, "stage_plus_gh_cycles": sg,
-                                    "handover_us": handover_us, "handovers": 2 * (n_tiers - 1)},
+                                    "handover_us": handover_us, "handovers": handovers},
                     "floor_source": "profiles/r03_v1_level_bench.txt (tools/microbench/level_bench on MI355X), cycles at 2.4 GHz"})
     return out
 

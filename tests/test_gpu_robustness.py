@@ -591,3 +591,27 @@ def test_reference_order_sums_decide_like_the_oracle(gpu, orc, monkeypatch, seed
     r2 = g2.solve(**opts)
     assert r2["status"] == 0
     g2.close()
+
+
+@pytest.mark.gpu
+def test_not_descent_exit_of_the_merged_launch_leaves_the_phase_s_iterate(gpu, orc, monkeypatch):
+    """NOT_DESCENT_DIRECTION out of k_sgp mode 2 (forward sweep + first trial in one launch): the trial sweep has run before the
+    direction test, the reference returns from line_search with the phase-S iterate at lambda (dual_Newton_tree.c:944-954).  The device
+    restores it with one stage sweep at the current duals: x, u, lambda equal the launch-per-phase kernels', bit for bit (NaN where the
+    NaN datum reaches)."""
+    f = P.pruned_chain_qp(seed=11)
+    flat = {k: np.array(v, copy=True) for k, v in f.as_dict().items()}
+    flat["q"][len(flat["q"]) // 2] = np.nan
+    assert orc.solve(flat, lambda0=f.lambda0)["status"] == 2
+    sols = {}
+    for label in ("three launches", "launch per phase"):
+        if label == "launch per phase":
+            monkeypatch.setenv("TREEQP_AMD_NO_WIDE3", "1")
+        g = gpu.TqGpu(flat["nk"], flat["nx"], flat["nu"]).upload(flat, f.lambda0)
+        assert g.path == 0
+        r = g.solve()
+        assert r["status"] == 2 and r["iter"] == 0
+        sols[label] = g.solution()
+        g.close()
+    for key in ("x", "u", "lam"):
+        assert np.array_equal(sols["three launches"][key], sols["launch per phase"][key], equal_nan=True), key

@@ -2918,6 +2918,15 @@ int solve_end(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, tqgpu_result *
     res->n_launches = launches; res->device_time = 1e-3 * ms; res->last_error_norm = c.err; res->last_fval = c.fval;
     s->last_iter = c.iter;
     s->last_ls_extra = c.ls_total > c.iter ? 1 : 0;
+    if (s->w3_now && s->w3_merge && c.status == 2 && s->T.Np > 1) {
+        /* NOT_DESCENT_DIRECTION out of the merged launch (k_sgp mode 2: forward sweep + first trial): the trial sweep ran before the
+         * direction test and has put x, u, xUnc, QinvCal of the point lambda + dlambda in place.  The reference returns from
+         * line_search with the phase-S iterate at lambda (dual_Newton_tree.c:944-954): one stage sweep at the current duals (which the
+         * trial did not touch: it wrote the other buffer) restores exactly that -- same arithmetic, operation for operation. */
+        hipLaunchKernelGGL(k_stage, dim3(s->T.Nn), dim3(WAVE), s->lds_stage, st, s->T, s->D, 0, 0, 0);
+        launches++; res->n_launches = launches;
+        s->stream_pending = true;
+    }
     if (s->w3_now) {
         s->ls_pred.clear();
         if (c.status == 0 && c.ls_total > c.iter) {

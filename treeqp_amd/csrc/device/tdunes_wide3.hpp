@@ -563,7 +563,7 @@ __global__ void __launch_bounds__(WT) k_sgp_t(Tree T, Data D, Opts O, W3 Wd, int
                 if (lane < nxc) {                       /* (nx <= 64) */
                     const int i = lane;
                     double xk;
-                    if (kid < T.Np) { bool dead = false; xk = wait_tag(Wd.xu + 2 * (size_t)(xo + i), Wd.tag, dead); if (dead) { c->status = 3; __hip_atomic_store(&c->done, 1, RLX, AGENT); } }
+                    if (kid < T.Np) { bool dead = false; xk = wait_tag(Wd.xu + 2 * (size_t)(xo + i), Wd.tag, dead); if (dead) { c->status = 3; __hip_atomic_store(&c->done, 1, RLX, AGENT); __hip_atomic_store(Wd.cnt + 1, (int)Wd.tag, RLX, AGENT); } }      /* (cnt[1]: a bounded wait of THIS launch gave up -- the tail of a fresh first sweep zeroes the control block) */
                     else xk = xkl[rowoff + i];
                     double rv = fma(-1.0, xk, bl[rowoff + i]);
                     double acc = 0.0;
@@ -603,7 +603,11 @@ __global__ void __launch_bounds__(WT) k_sgp_t(Tree T, Data D, Opts O, W3 Wd, int
     if (lane == 0) {
         bool test = true;
         if (mode == 0) {
-            if (fresh) { Ctrl z{}; *c = z; }          /* a new solve: the control block starts from zero (k_hf_w counts regularised blocks into it) */
+            if (fresh) {          /* a new solve: the control block starts from zero (k_hf_w counts regularised blocks into it) */
+                const bool gave_up = __hip_atomic_load(Wd.cnt + 1, RLX, AGENT) == (int)Wd.tag;          /* ... unless a wait of this very launch timed out */
+                Ctrl z{}; *c = z;
+                if (gave_up) { c->status = 3; c->done = 1; }
+            }
             c->fval0 = f; c->fval = f;
         }
         else if (fwd) {
@@ -766,8 +770,12 @@ __global__ void __launch_bounds__(WT, TQ_W3_WPS) k_hf_w(Tree T, Data D, Opts O, 
     int e[28];
 #pragma unroll
     for (int i = 0; i < 28; i++) e[i] = T.desc[(size_t)DESC_INTS * ii + i];
-    if (!phase_main(D.ctrl, h)) return;
+    /* is this launch due?  ONE thread looks and the workgroup takes its answer: another workgroup may end the solve (a wait that gave up)
+     * while this one starts, and waves that looked for themselves could disagree about leaving before a barrier */
+    __shared__ int due;
+    if (tid == 0) due = phase_main(D.ctrl, h) ? 1 : 0;
     W3_BARRIER();
+    if (!due) return;
     int wave;
     {
 #ifdef TQ_W3_NO_ROT
