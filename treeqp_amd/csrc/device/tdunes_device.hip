@@ -1805,7 +1805,7 @@ int setup_persist(tqgpu_solver *s, int device) {
     s->psync.sgt = s->psync.bparts + n_bparts; s->psync.rfl = s->psync.sgt + n_sgt;
     s->psync.verdict = s->psync.rfl + n_rfl;
     s->psync.anc = s->psync.verdict + n_verdict;
-    s->psync.base = w; s->psync.npeer = 1; s->psync.relay_wg = -1;
+    s->psync.base = w; s->psync.npeer = 1; s->psync.relay_wg = -1; s->psync.anc_local = 1;
     HIP_TRY(hipMalloc(&s->d_peers, 8 * sizeof(unsigned long long *)));
     for (int r = 0; r < 8; r++) s->h_peers[r] = w;
     HIP_TRY(hipMemcpy(s->d_peers, s->h_peers, sizeof(s->h_peers), hipMemcpyHostToDevice));
@@ -3504,6 +3504,7 @@ extern "C" int tqgpu_pshard_init(tqgpu_solver *s, int rank, int nranks) {
     s->export_valid = false;
     s->pshard = true; s->rank = rank; s->nranks = nranks; s->part_top = nranks > 1 ? top : -1;
     s->psync.npeer = nranks;
+    s->psync.anc_local = (nranks == 1 || top >= 1) ? 1 : 0;          /* tiers 0 .. top are dealt over the ranks by contiguous subtree ranges: with top >= 1 a tier-1 workgroup sits with the bottom-tier workgroups below it */
     s->psync.relay_wg = (rank > 0 && !map.empty()) ? map[0] : -1;          /* ranks without the top workgroup: their first workgroup passes the verdict on to the host */
     for (int r = 0; r < 8; r++) s->h_peers[r] = s->psync.base;             /* until connected: own slab */
     HIP_TRY(hipMemcpy(s->d_peers, s->h_peers, sizeof(s->h_peers), hipMemcpyHostToDevice));

@@ -126,6 +126,7 @@ struct PSync {
     u64 *verdict;           /* [16] in the slab: the control block as the top workgroup left it + seq, for the ranks that do not run the top workgroup */
     u64 *anc;               /* [blocks][D][NX + 1][2]  forward records [z0 | M] of the blocks of tier 1, for the bottom tier's walk down its path (p_forward_tier; tag: pass) */
     int relay_wg;           /* sharded launch without the top workgroup: the workgroup (global number) that passes the verdict on to THIS rank's host, else -1 */
+    int anc_local;          /* sharded launch: tier 1 is dealt over the ranks like tier 0 (a tier-1 workgroup and the bottom-tier workgroups below it share a rank): its forward records stay in this rank's slab */
 };
 #define SYS __HIP_MEMORY_SCOPE_SYSTEM
 /* a tagged double to every slab of a sharded launch */
@@ -1516,7 +1517,9 @@ __device__ __forceinline__ void p_run(const PConst &C, const Opts &O, const PGeo
                 constexpr int REC = D * PLds<NX, NU, MD>::LDM;
                 for (int i = threadIdx.x; i < nbt * REC; i += FW * WAVE) {
                     const int loc = i / REC, wq = i - loc * REC;
-                    pst_tag(Sy, Sy.anc + ((size_t)p_slot_node<NX, NU, MD>(loc, l0, s, C) * REC + wq) * 2, L.mz_(loc)[wq], tag_e);
+                    u64 *dst = Sy.anc + ((size_t)p_slot_node<NX, NU, MD>(loc, l0, s, C) * REC + wq) * 2;
+                    if (Sy.anc_local) st_tag(dst, L.mz_(loc)[wq], tag_e);          /* (16 KB per workgroup and pass: not over xGMI to ranks that never read them) */
+                    else pst_tag(Sy, dst, L.mz_(loc)[wq], tag_e);
                 }
             }
         }
@@ -1731,7 +1734,7 @@ __global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_persist(PConst C, Opts O,
 #else
 {
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
-    Sy.npeer = 1; Sy.relay_wg = -1;          /* one device: a compile-time fact here, so that the stores to peer slabs and the verdict relay fold away (left as run-time tests they cost 18 us per C2 solve: scalar registers) */
+    Sy.npeer = 1; Sy.relay_wg = -1; Sy.anc_local = 1;          /* one device: a compile-time fact here, so that the stores to peer slabs and the verdict relay fold away (left as run-time tests they cost 18 us per C2 solve: scalar registers) */
     persist_entry<NX, NU, MD, RU>(C, O, Gm, Sy, prologue, (int)blockIdx.x, lds_all);
 }
 #endif
@@ -1778,7 +1781,7 @@ __global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_mpersist(PConst C, Opts O
 #else
 {
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
-    Sy.npeer = 1; Sy.relay_wg = -1;
+    Sy.npeer = 1; Sy.relay_wg = -1; Sy.anc_local = 1;
     mpersist_entry<NX, NU, MD, RU>(C, O, Gm, Sy, prologue, (int)blockIdx.x, lds_all);
 }
 #endif
@@ -1803,7 +1806,7 @@ __global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_persist_batch(const PItem
     PSync Sy = it->Sy;
     Sy.seq = seq;
     Sy.nap = nap;
-    Sy.npeer = 1; Sy.relay_wg = -1;
+    Sy.npeer = 1; Sy.relay_wg = -1; Sy.anc_local = 1;
     if (MSTAGE) mpersist_entry<NX, NU, MD, false>(C, O, Gm, Sy, 1, b, lds_all);
     else persist_entry<NX, NU, MD, false>(C, O, Gm, Sy, 1, b, lds_all);
 }
