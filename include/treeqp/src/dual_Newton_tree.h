@@ -52,7 +52,8 @@ typedef struct stage_qp_fcn_ptrs_ {
 typedef struct treeqp_tdunes_opts_t_ {
     int maxIter;
     stage_qp_t *qp_solver;          /* per node */
-    int checkLastActiveSet;         /* accepted; the device path always rebuilds (bit-identical result) */
+    int checkLastActiveSet;         /* 0 / 1 (the reference's default): every block is rebuilt every iteration, which is bit-identical to the reference's skip logic;
+                                     * 2: the persistent kernels keep the factors of workgroups whose active set did not change ("Active-set reuse") */
     double stationarityTolerance;
     termination_t termCondition;
     regType_t regType;
