@@ -11,7 +11,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS S
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/$TAG/pmc_${W}_$i -o p -- python3 bench.py --workload $W --steps 20 --warmup 5 --no-cpu-baseline --no-batched > gpurun_out/$TAG/pmc_${W}_$i.log 2>&1 || echo "pmc pass $i failed"
 done
-python tools/pmc_aggregate.py gpurun_out/$TAG | grep -v "rocclr" > gpurun_out/$TAG/${W}_pmc.txt
+python tools/pmc_aggregate.py gpurun_out/$TAG --prefix pmc_${W}_ | grep -v "rocclr" > gpurun_out/$TAG/${W}_pmc.txt
 head -12 gpurun_out/$TAG/${W}_kernel_stats.csv
 grep -E "FETCH_SIZE|WRITE_SIZE" gpurun_out/$TAG/${W}_pmc.txt
 python -c "

@@ -1,12 +1,17 @@
 """Aggregate rocprofv3 --pmc counter CSVs (<dir>/**/*counter_collection.csv) per kernel and counter.
-Usage: python tools/pmc_aggregate.py <dir> [COUNTER]   (no counter: every counter found, per kernel: calls, total, per call)"""
+Usage: python tools/pmc_aggregate.py <dir> [COUNTER] [--prefix pmc_C2_]   (no counter: every counter found, per kernel: calls, total, per call;
+--prefix: only the pass directories <dir>/<prefix>* -- one workload's passes when several workloads share <dir>)"""
 import csv, glob, re, sys
 from collections import defaultdict
 
-d = sys.argv[1]
-only = sys.argv[2] if len(sys.argv) > 2 else None
+args = sys.argv[1:]
+prefix = ""
+if "--prefix" in args:
+    k = args.index("--prefix"); prefix = args[k + 1]; args = args[:k] + args[k + 2:]
+d = args[0]
+only = args[1] if len(args) > 1 else None
 acc = defaultdict(lambda: [0, 0.0])
-for f in sorted(glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)):
+for f in sorted(glob.glob(f"{d}/{prefix}*/**/*counter_collection.csv", recursive=True) if prefix else glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)):
     with open(f) as fh:
         for row in csv.DictReader(fh):
             c = row.get("Counter_Name")
