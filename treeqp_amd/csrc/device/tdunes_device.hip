@@ -875,6 +875,102 @@ __device__ void factor_body(const Tree &T, const Data &D, const Opts &O, int ii,
     }
 }
 
+/* factor_body for NG small blocks of one level AT ONCE in one wave (the single-workgroup kernel, trees whose levels are wider than its 16
+ * waves: the chains of a pruned scenario tree are 27 - 40 blocks of 8 x 8 on every level): the wave is split into NG groups of 64 / NG
+ * lanes, group g works on block ii0 + g in its own LDS window with factor_body's loops (lane -> lane within the group, stride -> the
+ * group's width).  A block step is a chain of LDS and memory round trips around a handful of multiply-adds -- ~8 us whatever the
+ * block's size -- and three of them side by side take the time of one.  Per block the arithmetic is factor_body's operation for
+ * operation (bit-identical results).  All blocks of a call have the same d and nx (the caller checks), d + 1 + nx <= 64 / NG. */
+template <int NG, int DC = 0, int NXC = 0>      /* DC, NXC > 0: the blocks' dimensions, known at compile time (index arithmetic without divisions, loops unrolled) */
+__device__ void factor_body_g(const Tree &T, const Data &D, const Opts &O, int ii0, int nblk, int lane, double *lds, int win) {
+    constexpr int GW = WAVE / NG;
+    Ctrl *c = D.ctrl;
+    const int g = lane / GW, l = lane - g * GW;
+    const bool act = g < NG && g < nblk;
+    const int ii = ii0 + (act ? g : 0);
+    const int d = DC > 0 ? DC : T.bdim[ii], nxi = NXC > 0 ? NXC : T.nx[ii];
+    const int R = d + 1 + nxi, ld = R | 1;
+    double *Tm = lds + (size_t)(g < NG ? g : 0) * win;      /* ld x d */
+    double *invd = Tm + (size_t)ld * d;                     /* d */
+    const double *W = D.W + T.woff[ii];
+    const int bo = T.xoff[T.kid0[ii]];
+    const double *Ut = D.Ut + T.utoff[ii];
+    bool redo = true;                       /* pass 1 (on-the-fly regularisation) only touches the groups whose block needs it */
+    for (int pass = 0; pass < 2; pass++) {
+        if (redo) {
+            for (int e = l; e < d * d; e += GW) {
+                const int i = e % d, j = e / d;
+                double w = W[i + (size_t)j * d];
+                if (i == j && (O.regType == 1 || pass == 1)) w += O.regValue;   /* ddiare */
+                Tm[i + (size_t)j * ld] = w;
+            }
+            for (int j = l; j < d; j += GW) Tm[d + (size_t)j * ld] = D.resMod[bo + j];
+            for (int e = l; e < nxi * d; e += GW) {
+                const int i = e % nxi, j = e / nxi;
+                Tm[d + 1 + i + (size_t)j * ld] = Ut[i + (size_t)j * nxi];
+            }
+        }
+        WSYNC();
+        for (int j = 0; j < d; j++) {           /* tall_potrf, per group */
+            if (redo) for (int i = j + l; i < R; i += GW) {
+                double s = Tm[i + (size_t)j * ld];
+                for (int k = 0; k < j; k++) s = fma(-Tm[i + (size_t)k * ld], Tm[j + (size_t)k * ld], s);
+                Tm[i + (size_t)j * ld] = s;
+            }
+            WSYNC();
+            const double cjj = Tm[j + (size_t)j * ld];
+            const double finv = cjj > 0.0 ? 1.0 / sqrt(cjj) : 0.0;      /* pivot <= 0 -> zero column */
+            if (redo) {
+                for (int i = j + l; i < R; i += GW) Tm[i + (size_t)j * ld] *= finv;
+                if (l == 0) invd[j] = finv;
+            }
+            WSYNC();
+        }
+        if (O.regType != 2 || pass == 1) break;
+        /* on-the-fly Levenberg-Marquardt, block by block: any diagonal entry <= regTol -> shift and refactorise THAT block */
+        int small = 0;
+        for (int j = l; j < d; j += GW) small |= (Tm[j + (size_t)j * ld] <= O.regTol);
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(small != 0);
+        const unsigned long long gmask = (GW == 64 ? ~0ull : ((1ull << GW) - 1ull)) << (g < NG ? g * GW : 0);
+        redo = g < NG && (bal & gmask) != 0ull;
+        if (bal == 0ull) break;
+        if (redo && act && l == 0) atomicAdd(&c->n_reg, 1);
+        WSYNC();
+    }
+    if (!act) return;
+    /* outputs: factor, reciprocal diagonal */
+    double *L = D.CholW + T.woff[ii];
+    for (int e = l; e < d * d; e += GW) {
+        const int i = e % d, j = e / d;
+        if (i >= j) L[i + (size_t)j * d] = Tm[i + (size_t)j * ld];
+    }
+    for (int j = l; j < d; j += GW) D.invd[bo + j] = invd[j];
+    for (int j = l; j < d; j += GW) D.dlam[bo + j] = Tm[d + (size_t)j * ld];
+    double *CUt = D.CholUt + T.utoff[ii];
+    for (int e = l; e < nxi * d; e += GW) {
+        const int i = e % nxi, j = e / nxi;
+        CUt[i + (size_t)j * nxi] = Tm[d + 1 + i + (size_t)j * ld];
+    }
+    /* Schur complement into the parent's diagonal sub-block and right-hand side.  (Fetching a lane's entries in one batch before updating them
+     * -- the loop below is a memory round trip per trip -- measured SLOWER: 235 against 180 us per backward sweep of a 308-node tree; the
+     * kernel has no registers to hold a batch in.) */
+    const int dd = T.dad[ii], pos = T.pos[ii], ddim = T.bdim[dd];
+    double *Wd = D.W + T.woff[dd];
+    const int xo = T.xoff[ii];
+    for (int e = l; e < nxi * nxi; e += GW) {
+        const int i = e % nxi, j = e / nxi;
+        if (i < j) continue;
+        double acc = 0.0;
+        for (int cidx = 0; cidx < d; cidx++) acc = fma(Tm[d + 1 + i + (size_t)cidx * ld], Tm[d + 1 + j + (size_t)cidx * ld], acc);
+        Wd[(pos + i) + (size_t)(pos + j) * ddim] -= acc;
+    }
+    for (int i = l; i < nxi; i += GW) {
+        double acc = 0.0;
+        for (int cidx = 0; cidx < d; cidx++) acc = fma(Tm[d + 1 + i + (size_t)cidx * ld], Tm[d + (size_t)cidx * ld], acc);
+        D.resMod[xo + i] -= acc;
+    }
+}
+
 #if TQ_HAS(TQP_HOST)
 __global__ void __launch_bounds__(WAVE) k_factor(Tree T, Data D, Opts O, int first, int h) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -941,6 +1037,56 @@ __device__ void forward_body(const Tree &T, const Data &D, int ii, int lane, dou
     }
     pd = wave_sum(pd);
     if (lane == 0) D.part_dot[ii] = pd;
+}
+
+/* forward_body for NG blocks of one level side by side in one wave (see factor_body_g); the partial of res' dlam of every block is taken with the
+ * lanes arranged as forward_body has them (entry j in lane j), so that it comes out bit-identical */
+template <int NG>
+__device__ void forward_body_g(const Tree &T, const Data &D, int ii0, int nblk, int lane, double *lds, int win) {
+    constexpr int GW = WAVE / NG;
+    const int g = lane / GW, l = lane - g * GW;
+    const bool act = g < NG && g < nblk;
+    const int ii = ii0 + (act ? g : 0);
+    const int d = T.bdim[ii], nxi = T.nx[ii], ld = d | 1;
+    double *L = lds + (size_t)(g < NG ? g : 0) * win;      /* ld x d */
+    double *z = L + (size_t)ld * d;       /* d */
+    double *dl = z + d;                   /* nxi */
+    double *iv = dl + nxi;                /* d */
+    const int bo = T.xoff[T.kid0[ii]], xo = T.xoff[ii];
+    const double *Lg = D.CholW + T.woff[ii];
+    for (int e = l; e < d * d; e += GW) {
+        const int i = e % d, j = e / d;
+        if (i >= j) L[i + (size_t)j * ld] = Lg[i + (size_t)j * d];
+    }
+    for (int j = l; j < d; j += GW) iv[j] = D.invd[bo + j];
+    for (int i = l; i < nxi; i += GW) dl[i] = D.dlam[xo + i];
+    WSYNC();
+    const double *CUt = D.CholUt + T.utoff[ii];
+    for (int j = l; j < d; j += GW) {
+        double acc = 0.0;
+        for (int i = 0; i < nxi; i++) acc = fma(CUt[i + (size_t)j * nxi], dl[i], acc);
+        z[j] = fma(-1.0, acc, D.dlam[bo + j]);
+    }
+    for (int k = d - 1; k >= 0; k--) {
+        WSYNC();
+        const double zk = z[k] * iv[k];
+        for (int i = l; i < k; i += GW) z[i] = fma(-L[k + (size_t)i * ld], zk, z[i]);
+        WSYNC();
+        if (l == 0) z[k] = zk;
+    }
+    WSYNC();
+    double term = 0.0;
+    for (int j = l; j < d; j += GW) {          /* (d <= GW: one trip) */
+        if (act) D.dlam[bo + j] = z[j];
+        term = fma(D.res[bo + j], z[j], term);
+    }
+#pragma unroll
+    for (int gg = 0; gg < NG; gg++) {
+        double v = __shfl(term, gg * GW + (lane < d ? lane : 0));
+        v = lane < d ? v : 0.0;
+        const double pd = wave_sum(v);
+        if (lane == 0 && gg < nblk) D.part_dot[ii0 + gg] = pd;
+    }
 }
 
 #if TQ_HAS(TQP_HOST)
@@ -2319,8 +2465,33 @@ extern "C" int tqgpu_create(tqgpu_solver **out, int device, int Nn, const int *n
             }
         }
         if (s->gpersist_ok) {
-            if (hipMalloc(&s->d_lvl_first, sizeof(int) * s->lvl_first.size()) != hipSuccess ||
-                hipMemcpy(s->d_lvl_first, s->lvl_first.data(), sizeof(int) * s->lvl_first.size(), hipMemcpyHostToDevice) != hipSuccess)
+            /* behind the level table: for every level of parents, how many of its blocks one wave takes side by side in the backward /
+             * forward / Hessian sweeps (factor_body_g ...): levels wider than the workgroup's 16 waves whose blocks all have the same
+             * small dimensions (the chains of a pruned scenario tree); 1 = one block per wave */
+            std::vector<int> tab(s->lvl_first);
+            const bool no_grp = getenv("TREEQP_AMD_GP_NO_GROUPS") != nullptr;
+            for (int lvl = 0; lvl <= s->Nh; lvl++) {
+                int grp = 1;
+                const int first = s->lvl_first[lvl], count = s->lvl_first[lvl + 1] - first;
+                if (!no_grp && lvl >= 1 && lvl < s->Nh && count > GP_WAVES && !s->dense) {
+                    const int d0 = s->bdim[first], n0 = s->nx[first], u0 = s->nu[first], c0 = s->nk[first];
+                    bool same = true;
+                    for (int k = first; k < first + count && same; k++) {
+                        same = s->bdim[k] == d0 && s->nx[k] == n0 && s->nu[k] == u0 && s->nk[k] == c0;
+                        for (int cc = 0; cc < s->nk[k] && same; cc++) same = s->nx[s->kid0[k] + cc] == s->nx[s->kid0[first] + cc];
+                    }
+                    const int R = d0 + 1 + n0;
+                    /* doubles of a group's window: factor_body's tall matrix, forward_body's factor + vectors, hess_body's C and C P */
+                    const size_t need = std::max(std::max((size_t)(R | 1) * d0 + d0 + 2, (size_t)(d0 | 1) * d0 + 2 * d0 + n0 + 2), (size_t)2 * d0 * (n0 + u0) + 2);
+                    if (same && d0 >= 1) {
+                        if (R <= WAVE / 3 && 3 * need <= s->lds_gp_wave) grp = 3;
+                        else if (R <= WAVE / 2 && 2 * need <= s->lds_gp_wave) grp = 2;
+                    }
+                }
+                tab.push_back(grp);
+            }
+            if (hipMalloc(&s->d_lvl_first, sizeof(int) * tab.size()) != hipSuccess ||
+                hipMemcpy(s->d_lvl_first, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice) != hipSuccess)
                 return cleanup_fail(fail(TQGPU_ENOMEM, "hipMalloc failed"));
         }
     }

@@ -262,7 +262,7 @@ __device__ __forceinline__ void g_persist_body(Tree T_in, Data D_in, Opts O, GPa
         if (flag) break;
 
         /* ---- H: block dual Hessian (:551-615) ---- */
-        for (int p = wave; p < Np; p += GP_WAVES) hess_body(sT, sD, p, lane, lds);
+        for (int p = wave; p < Np; p += GP_WAVES) hess_body(sT, sD, p, lane, lds);      /* (side by side in lane groups, as the sweeps below: measured slower, 67 against 56 us per iteration of a 308-node tree) */
         __syncthreads();
         GP_MARK(2);
 
@@ -270,13 +270,20 @@ __device__ __forceinline__ void g_persist_body(Tree T_in, Data D_in, Opts O, GPa
          * parent's block), then forward substitution (:641-805) ---- */
         for (int lvl = Nh - 1; lvl >= 0; lvl--) {
             const int first = G.lvl_first[lvl], count = G.lvl_first[lvl + 1] - first;
-            for (int b = wave; b < count; b += GP_WAVES) factor_body(sT, sD, O, first + b, lane, lds);
+            const int grp = G.lvl_first[Nh + 2 + lvl];          /* blocks of this level one wave takes side by side (1: one block per wave) */
+            if (grp == 3 && sT.bdim[first] == 8 && sT.nx[first] == 8) { for (int b = 3 * wave; b < count; b += 3 * GP_WAVES) factor_body_g<3, 8, 8>(sT, sD, O, first + b, min(3, count - b), lane, lds, G.lds_wave / 3); }
+            else if (grp == 3) { for (int b = 3 * wave; b < count; b += 3 * GP_WAVES) factor_body_g<3>(sT, sD, O, first + b, min(3, count - b), lane, lds, G.lds_wave / 3); }
+            else if (grp == 2) { for (int b = 2 * wave; b < count; b += 2 * GP_WAVES) factor_body_g<2>(sT, sD, O, first + b, min(2, count - b), lane, lds, G.lds_wave / 2); }
+            else for (int b = wave; b < count; b += GP_WAVES) factor_body(sT, sD, O, first + b, lane, lds);
             __syncthreads();
         }
         GP_MARK(3);
         for (int lvl = 1; lvl < Nh; lvl++) {
             const int first = G.lvl_first[lvl], count = G.lvl_first[lvl + 1] - first;
-            for (int b = wave; b < count; b += GP_WAVES) forward_body(sT, sD, first + b, lane, lds);
+            const int grp = G.lvl_first[Nh + 2 + lvl];
+            if (grp == 3) { for (int b = 3 * wave; b < count; b += 3 * GP_WAVES) forward_body_g<3>(sT, sD, first + b, min(3, count - b), lane, lds, G.lds_wave / 3); }
+            else if (grp == 2) { for (int b = 2 * wave; b < count; b += 2 * GP_WAVES) forward_body_g<2>(sT, sD, first + b, min(2, count - b), lane, lds, G.lds_wave / 2); }
+            else for (int b = wave; b < count; b += GP_WAVES) forward_body(sT, sD, first + b, lane, lds);
             __syncthreads();
         }
         GP_MARK(4);
