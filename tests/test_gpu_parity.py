@@ -509,6 +509,8 @@ FUSED_CASES = [
     ("chain_2_1_4_h3", lambda: P.linear_chain(4, 3, 3, nm=1, nu=1)),                              # four children: d = 16 from nx = 4
     ("chain_8_3_2_h3", lambda: P.linear_chain(2, 3, 3)),
     ("chain_8_3_2_h10", lambda: P.linear_chain(2, 10, 10)),
+    ("chain_4_1_4_h5", lambda: P.linear_chain(4, 5, 5, nm=2)),                                    # three tiers of two levels (md = 4): the bottom tier walks down its path through tier 1 (round 4)
+    ("chain_4_2_3_h6_tight", lambda: P.linear_chain(3, 6, 6, nm=2, nu=2, ubound=0.1)),            # the same with md = 3 and passes dropped by rejected trials
 ]
 
 
