@@ -978,3 +978,26 @@ def test_smallest_and_longest_shapes(gpu, orc, name, make):
     assert (r["status"], r["iter"], r["ls_total"]) == (ref["status"], ref["iter"], ref["ls_total"])
     assert_solution_close(g.solution(), ref, TOL)
     g.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 4])
+def test_small_block_wide_trees_take_the_three_launch_family(gpu, orc, monkeypatch, seed):
+    """Trees of SMALL dual blocks (d <= 16) that are too wide for the single-workgroup kernel (here: a level of more than 96 nodes) run
+    on the workgroup-per-block kernels -- three launches per Newton iteration -- since round 4, not on the launch-per-phase kernels
+    (TREEQP_AMD_SMALL_WIDE=0): same verdict, iteration and trial counts as the oracle on both, a quarter of the launches."""
+    f = P.random_shape_qp(seed, depth=5, max_kids=4, nx_range=(2, 4), nu_range=(1, 2), ubound=0.3)
+    ref = orc.solve(f.as_dict(), lambda0=f.lambda0)
+    res = {}
+    for label in ("three launches", "launch per phase"):
+        if label == "launch per phase":
+            monkeypatch.setenv("TREEQP_AMD_SMALL_WIDE", "0")
+        g = gpu.TqGpu(f.nk, f.nx, f.nu).upload(f.as_dict(), f.lambda0)
+        assert g.path == 0
+        g.solve()
+        r = g.solve()                          # (the second solve enqueues the first one's trial counts ahead)
+        res[label] = (r, g.solution())
+        g.close()
+        assert (r["status"], r["iter"], r["ls_total"]) == (ref["status"], ref["iter"], ref["ls_total"]), label
+        assert_solution_close(res[label][1], ref, TOL)
+    assert 2 * res["three launches"][0]["n_launches"] < res["launch per phase"][0]["n_launches"]

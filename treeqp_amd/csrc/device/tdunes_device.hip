@@ -1527,6 +1527,15 @@ int build_tables(tqgpu_solver *s) {
             s->lds_forward_w = std::max(s->lds_forward_w, wide_lds_forward(d));
         }
         s->wide = dmax > 16 && dmax <= 64 && rmax <= 128 && nzmax <= 32;      /* k_hess_w keeps a parent's entries of P for 8 k-steps of 4 in registers */
+        /* Trees of SMALL blocks (d <= 16) that are too wide for the single-workgroup kernel (a level of more than 6 x 16 blocks) take the
+         * workgroup-per-block kernels as well: three launches per Newton iteration instead of the five to eight of the launch-per-phase
+         * kernels (TREEQP_AMD_SMALL_WIDE=0: as before) */
+        {
+            int widest = 0;
+            for (int l = 0; l + 1 < (int)s->lvl_first.size(); l++) widest = std::max(widest, s->lvl_first[l + 1] - s->lvl_first[l]);
+            const char *e = getenv("TREEQP_AMD_SMALL_WIDE");
+            if (!s->wide && dmax >= 3 && dmax <= 16 && widest > 6 * 16 && rmax <= 128 && nzmax <= 32 && !(e && atoi(e) == 0)) s->wide = true;
+        }
     }
     const size_t lim = 160 * 1024;
     if (s->lds_factor > lim || s->lds_hess > lim)
