@@ -341,11 +341,9 @@ def main():
         # verdict (status, iteration count) before the next starts -- the solver is timed, not this interpreter
         r, iters, ls, launches = g.solve_n(args.steps, **opts)
     else:
-        for _ in range(args.steps):
-            it_, ls_, la_, r = solve_step()   # returns when the verdict of every tree is on the host
-            iters += it_
-            ls += ls_
-            launches += la_
+        # a batch per step: the same loop in C (tqgpu_solve_batch_n): every call returns when the verdict of every tree is on the host
+        rs_, iters, ls, launches = capi.solve_batch_n(mirrors, args.steps, **opts)
+        r = rs_[0]
     for m in mirrors:
         m.device_times(1)                 # synchronises: all K solves are complete (state written back)
     barrier()
@@ -462,8 +460,7 @@ def main():
                 ksteps = max(20, min(args.steps, 100))
                 tb0 = time.perf_counter()
                 nit = 0
-                for _ in range(ksteps):
-                    nit += sum(rr["iter"] for rr in capi.solve_batch(batch))
+                nit = capi.solve_batch_n(batch, ksteps)[1]                     # (the loop in C: the library is timed, not this interpreter's ctypes marshalling of 7 x 8 result fields per step)
                 g.device_times(1)                                            # synchronises
                 tb = time.perf_counter() - tb0
                 sweep.append({"trees_per_gpu": nb, "value": nit / tb, "ms_per_step": 1e3 * tb / ksteps})

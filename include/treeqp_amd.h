@@ -188,6 +188,10 @@ int tqgpu_pshard_solve_local(tqgpu_solver **ranks, int n, const tqgpu_opts *opts
  * of the reference's drivers (examples/spring_mass_dual_newton_tree.c:135-140, `for (jj = 0; jj < NREP; jj++)
  * treeqp_tdunes_solve(...)`) in C.  res: the last solve; sums over the solves in *iter_sum, *ls_sum, *launch_sum (each may be NULL). */
 int tqgpu_solve_n(tqgpu_solver *s, const tqgpu_opts *opts, int n, tqgpu_result *res, long *iter_sum, long *ls_sum, long *launch_sum);
+/* the same loop for a batch: `steps` calls of tqgpu_solve_batch(solvers, n, ...) one after the other (the scenario sweep of
+ * examples/fault_tolerance.c:486-530 repeated, e.g. once per MPC step); results: the n results of the last call; sums over all
+ * calls and members in *iter_sum, *ls_sum, *launch_sum (each may be NULL) */
+int tqgpu_solve_batch_n(tqgpu_solver **solvers, int n, const tqgpu_opts *opts, int steps, tqgpu_result *results, long *iter_sum, long *ls_sum, long *launch_sum);
 
 /* Batched multi-tree solve: n independent mirrors with the same options (examples/fault_tolerance.c:486-530
  * holds one tree_qp_in / workspace pair per configuration and solves them one after the other).  Mirrors whose

@@ -463,6 +463,24 @@ def solve_batch(mirrors, profile=0, **kw) -> list:
     return [{f: getattr(res[i], f) for f, _ in GpuResult._fields_} for i in range(n)]
 
 
+def solve_batch_n(mirrors, steps: int, profile=0, **kw):
+    """`steps` batched solves back to back in C (tqgpu_solve_batch_n) -> (results of the last call, sum of iterations, of trials, of launches)."""
+    o = GpuOpts(maxIter=100, termCondition=2, stationarityTolerance=1e-8, regType=2, regTol=1e-6, regValue=1e-6,
+                lineSearchMaxIter=50, lineSearchGamma=0.1, lineSearchBeta=0.6, lineSearchRestartTrigger=-1, profile=profile, checkLastActiveSet=1)
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise KeyError(k)
+        setattr(o, k, v)
+    n = len(mirrors)
+    arr = (C.c_void_p * n)(*[m.h for m in mirrors])
+    res = (GpuResult * n)()
+    it, ls, la = C.c_long(0), C.c_long(0), C.c_long(0)
+    rc = lib().tqgpu_solve_batch_n(arr, n, C.byref(o), int(steps), res, C.byref(it), C.byref(ls), C.byref(la))
+    if rc != 0:
+        raise RuntimeError(f"tqgpu_solve_batch_n failed ({rc}): {lib().tqgpu_last_error().decode()}")
+    return [{f: getattr(res[i], f) for f, _ in GpuResult._fields_} for i in range(n)], it.value, ls.value, la.value
+
+
 class TqGpu:
     def __init__(self, nk, nx, nu, device: int = -1):
         L = lib()

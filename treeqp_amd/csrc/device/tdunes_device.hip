@@ -1352,6 +1352,7 @@ struct tqgpu_solver {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> iter_ev;
     std::vector<double> iter_times;
+    bool times_dirty = true;              /* iter_times / phase_times may hold times of an earlier (profiled) solve */
     /* profile level 3 (profiling.h:38-68): events around the phase groups of every iteration on the launch-per-level path:
      * [iteration][0..4] = start, gradient + termination test + dual Hessian done, factorisation + substitution done, line search done */
     std::vector<hipEvent_t> phase_ev;
@@ -2854,6 +2855,7 @@ struct SolveCtx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool fast = false, persist = false, first_launch = true, prelaunched = false, gpersist = false, phases = false, events = true;
     unsigned batch_seq = 0;          /* != 0: this solve's persistent launch is part of a batch launch the caller makes with this launch number */
+    int env_stamps = -1, env_nomirror = -1;          /* >= 0: TREEQP_AMD_STAMPS / TREEQP_AMD_NO_W3_MIRROR as the caller read them (tqgpu_solve_batch: once per call, not once per member) */
 #ifdef TQ_HOSTPROF
     std::chrono::steady_clock::time_point hp0, hp1, hp2;
 #endif
@@ -2870,7 +2872,8 @@ int solve_begin(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, GItem *defer
     O.lsMaxIter = o->lineSearchMaxIter; O.lsRestartTrigger = o->lineSearchRestartTrigger; O.reuse = o->checkLastActiveSet == 2 ? 1 : 0;
     O.tol = o->stationarityTolerance; O.regTol = o->regTol; O.regValue = o->regValue;
     O.gamma = o->lineSearchGamma; O.beta = o->lineSearchBeta;
-    { const char *e = getenv("TREEQP_AMD_STAMPS"); O.stamps = e ? std::max(1, atoi(e)) : 0; }
+    if (cx.env_stamps >= 0) O.stamps = cx.env_stamps;          /* (a batch call reads the environment once for all its members) */
+    else { const char *e = getenv("TREEQP_AMD_STAMPS"); O.stamps = e ? std::max(1, atoi(e)) : 0; }
     if (O.termCondition < 0 || O.termCondition > 2 || O.regType < 0 || O.regType > 2 || O.regValue < 0)
         return fail(TQGPU_EINVAL, "invalid option value");
 
@@ -2884,7 +2887,9 @@ int solve_begin(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, GItem *defer
     if (o->profile) {
         while ((int)s->iter_ev.size() < o->maxIter + 1) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); s->iter_ev.push_back(ev); }
     }
-    s->iter_times.assign((size_t)std::max(o->maxIter, 1), NAN);
+    /* (the per-iteration / per-phase time records are all-NaN unless a profiled solve has written into them: not refilled per solve) */
+    const size_t n_it = (size_t)std::max(o->maxIter, 1);
+    if (s->times_dirty || s->iter_times.size() != n_it) s->iter_times.assign(n_it, NAN);
 
     s->w3_now = false;
     cx.fast = tiered_capable(s) && o->profile < 3;          /* level 3: the launch-per-level kernels, whose launches ARE the reference's phases */
@@ -2893,8 +2898,9 @@ int solve_begin(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, GItem *defer
         while ((int)s->phase_ev.size() < 4 * (o->maxIter + 1)) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); s->phase_ev.push_back(ev); }
         if (!s->sweep_ev0) { HIP_TRY(hipEventCreate(&s->sweep_ev0)); HIP_TRY(hipEventCreate(&s->sweep_ev1)); }
     }
-    s->phase_times.assign((size_t)3 * std::max(o->maxIter, 1), NAN);
+    if (s->times_dirty || s->phase_times.size() != 3 * n_it) s->phase_times.assign(3 * n_it, NAN);
     s->first_sweep_time = NAN;
+    s->times_dirty = o->profile != 0;
     cx.persist = persist_capable(s) && !o->profile && o->maxIter > 0;
     cx.gpersist = !cx.persist && uses_gpersist(s, defer != nullptr) && !o->profile && o->maxIter > 0;
     if (cx.gpersist) cx.persist = true;                  /* same host flow: one launch, verdict through the result block */
@@ -2906,7 +2912,7 @@ int solve_begin(tqgpu_solver *s, const tqgpu_opts *o, SolveCtx &cx, GItem *defer
     /* the three-launch family reports through the pinned result block as well (launches of k_sg / k_sgp post the control block and
      * their own clock: w3_mirror) */
     const bool w3_will = !cx.persist && s->w3_ok && !s->dense && !cx.phases && !cx.fast && !s->sharded;
-    const bool no_mirror = getenv("TREEQP_AMD_NO_W3_MIRROR") != nullptr;        /* (A/B and tests: copy + synchronisation per read, HIP events per solve, as before) */
+    const bool no_mirror = cx.env_nomirror >= 0 ? cx.env_nomirror != 0 : getenv("TREEQP_AMD_NO_W3_MIRROR") != nullptr;        /* (A/B and tests: copy + synchronisation per read, HIP events per solve, as before) */
     s->w3_mirror = w3_will && !o->profile && !no_mirror;
     s->w3_seen = false;
     if (s->w3_mirror) s->h_res->seq = 0;          /* (no launch of this mirror is in flight) */
@@ -3277,6 +3283,14 @@ extern "C" int tqgpu_solve_batch(tqgpu_solver **solvers, int n, const tqgpu_opts
     for (int i = 0; i < n; i++) if (!solvers[i]) return fail(TQGPU_EINVAL, "tqgpu_solve_batch: null mirror");
     for (int i = 0; i < n; i++) if (solvers[i]->pshard && solvers[i]->nranks > 1) return fail(TQGPU_EINVAL, "tqgpu_solve_batch: a member is one rank of a sharded solve (tqgpu_pshard_init)");
     std::vector<SolveCtx> cx((size_t)n);
+    /* the environment switches of a batch call, read ONCE (a getenv is a scan of the environment: two dozen of them per call of seven members
+     * were microseconds of a 125 us step) */
+    const bool env_batch_launches = getenv("TREEQP_AMD_BATCH_LAUNCHES") != nullptr, env_batch_sync = getenv("TREEQP_AMD_BATCH_SYNC") != nullptr;
+    {
+        const char *e = getenv("TREEQP_AMD_STAMPS");
+        const int st = e ? std::max(1, atoi(e)) : 0, nm = getenv("TREEQP_AMD_NO_W3_MIRROR") != nullptr ? 1 : 0;
+        for (int k = 0; k < n; k++) { cx[(size_t)k].env_stamps = st; cx[(size_t)k].env_nomirror = nm; }
+    }
     int first_err = TQGPU_OK;
     std::string first_msg;
     for (int k = 0; k < n; k++) {          /* as tqgpu_solve: a mirror that backed off the persistent path returns to it after PERSIST_BACKOFF solves */
@@ -3299,7 +3313,7 @@ extern "C" int tqgpu_solve_batch(tqgpu_solver **solvers, int n, const tqgpu_opts
              * member needs more.  Members that go out together as ONE launch (batch kernel) fill the device up to what is co-resident:
              * a tree's waves are parked at barriers and waits two thirds of the time, and trees that share CUs fill those gaps
              * (C2: 3 trees 72 k it/s, 5 trees 98 k; C1: 22 trees 656 k, 38 trees 922 k). */
-            const bool one_launch = persist_like && batch_kernel_index(s) >= 0 && o->checkLastActiveSet != 2 && !getenv("TREEQP_AMD_BATCH_LAUNCHES");
+            const bool one_launch = persist_like && batch_kernel_index(s) >= 0 && o->checkLastActiveSet != 2 && !env_batch_launches;
             const int cap = (!one_launch && s->n_cu > 0 && need <= s->n_cu) ? std::min(s->co_capacity, s->n_cu) : s->co_capacity;
             if (j > i && (s->device != dev || used + need > cap)) break;
             used += need;
@@ -3332,7 +3346,7 @@ extern "C" int tqgpu_solve_batch(tqgpu_solver **solvers, int n, const tqgpu_opts
                 if (!f) f = s;
                 if (batch_kernel_index(s) == batch_kernel_index(f) && s->geom.G == f->geom.G && s->lds_persist == f->lds_persist && s->Nn == f->Nn) pm.push_back(k);
             }
-            if (pm.size() < 2 || getenv("TREEQP_AMD_BATCH_LAUNCHES")) pm.clear();      /* (=1: one launch per tree, the round-1 protocol) */
+            if (pm.size() < 2 || env_batch_launches) pm.clear();      /* (=1: one launch per tree, the round-1 protocol) */
         }
         for (int k = begun_from; k < begun_to; k++) {
             /* a member of the previous batch launch that goes out again on the same lead's stream is ordered behind it by that stream */
@@ -3432,17 +3446,31 @@ extern "C" int tqgpu_solve_batch(tqgpu_solver **solvers, int n, const tqgpu_opts
         /* the members' later work (solution export, the next solve) runs on their own streams: it has to find the batch launch
          * complete -- every verdict is in, so this waits for the write-back of the last workgroups only, once per batch */
         if (!pm.empty() && ok_to == begun_to) {
-            if (first_err != TQGPU_OK || getenv("TREEQP_AMD_BATCH_SYNC")) HIP_TRY(hipStreamSynchronize(solvers[pm[0]]->stream));
+            if (first_err != TQGPU_OK || env_batch_sync) HIP_TRY(hipStreamSynchronize(solvers[pm[0]]->stream));
             else for (size_t m = 1; m < pm.size(); m++) solvers[pm[m]]->settle_stream = solvers[pm[0]]->stream;      /* see settle() */
         }
         if (gp_launched) {
-            if (first_err != TQGPU_OK || getenv("TREEQP_AMD_BATCH_SYNC")) HIP_TRY(hipStreamSynchronize(lead->stream));
+            if (first_err != TQGPU_OK || env_batch_sync) HIP_TRY(hipStreamSynchronize(lead->stream));
             else for (size_t m = 1; m < gi; m++) solvers[gp_members[m]]->settle_stream = lead->stream;
         }
         if (first_err != TQGPU_OK) break;
         i = j;
     }
     if (first_err != TQGPU_OK) return fail(first_err, first_msg);
+    return TQGPU_OK;
+}
+
+extern "C" int tqgpu_solve_batch_n(tqgpu_solver **solvers, int n, const tqgpu_opts *o, int steps, tqgpu_result *results, long *iter_sum, long *ls_sum, long *launch_sum) {
+    if (steps < 1) return fail(TQGPU_EINVAL, "tqgpu_solve_batch_n: bad arguments");
+    long it = 0, ls = 0, la = 0;
+    for (int k = 0; k < steps; k++) {
+        const int rc = tqgpu_solve_batch(solvers, n, o, results);
+        if (rc != TQGPU_OK) return rc;
+        for (int i = 0; i < n; i++) { it += results[i].iter; ls += results[i].ls_total; la += results[i].n_launches; }
+    }
+    if (iter_sum) *iter_sum = it;
+    if (ls_sum) *ls_sum = ls;
+    if (launch_sum) *launch_sum = la;
     return TQGPU_OK;
 }
 
