@@ -448,6 +448,7 @@ def main():
             # throughput leg (reported beside the latency metric, never as `value`): independent trees of the same workload solved by
             # one batched call per step -- what a scenario sweep (fault_tolerance.c:486-530) gets -- swept up to what is co-resident
             cap = {"workgroups_per_tree": geo["workgroups"], "capacity": geo["capacity"], "compute_units": geo["compute_units"]}
+            g.event_timing(False)              # (the roofline leg above switched the event pair on; a batch call of one tree would record it)
             sweep = []
             more = []
             nb = 1
