@@ -109,3 +109,28 @@ def fuzz_case(seed, s0=20000):
     if rt == 1:
         opts["regValue"] = 1e-8
     return f, opts
+
+
+def ulp_sensitivity(orc, f, opts, upto, copies=6):
+    """Does the ORACLE keep its own line-search decisions when every non-zero of the problem data moves by one unit in the last place?
+    Returns the number of perturbed copies (of `copies`) whose trial counts differ from the unperturbed oracle run in an iteration
+    <= `upto` (or whose verdict differs).  A case with a positive count is decided by rounding at or before that iteration in ANY
+    implementation of the algorithm: the parity campaign lists a device / oracle difference there apart from a mismatch."""
+    import numpy as np
+    d = f.as_dict()
+    base = orc.solve(d, orc.default_opts(**opts), lambda0=f.lambda0)
+    rng = np.random.default_rng(12345)
+    moved = 0
+    for _ in range(copies):
+        d2 = dict(d)
+        for k in ("A", "B", "b", "Qd", "Rd", "q", "r"):
+            a = np.array(d2[k], dtype=np.float64, copy=True)
+            a *= 1.0 + (rng.integers(0, 2, a.shape) * 2 - 1) * 2.0 ** -52
+            d2[k] = a
+        p = orc.solve(d2, orc.default_opts(**opts), lambda0=f.lambda0)
+        n = min(upto + 1, base["iter"], p["iter"])
+        same = p["status"] == base["status"] and all(int(p["trace_ls"][k]) == int(base["trace_ls"][k]) for k in range(n))
+        if n < upto + 1 and p["iter"] != base["iter"]:
+            same = False
+        moved += 0 if same else 1
+    return moved
