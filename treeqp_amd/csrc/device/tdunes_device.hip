@@ -3224,7 +3224,14 @@ hipStream_t g_occ_stream = nullptr;
 extern "C" int tqgpu_debug_occupy(int device, int blocks, int lds_kb, int ms) {
     if (blocks < 1 || lds_kb < 0 || lds_kb > 160 || ms < 1) return fail(TQGPU_EINVAL, "tqgpu_debug_occupy: bad arguments");
     if (device >= 0) HIP_TRY(hipSetDevice(device));
-    if (!g_occ_stream) HIP_TRY(hipStreamCreateWithFlags(&g_occ_stream, hipStreamNonBlocking));
+    if (!g_occ_stream) {
+        /* a stream of another PRIORITY than the solvers': the runtime deals streams of one priority over a handful of hardware queues, and
+         * two streams that share a queue run their kernels one after the other -- the occupying kernel would then hold back the very launch
+         * it is meant to run beside (one test run in four, depending on how many mirrors the process had created before) */
+        int least = 0, greatest = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_TRY(hipStreamCreateWithPriority(&g_occ_stream, hipStreamNonBlocking, greatest));
+    }
     const size_t lds = (size_t)lds_kb * 1024;
     if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_occupy), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_occupy, dim3((unsigned)blocks), dim3(256), lds, g_occ_stream, (unsigned long long)std::min(ms, 3000) * 100000ull, (int *)nullptr);

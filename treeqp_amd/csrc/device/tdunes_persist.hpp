@@ -157,6 +157,9 @@ __device__ __forceinline__ void pst_word(const PSync &Sy, unsigned *p, unsigned 
 /* Poll loops read the payload AND the two "launch is over" words in the same round trip (the loads are
  * independent, so they are in flight together); a poll iteration is then one memory latency long and needs
  * no sleep.  `over` = halt word == launch number or timeout word set; false = give up. */
+#ifndef TQ_POLL_NAP
+#define TQ_POLL_NAP 1
+#endif
 struct PollGuard {
     unsigned h, tmo, cm;
     __device__ __forceinline__ void load(const PSync &Sy) {
@@ -174,7 +177,7 @@ struct PollGuard {
         /* a nap between two looks: every look is 3 - 35 loads per lane that go to the memory side, and with a few hundred workgroups
          * polling they are in each other's (and the producers') way.  Short (64 cycles) here: this is on every hand-over's critical
          * path.  The one long wait of a pass naps longer in large launches (p_forward_tier). */
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(TQ_POLL_NAP);
         return true;
     }
 };
