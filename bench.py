@@ -409,6 +409,10 @@ def main():
                   3: "g_persist(_batch): the whole solve in one launch of one workgroup per tree",
                   1: "one Newton iteration = f_back x tiers, f_top, f_fwd x tiers, f_stage, k_ls_decide (tiered path)",
                   0: "blocks of 16 < d <= 64 rows: one Newton iteration = k_sgp (stage + gradient + Armijo / termination tails), k_hf_w (H + backward sweep with panel look-ahead, MFMA), k_fwd3 (forward sweep + direction test); other trees on this path: k_grad, k_check, k_hess, k_factor_all, k_forward_all, k_ls_*, k_stage"}[g.path]
+        if len(mirrors) > 1 and launches <= 1.5 * args.steps * len(mirrors):
+            # every tree of the step in ONE launch: the batch kernels (a member's own path, taken when it is solved alone, does not matter here)
+            kernel = ("f_persist_batch: one launch per step, every tree its own set of tier-subtree workgroups" if g.path == 2 else
+                      "g_persist_batch: one launch per step, one workgroup per tree (all phases of all Newton iterations of the tree)")
         out = {
             "metric": "dual_newton_iterations_per_second",
             "value": tot_iters / tmax,

@@ -43,21 +43,36 @@ struct GParams {
  * tree) are the trees with many trials (one with 95 trials spent 14 of its 18 ms in them).  Same arithmetic as stage_body's
  * clipping branch; the sums of a node are taken over its row (row16_sum) instead of over the wave.  Needs nx + nu <= 16 for
  * every node of the group, clipping nodes only; `win` doubles of the wave's LDS window per row. */
-__device__ void stage_body16(const Tree &T, const Data &D, int mode, int k0, int count, int lane, double *lds, int win, bool batch) {
-    const Ctrl *c = D.ctrl;
+struct SweepCtl { int cur; double step; bool save_s; };      /* what a sweep reads from the control block -- once per wave and sweep, not once per group of nodes */
+__device__ __forceinline__ SweepCtl sweep_ctl(const Ctrl *c, int mode) {
+    SweepCtl sc;
+    sc.cur = c->cur; sc.step = c->tau - c->tauPrev; sc.save_s = mode == 1 && c->ls_iter == 1;
+    return sc;
+}
+__device__ void stage_body16(const Tree &T, const Data &D, int mode, int k0, int count, int lane, double *lds, int win, bool batch, const SweepCtl &sc) {
     const int g = lane >> 4, t = lane & 15;
     const bool act = g < count;
     const int k = act ? k0 + g : k0;
     const int nxk = T.nx[k], nuk = T.nu[k], xo = T.xoff[k], uo = T.uoff[k];
     const int nkid = T.nk[k], d = T.bdim[k];
-    const double *lamc = c->cur ? D.lam1 : D.lam0;
-    double *lamn = c->cur ? D.lam0 : D.lam1;
-    const double step = c->tau - c->tauPrev;
-    const bool save_s = mode == 1 && c->ls_iter == 1;
+    const double *lamc = sc.cur ? D.lam1 : D.lam0;
+    double *lamn = sc.cur ? D.lam0 : D.lam1;
+    const double step = sc.step;
+    const bool save_s = sc.save_s;
     double *lk = lds + (size_t)g * win;         /* d doubles */
     double *lown = lk + d;                      /* nxk doubles */
     const int kid0k = nkid > 0 ? T.kid0[k] : 0;
     const int ko = nkid > 0 ? T.xoff[kid0k] : 0;
+    /* everything of the lane's entry that does not depend on the duals is requested NOW, in one round of loads with the duals below: taken where
+     * it is used -- behind stores the compiler must assume to alias -- each of them was a round trip of its own to the L2 (six to eight per
+     * group of four nodes; the trees that do not fit the LDS mirror are the stragglers of a batch) */
+    const bool ent = act && t < nxk + nuk, isx0 = t < nxk;
+    const int je = ent ? (isx0 ? xo + t : uo + t - nxk) : (isx0 ? xo : uo);
+    const double c_lin = ent ? (isx0 ? D.q : D.r)[je] : 0.0, c_inv = ent ? (isx0 ? D.Qinv : D.Rinv)[je] : 0.0;
+    const double c_lo = ent ? (isx0 ? D.xmin : D.umin)[je] : 0.0, c_hi = ent ? (isx0 ? D.xmax : D.umax)[je] : 0.0;
+    const double c_w = ent ? (isx0 ? D.Qd : D.Rd)[je] : 0.0;
+    const double c_unc = (ent && save_s) ? (isx0 ? D.xUnc : D.uUnc)[je] : 0.0;
+    const double c_b0 = (act && t < d) ? D.b[ko + t] : 0.0, c_b1 = (act && t + 16 < d) ? D.b[ko + t + 16] : 0.0;      /* b of the children (the node's constant term), first two rounds of the loop at the end */
     if (act) {
         for (int tt = t; tt < d; tt += 16) {
             double v = lamc[ko + tt];
@@ -78,7 +93,7 @@ __device__ void stage_body16(const Tree &T, const Data &D, int mode, int k0, int
     if (act && t < nxk + nuk) {
         const bool isx = t < nxk;
         const int j = isx ? t : t - nxk;
-        double v = isx ? fma(-1.0, D.q[xo + j], lown[j]) : -1.0 * D.r[uo + j];
+        double v = isx ? fma(-1.0, c_lin, lown[j]) : -1.0 * c_lin;
         int rowoff = 0;
         for (int cc = 0; cc < nkid; cc++) {
             const int kid = kid0k + cc, nxc = T.nx[kid];
@@ -90,27 +105,31 @@ __device__ void stage_body16(const Tree &T, const Data &D, int mode, int k0, int
         }
         if (isx) {
             D.qmod[xo + j] = v;
-            const double qi = D.Qinv[xo + j];
-            const double unc = qi * v, lo = D.xmin[xo + j], hi = D.xmax[xo + j];
+            const double qi = c_inv;
+            const double unc = qi * v, lo = c_lo, hi = c_hi;
             double xv, cal;
             if (unc >= hi) { xv = hi; cal = 0.0; } else if (unc <= lo) { xv = lo; cal = 0.0; } else { xv = unc; cal = qi; }
-            if (save_s) D.xUncS[xo + j] = D.xUnc[xo + j];
+            if (save_s) D.xUncS[xo + j] = c_unc;
             D.xUnc[xo + j] = unc; D.x[xo + j] = xv; D.QinvCal[xo + j] = cal;
-            p_qx = (D.Qd[xo + j] * xv) * xv;
+            p_qx = (c_w * xv) * xv;
             p_hx = v * xv;
         } else {
             D.rmod[uo + j] = v;
-            const double ri = D.Rinv[uo + j];
-            const double unc = ri * v, lo = D.umin[uo + j], hi = D.umax[uo + j];
+            const double ri = c_inv;
+            const double unc = ri * v, lo = c_lo, hi = c_hi;
             double uv, cal;
             if (unc >= hi) { uv = hi; cal = 0.0; } else if (unc <= lo) { uv = lo; cal = 0.0; } else { uv = unc; cal = ri; }
-            if (save_s) D.uUncS[uo + j] = D.uUnc[uo + j];
+            if (save_s) D.uUncS[uo + j] = c_unc;
             D.uUnc[uo + j] = unc; D.u[uo + j] = uv; D.RinvCal[uo + j] = cal;
-            p_ru = (D.Rd[uo + j] * uv) * uv;
+            p_ru = (c_w * uv) * uv;
             p_hu = v * uv;
         }
     }
-    if (act) for (int tt = t; tt < d; tt += 16) p_c = fma(D.b[ko + tt], lk[tt], p_c);
+    if (act) {
+        if (t < d) p_c = fma(c_b0, lk[t], p_c);
+        if (t + 16 < d) p_c = fma(c_b1, lk[t + 16], p_c);
+        for (int tt = t + 32; tt < d; tt += 16) p_c = fma(D.b[ko + tt], lk[tt], p_c);
+    }
     p_qx = row16_sum(p_qx); p_hx = row16_sum(p_hx); p_ru = row16_sum(p_ru); p_hu = row16_sum(p_hu); p_c = row16_sum(p_c);
     if (act && t == 0) {
         double f = -0.5 * p_qx - p_c;       /* clipping.c:375 */
@@ -230,7 +249,7 @@ __device__ __forceinline__ void g_persist_body(Tree T_in, Data D_in, Opts O, GPa
     /* first sweep at lambda0 (phase S of iteration 0) and fval0 */
     const int win16 = G.lds_wave / 4;           /* LDS per row of 16 lanes in stage_body16 */
     auto stage_sweep = [&](int mode) {
-        if (G.small16 && !sD.strict) { for (int k0 = 4 * wave; k0 < Nn; k0 += 4 * GP_WAVES) stage_body16(sT, sD, mode, k0, min(4, Nn - k0), lane, lds, win16, !G.const_in_lds); }
+        if (G.small16 && !sD.strict) { const SweepCtl sc = sweep_ctl(c, mode); for (int k0 = 4 * wave; k0 < Nn; k0 += 4 * GP_WAVES) stage_body16(sT, sD, mode, k0, min(4, Nn - k0), lane, lds, win16, !G.const_in_lds, sc); }
         else for (int k = wave; k < Nn; k += GP_WAVES) stage_body(sT, sD, mode, k, lane, lds, !G.const_in_lds);
     };
     stage_sweep(0);
