@@ -16,7 +16,9 @@
  */
 #pragma once
 
+#ifndef GP_WAVES
 #define GP_WAVES 16
+#endif
 
 struct GParams {
     const int *lvl_first;        /* [Nh + 2] first node of every tree level (device copy) */
