@@ -623,6 +623,23 @@ def test_far_from_tolerance_differences_of_the_campaign_are_rounding_decisions(g
 
 
 @pytest.mark.gpu
+def test_sequences_of_changed_problems_through_the_dropin_api(gpu, orc):
+    """One solver object, a random sequence of solves with the caller changing the problem in between (b of an edge, q / r or the weights
+    of a node, the bounds of a node, A / B of an edge, nothing), warm-started from the previous duals or not -- treeqp_tdunes_solve
+    re-reads qp_in at every call (dual_Newton_tree.c:1142-1160) and the device mirror uploads and repacks only what changed.  Every solve
+    against the oracle on the problem as it stands, same starting duals: verdict and iteration count equal, solution within 1e-9.
+    24 sequences of 8 solves over the six tree classes of tools/fuzz_sequence.py (uniform, random shapes, pruned chains, blocks of
+    more than 16 rows, and the two persistent-path shapes); the campaign itself: profiles/r04_v3_fuzz_sequence.txt (36 000 solves)."""
+    import importlib.util
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location("fuzz_sequence", Path(__file__).resolve().parent.parent / "tools" / "fuzz_sequence.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    stats = mod.run(24, 8000, 8)
+    assert stats["fail"] == 0 and stats["solves"] == 24 * 8, stats
+
+
+@pytest.mark.gpu
 def test_not_descent_exit_of_the_merged_launch_leaves_the_phase_s_iterate(gpu, orc, monkeypatch):
     """NOT_DESCENT_DIRECTION out of k_sgp mode 2 (forward sweep + first trial in one launch): the trial sweep has run before the
     direction test, the reference returns from line_search with the phase-S iterate at lambda (dual_Newton_tree.c:944-954).  The device
