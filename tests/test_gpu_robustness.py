@@ -640,6 +640,22 @@ def test_sequences_of_changed_problems_through_the_dropin_api(gpu, orc):
 
 
 @pytest.mark.gpu
+def test_batches_of_mixed_tree_classes(gpu, orc):
+    """tqgpu_solve_batch on batches of 2 - 12 trees of MIXED classes under one option set: the call groups its members by the launch that
+    can carry them (a persistent batch launch per shape, one single-workgroup batch launch, the others one after the other).  Every
+    member against the oracle, the call made twice: verdict, iteration and trial counts equal, solution within 1e-9 (rounding-level
+    endgames as in the parity campaign apart).  16 batches of tools/fuzz_batch.py; the campaign: profiles/r04_v3_fuzz_batch.txt
+    (6 000 batches, 84 190 member solves, 405 different mixes of device paths in one batch)."""
+    import importlib.util
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location("fuzz_batch", Path(__file__).resolve().parent.parent / "tools" / "fuzz_batch.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    stats = mod.run(16, 20000)
+    assert stats["fail"] == 0 and stats["batches"] == 16 and stats["solves"] > 100, stats
+
+
+@pytest.mark.gpu
 def test_not_descent_exit_of_the_merged_launch_leaves_the_phase_s_iterate(gpu, orc, monkeypatch):
     """NOT_DESCENT_DIRECTION out of k_sgp mode 2 (forward sweep + first trial in one launch): the trial sweep has run before the
     direction test, the reference returns from line_search with the phase-S iterate at lambda (dual_Newton_tree.c:944-954).  The device
