@@ -33,8 +33,21 @@ def run(n_seq=40, s0=7000, n_steps=12):
     for q in range(n_seq):
         seed = s0 + q
         rng = np.random.default_rng(seed)
-        kind = q % 6
-        if kind >= 4:
+        kind = seed % 8
+        x0 = None
+        if kind >= 6:
+            # the same two classes with x0 eliminated (tree_qp_in_eliminate_x0: the root has no state; fault_tolerance.c:625-632 changes x0 between
+            # solves with tree_qp_in_set_x0_colmaj): change 6 below is a new x0
+            f = P.linear_chain(2, (nr := int(rng.integers(3, 7))), nr) if kind == 6 else P.spring_mass(Nh=int(rng.integers(3, 8)), Nr=int(rng.integers(1, 3)))
+            nk = f.nk(); Nn = len(nk)
+            qp = capi.TreeQp(np.full(Nn, f.nx, dtype=np.int32), np.where(nk > 0, f.nu, 0).astype(np.int32), nk).fill_lti(f)
+            qp.eliminate_x0()
+            nx, nu = qp.nx, qp.nu
+            x0 = np.asarray(f.x0, dtype=float)
+            opts = {}
+            f.name = f"lti kind {kind} Nn={Nn}, x0 eliminated"
+            f.lambda0 = None
+        elif kind >= 4:
             # uniform / multistage trees of the shapes the persistent single-launch kernels are instantiated for, through the reference's own
             # fill routine (tree_qp_in_fill_lti_data_diag_weights)
             f = P.linear_chain(2, (nr := int(rng.integers(3, 8))), nr) if kind == 4 else P.spring_mass()
@@ -56,7 +69,10 @@ def run(n_seq=40, s0=7000, n_steps=12):
         for step in range(n_steps):
             change = int(rng.integers(0, 7)) if step > 0 else 0
             flat = qp.flat()
+            if change == 6 and x0 is not None:
+                qp.set_x0(x0 * float(rng.uniform(0.3, 1.3)) + 0.02 * rng.standard_normal(len(x0)))
             trail.append(change)
+            last_touch = None
             # --- apply the change through the reference's setters
             if change in (1, 5):
                 e = int(rng.integers(0, Nn - 1)); k = e + 1
@@ -85,6 +101,7 @@ def run(n_seq=40, s0=7000, n_steps=12):
                 sc = float(rng.uniform(0.6, 1.5))
                 fin = lambda v: np.where(np.abs(v) < 1e10, v * sc, v)
                 qp.set_node_bounds(k, fin(xl), fin(xu), fin(ul), fin(uu))
+                last_touch = f"bounds of node {k} x {sc:.3f}: x in [{fin(xl)}, {fin(xu)}], u in [{fin(ul)}, {fin(uu)}]"
             flat = qp.flat()
             warm = lam_prev is not None and rng.random() < 0.5
             lam0 = lam_prev if warm else (f.lambda0 if f.lambda0 is not None else np.zeros(int(np.sum(nx[1:]))))
@@ -95,8 +112,8 @@ def run(n_seq=40, s0=7000, n_steps=12):
             gp = int(capi.lib().tqgpu_uses_fused_path(C.c_void_p(s.work.device)))
             by_path[gp] = by_path.get(gp, 0) + 1
             stats["solves"] += 1
-            scale = max(1.0, float(np.max(np.abs(ref["x"]))))
-            err = max(float(np.max(np.abs(sol[k] - ref[k]))) if len(ref[k]) else 0.0 for k in ("x", "u", "lam")) / scale
+            # (every array relative to its own largest entry: a nearly infeasible problem has duals of 1e5 and more)
+            err = max(float(np.max(np.abs(sol[k] - ref[k]))) / max(1.0, float(np.max(np.abs(ref[k])))) if len(ref[k]) else 0.0 for k in ("x", "u", "lam"))
             st_ref = ref["status"]
             same = (st == st_ref or (st == 1 and ref["iter"] == opts.get("maxIter", 100))) and qp.info["iter"] == ref["iter"]
             if st_ref != 0:
@@ -113,6 +130,18 @@ def run(n_seq=40, s0=7000, n_steps=12):
                     print(f"  (rounding-level endgame: seed {seed} step {step} change {change} warm {warm}: device iterations {qp.info['iter']} oracle {ref['iter']}, difference {err:.1e})", flush=True)
                 else:
                     stats["fail"] += 1
+                    for key_, off_ in (("x", xoff), ("u", uoff)):
+                        dv = np.abs(sol[key_] - ref[key_])
+                        if len(dv) and dv.max() > 1e-9:
+                            j_ = int(np.argmax(dv)); node_ = int(np.searchsorted(off_, j_, side="right") - 1)
+                            print(f"    largest difference in {key_}: entry {j_ - int(off_[node_])} of node {node_} (children {int(nk[node_])}): device {sol[key_][j_]:.9g} oracle {ref[key_][j_]:.9g}; last change touched {last_touch}", flush=True)
+                    dl = np.abs(sol["lam"] - ref["lam"])
+                    if len(dl) and dl.max() > 1e-9:
+                        j_ = int(np.argmax(dl)); loff = xoff[1:] - nx[0]; node_ = int(np.searchsorted(loff, j_, side="right"))
+                        kx = slice(int(xoff[node_]), int(xoff[node_ + 1]))
+                        print(f"    largest difference in lam: entry {j_ - int(loff[node_ - 1])} of the duals of node {node_} ({int((dl > 1e-9).sum())} entries differ): device {sol['lam'][j_]:.9g} oracle {ref['lam'][j_]:.9g}; "
+                              f"x of that node {np.array2string(ref['x'][kx], precision=6)} in [{flat['xmin'][kx][0]:.6g}, {flat['xmax'][kx][0]:.6g}]; KKT residual of the device's solution {qp.max_kkt_res():.2e}, "
+                              f"of the oracle's {float(orc.max_kkt(flat, ref)):.2e}", flush=True)
                     print(f"MISMATCH seed {seed} step {step} changes so far {trail} warm {warm} path {gp}: device status {st} iter {qp.info['iter']} oracle {st_ref} / {ref['iter']} err {err:.2e} [{f.name}]", flush=True)
             lam_prev = sol["lam"].copy()
         s.destroy()
