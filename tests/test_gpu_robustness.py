@@ -628,8 +628,9 @@ def test_sequences_of_changed_problems_through_the_dropin_api(gpu, orc):
     of a node, the bounds of a node, A / B of an edge, nothing), warm-started from the previous duals or not -- treeqp_tdunes_solve
     re-reads qp_in at every call (dual_Newton_tree.c:1142-1160) and the device mirror uploads and repacks only what changed.  Every solve
     against the oracle on the problem as it stands, same starting duals: verdict and iteration count equal, solution within 1e-9.
-    24 sequences of 8 solves over the six tree classes of tools/fuzz_sequence.py (uniform, random shapes, pruned chains, blocks of
-    more than 16 rows, and the two persistent-path shapes); the campaign itself: profiles/r04_v3_fuzz_sequence.txt (36 000 solves)."""
+    24 sequences of 8 solves over the eight tree classes of tools/fuzz_sequence.py (uniform, random shapes, pruned chains, blocks of
+    more than 16 rows, the two persistent-path shapes, and those two with x0 eliminated and a new x0 among the changes); the campaign
+    itself: profiles/r04_v3_fuzz_sequence.txt (84 000 solves)."""
     import importlib.util
     from pathlib import Path
     spec = importlib.util.spec_from_file_location("fuzz_sequence", Path(__file__).resolve().parent.parent / "tools" / "fuzz_sequence.py")
