@@ -134,3 +134,27 @@ def ulp_sensitivity(orc, f, opts, upto, copies=6):
             same = False
         moved += 0 if same else 1
     return moved
+
+
+def ulp_solution_spread(orc, f, opts, copies=4):
+    """How far the ORACLE's solution moves (largest relative change over x, u, lambda, each relative to its own largest entry) when every
+    non-zero of the problem data moves by one unit in the last place: the conditioning of the run as the oracle takes it -- a device /
+    oracle difference of that size or below, with equal verdict and counts, is rounding in an ill-conditioned Newton system, not an error."""
+    import numpy as np
+    d = f.as_dict()
+    base = orc.solve(d, orc.default_opts(**opts), lambda0=f.lambda0)
+    rng = np.random.default_rng(54321)
+    spread = 0.0
+    for _ in range(copies):
+        d2 = dict(d)
+        for k in ("A", "B", "b", "Qd", "Rd", "q", "r"):
+            a = np.array(d2[k], dtype=np.float64, copy=True)
+            a *= 1.0 + (rng.integers(0, 2, a.shape) * 2 - 1) * 2.0 ** -52
+            d2[k] = a
+        p = orc.solve(d2, orc.default_opts(**opts), lambda0=f.lambda0)
+        for k in ("x", "u", "lam"):
+            if len(base[k]):
+                with np.errstate(invalid="ignore"):
+                    v = float(np.nanmax(np.abs(p[k] - base[k]))) / max(1.0, float(np.nanmax(np.abs(base[k]))))
+                spread = max(spread, v)
+    return spread
