@@ -5,7 +5,7 @@ tightness, starting duals and option sets (three termination norms, three regula
 caps) -- against the CPU oracle: verdict, iteration and trial counts equal, solution within 1e-9 (relative, per array); rounding-level
 endgames classed as in tools/fuzz_parity.py (window of 10 x tolerance, else the one-ulp perturbation test).
 Usage: python tools/fuzz_persist.py [cases] [first seed]"""
-import sys, time
+import os, sys, time
 from pathlib import Path
 import numpy as np
 ROOT = Path(__file__).resolve().parent.parent
@@ -31,6 +31,8 @@ def case(seed):
     opts["stationarityTolerance"] = 1e-12 if opts["termCondition"] == 0 else 1e-8
     opts["regValue"] = 1e-8 if opts["regType"] == 1 else 1e-6
     lam0 = 0.1 * rng.standard_normal(int(np.sum(f.nx[1:]))) if rng.random() < 0.5 else None
+    if os.environ.get("FUZZ_KEEP_FACTORS"):
+        opts["checkLastActiveSet"] = 2          # the factor-keeping kernel variant on the device (the oracle's result does not depend on the option)
     f.lambda0 = lam0              # (what helpers.ulp_sensitivity starts the oracle from)
     return f, opts, lam0, nx, nu, md, Nr, Nh
 
