@@ -7,7 +7,7 @@ mkdir -p build/asan
 H=treeqp_amd/csrc/host
 SAN="-g -O1 -std=gnu99 -fPIC -fsanitize=address,undefined -fno-omit-frame-pointer"
 for f in blasfeo_compat tree_topology host_utils qp_container tdunes_host; do gcc $SAN -Iinclude -c $H/$f.c -o build/asan/$f.o; done
-hipcc -shared -fPIC --offload-arch=gfx950 build/asan/*.o build/obj/tdunes_device.hip.o -o build/asan/libtreeqp_amd.so -lm -fsanitize=address,undefined
+hipcc -shared -fPIC --offload-arch=gfx950 build/asan/*.o build/obj/device_*.o -o build/asan/libtreeqp_amd.so -lm -fsanitize=address,undefined      # (the device parts of the current product build: python treeqp_amd/build.py first)
 gcc $SAN -fopenmp -shared -o build/asan/liboracle.so oracle/tdunes_oracle.c -lm
 cp treeqp_amd/lib/libtreeqp_amd.so build/asan/lib_orig.so; cp oracle/liboracle.so build/asan/liboracle_orig.so
 restore() { cp build/asan/lib_orig.so treeqp_amd/lib/libtreeqp_amd.so; cp build/asan/liboracle_orig.so oracle/liboracle.so; }
