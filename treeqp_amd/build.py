@@ -29,7 +29,8 @@ DEVICE_SOURCES = ["tdunes_device.hip"]
 
 HOST_CFLAGS = ["-O2", "-g", "-fPIC", "-std=gnu99", "-Wall", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
 # max-ilp: with one or two waves per SIMD there is no occupancy to protect; scheduling the latency-bound chains for ILP measured 1.3 % faster on C2
-HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-mllvm", "-amdgpu-sched-strategy=max-ilp", *(["-DTQ_HOSTPROF"] if __import__("os").environ.get("TQ_HOSTPROF") else []), *(["-DTQ_FINE_STAMPS"] if __import__("os").environ.get("TQ_FINE_STAMPS") else []), *__import__("os").environ.get("TQ_DEFS", "").split(), "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-mllvm", "-amdgpu-sched-strategy=" + __import__("os").environ.get("TQ_SCHED", "max-ilp"),      # (TQ_SCHED: experiment builds with another scheduling strategy; the default scheduler does not compile this file on ROCm 7.2)
+              *(["-DTQ_HOSTPROF"] if __import__("os").environ.get("TQ_HOSTPROF") else []), *(["-DTQ_FINE_STAMPS"] if __import__("os").environ.get("TQ_FINE_STAMPS") else []), *__import__("os").environ.get("TQ_DEFS", "").split(), "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 
 def _run(cmd, **kw):
