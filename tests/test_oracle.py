@@ -136,3 +136,18 @@ def test_random_fixture_families_are_well_posed(orc):
         ref = orc.solve(f.as_dict(), orc.default_opts(**f.opts), lambda0=f.lambda0)
         assert ref["status"] == 0 and orc.max_kkt(f.as_dict(), ref) < 1e-8, f.name
     assert backtracking >= 15
+
+
+def test_one_ulp_perturbations_tell_rounding_decisions_from_sound_ones(orc):
+    """The classifier of the parity campaigns (helpers.ulp_sensitivity / ulp_solution_spread) on the oracle alone: the two campaign
+    cases whose line-search decisions flip in iterations 9 and 12 (tools/fuzz_replay.py 200000 272081 279701) do so under one-ulp
+    perturbations of the data in that iteration and in none before; a well-conditioned problem keeps every decision and moves its
+    solution by rounding only."""
+    from helpers import fuzz_case, ulp_sensitivity, ulp_solution_spread
+    for seed, first_diff in ((272081, 9), (279701, 12)):
+        f, opts = fuzz_case(seed, 200000)
+        assert ulp_sensitivity(orc, f, opts, first_diff - 1) == 0
+        assert ulp_sensitivity(orc, f, opts, first_diff) >= 3
+    f = P.random_shape_qp(5)
+    assert ulp_sensitivity(orc, f, {}, 100) == 0
+    assert ulp_solution_spread(orc, f, {}) < 1e-12
