@@ -1334,6 +1334,8 @@ struct tqgpu_solver {
     int *d_lvl_first = nullptr;
     size_t lds_gp_wave = 0;         /* doubles of LDS per wave of g_persist */
     size_t lds_gp_total = 0;        /* bytes of dynamic LDS of g_persist (windows + state mirror) */
+    bool persist_one = false;          /* the persistent launch of this tree takes the one-workgroup-per-CU build */
+    bool in_batch = false;             /* inside tqgpu_solve_batch: members launched one by one run side by side, two workgroups to a CU -- not with that build */
     bool gp_in_lds = false, gp_const_in_lds = false, gp_tab_in_lds = false, gp_small16 = false, gp_small8 = false;
     double *pab = nullptr, *pcst = nullptr;
     bool need_pack = true;          /* QP data changed since the constants were packed */
@@ -1885,7 +1887,7 @@ int setup_persist(tqgpu_solver *s, int device) {
     int wg = 0;
     for (int i = 0; i < s->n_tiers; i++) { G.l0[i] = s->tier_l0[i]; G.l1[i] = s->tier_l1[i]; G.grid[i] = s->tier_grid[i]; G.chain[i] = s->tier_chain[i]; G.wg0[i] = wg; wg += s->tier_grid[i]; }
     G.G = wg;
-    int per_cu = 0, per_cu_r = 1 << 20;      /* _r: the variant that can keep factors (checkLastActiveSet == 2) */
+    int per_cu = 0, per_cu_r = 1 << 20, per_cu_one = 0;      /* _r: the variant that can keep factors (checkLastActiveSet == 2); _one: the build for one workgroup per CU */
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     if (!s->mstage) {
@@ -1895,6 +1897,7 @@ int setup_persist(tqgpu_solver *s, int device) {
         s->lds_persist = PLds<nx, nu, md>::DOUBLES * sizeof(double);                                                         \
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f_persist<nx, nu, md, false>, FW * WAVE, s->lds_persist)); \
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_r, f_persist<nx, nu, md, true>, FW * WAVE, s->lds_persist)); \
+        if (allow_lds(f_persist_one<nx, nu, md>, s->lds_persist) != TQGPU_OK || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_one, f_persist_one<nx, nu, md>, FW * WAVE, s->lds_persist) != hipSuccess) per_cu_one = 0; \
         break;
             FAST_TABLE(X)
 #undef X
@@ -1907,6 +1910,7 @@ int setup_persist(tqgpu_solver *s, int device) {
         s->lds_persist = std::max(PLds<nx, nu, md>::DOUBLES, PLds<nx, nu, 1>::DOUBLES) * sizeof(double);                     \
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f_mpersist<nx, nu, md, false>, FW * WAVE, s->lds_persist)); \
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_r, f_mpersist<nx, nu, md, true>, FW * WAVE, s->lds_persist)); \
+        if (allow_lds(f_mpersist_one<nx, nu, md>, s->lds_persist) != TQGPU_OK || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_one, f_mpersist_one<nx, nu, md>, FW * WAVE, s->lds_persist) != hipSuccess) per_cu_one = 0; \
         break;
             MSTAGE_TABLE(X)
 #undef X
@@ -1936,6 +1940,8 @@ int setup_persist(tqgpu_solver *s, int device) {
     if (getenv("TREEQP_AMD_VERBOSE")) fprintf(stderr, "[treeqp_amd] persistent path: %d workgroups, %d per CU possible, capacity %d\n", G.G, per_cu, capacity);
     s->co_capacity = std::max(1, capacity);
     s->n_cu = prop.multiProcessorCount;
+    /* the build for ONE workgroup per CU (f_persist_one: more registers, 2 % faster) when the launch fits the device that way */
+    s->persist_one = per_cu_one >= 1 && G.G <= prop.multiProcessorCount * std::min(per_cu_one, 1) && !getenv("TREEQP_AMD_NO_PERSIST_ONE");
     if (per_cu < 1 || G.G > capacity) return TQGPU_OK;
     /* hand-over buffers (tagged 64-bit words, see tdunes_persist.hpp); zeroed once, never reset */
     const int nx0 = s->nx[0];
@@ -2060,6 +2066,7 @@ int launch_persist(tqgpu_solver *s, const Opts &O, int &launches, int prologue, 
     if (!s->mstage) {
         switch (s->fast) {
 #define X(idx, nx, nu, md) case idx: if (O.reuse) hipLaunchKernelGGL((f_persist<nx, nu, md, true>), dim3(s->geom.G), dim3(FW * WAVE), s->lds_persist, st, s->pconst, O, s->geom, s->psync, prologue); \
+                                    else if (s->persist_one && !s->in_batch) hipLaunchKernelGGL((f_persist_one<nx, nu, md>), dim3(s->geom.G), dim3(FW * WAVE), s->lds_persist, st, s->pconst, O, s->geom, s->psync, prologue); \
                                     else hipLaunchKernelGGL((f_persist<nx, nu, md, false>), dim3(s->geom.G), dim3(FW * WAVE), s->lds_persist, st, s->pconst, O, s->geom, s->psync, prologue); break;
             FAST_TABLE(X)
 #undef X
@@ -2068,6 +2075,7 @@ int launch_persist(tqgpu_solver *s, const Opts &O, int &launches, int prologue, 
     } else {
         switch (s->fast) {
 #define X(idx, nx, nu, md) case idx: if (O.reuse) hipLaunchKernelGGL((f_mpersist<nx, nu, md, true>), dim3(s->geom.G), dim3(FW * WAVE), s->lds_persist, st, s->pconst, O, s->geom, s->psync, prologue); \
+                                    else if (s->persist_one && !s->in_batch) hipLaunchKernelGGL((f_mpersist_one<nx, nu, md>), dim3(s->geom.G), dim3(FW * WAVE), s->lds_persist, st, s->pconst, O, s->geom, s->psync, prologue); \
                                     else hipLaunchKernelGGL((f_mpersist<nx, nu, md, false>), dim3(s->geom.G), dim3(FW * WAVE), s->lds_persist, st, s->pconst, O, s->geom, s->psync, prologue); break;
             MSTAGE_TABLE(X)
 #undef X
@@ -3290,6 +3298,11 @@ extern "C" int tqgpu_solve_batch(tqgpu_solver **solvers, int n, const tqgpu_opts
     for (int i = 0; i < n; i++) if (!solvers[i]) return fail(TQGPU_EINVAL, "tqgpu_solve_batch: null mirror");
     for (int i = 0; i < n; i++) if (solvers[i]->pshard && solvers[i]->nranks > 1) return fail(TQGPU_EINVAL, "tqgpu_solve_batch: a member is one rank of a sharded solve (tqgpu_pshard_init)");
     std::vector<SolveCtx> cx((size_t)n);
+    struct InBatch {                    /* (see tqgpu_solver::in_batch) */
+        tqgpu_solver **v; int n;
+        InBatch(tqgpu_solver **v_, int n_) : v(v_), n(n_) { for (int i = 0; i < n; i++) v[i]->in_batch = true; }
+        ~InBatch() { for (int i = 0; i < n; i++) v[i]->in_batch = false; }
+    } in_batch_guard(solvers, n);
     /* the environment switches of a batch call, read ONCE (a getenv is a scan of the environment: two dozen of them per call of seven members
      * were microseconds of a 125 us step) */
     const bool env_batch_launches = getenv("TREEQP_AMD_BATCH_LAUNCHES") != nullptr, env_batch_sync = getenv("TREEQP_AMD_BATCH_SYNC") != nullptr;

@@ -1741,6 +1741,20 @@ __global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_persist(PConst C, Opts O,
     persist_entry<NX, NU, MD, RU>(C, O, Gm, Sy, prologue, (int)blockIdx.x, lds_all);
 }
 #endif
+/* The same kernel compiled for ONE workgroup per CU (launch bounds: the compiler may take more than 256 registers -- 264 with the scalar
+ * spills' lanes for C2, against 244): 94.2 -> 92.5 us per C2 solve, 56.5 -> 55.6 on C1.  The host takes it when the launch fits the
+ * device at one workgroup per CU (C2: 73, C1: 10; not C3's 293, not a batch). */
+template <int NX, int NU, int MD>
+__global__ void __launch_bounds__(FW * WAVE, 1) f_persist_one(PConst C, Opts O, PGeom Gm, PSync Sy, int prologue)
+#if !TQ_HAS(TQP_PERSIST)
+;
+#else
+{
+    extern __shared__ __attribute__((aligned(16))) double lds_all[];
+    Sy.npeer = 1; Sy.relay_wg = -1; Sy.anc_local = 1;
+    persist_entry<NX, NU, MD, false>(C, O, Gm, Sy, prologue, (int)blockIdx.x, lds_all);
+}
+#endif
 /* the same launch as one rank's share of a sharded solve (tqgpu_pshard_*): hand-over words go to every rank's slab */
 /* SC only tells two builds of the same body apart: 1 = compiled in the part whose polls of the slab are system-scope loads (TQ_LD_SCOPE, tdunes_parts.hpp:
  * the slab is written by peers over xGMI), 0 = agent-scope polls as on one device (kept for A/B runs on a node: TREEQP_AMD_PSHARD_AGENT=1) */
@@ -1786,6 +1800,18 @@ __global__ void __launch_bounds__(FW * WAVE, TQ_WPS) f_mpersist(PConst C, Opts O
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     Sy.npeer = 1; Sy.relay_wg = -1; Sy.anc_local = 1;
     mpersist_entry<NX, NU, MD, RU>(C, O, Gm, Sy, prologue, (int)blockIdx.x, lds_all);
+}
+#endif
+
+template <int NX, int NU, int MD>      /* (one workgroup per CU: see f_persist_one) */
+__global__ void __launch_bounds__(FW * WAVE, 1) f_mpersist_one(PConst C, Opts O, PGeom Gm, PSync Sy, int prologue)
+#if !TQ_HAS(TQP_PERSIST)
+;
+#else
+{
+    extern __shared__ __attribute__((aligned(16))) double lds_all[];
+    Sy.npeer = 1; Sy.relay_wg = -1; Sy.anc_local = 1;
+    mpersist_entry<NX, NU, MD, false>(C, O, Gm, Sy, prologue, (int)blockIdx.x, lds_all);
 }
 #endif
 
@@ -1840,11 +1866,13 @@ __global__ void k_pack_persist(int Nn, int Np, int NX, int NU, Data D, double *A
 #if TQ_HAS(TQP_PERSIST)
 #define X(idx, nx, nu, md) TQ_SL(idx, \
     template __global__ void f_persist<nx, nu, md, false>(PConst, Opts, PGeom, PSync, int); \
+    template __global__ void f_persist_one<nx, nu, md>(PConst, Opts, PGeom, PSync, int); \
     template __global__ void f_persist<nx, nu, md, true>(PConst, Opts, PGeom, PSync, int);)
 FAST_TABLE(X)
 #undef X
 #define X(idx, nx, nu, md) TQ_SL(idx, \
     template __global__ void f_mpersist<nx, nu, md, false>(PConst, Opts, PGeom, PSync, int); \
+    template __global__ void f_mpersist_one<nx, nu, md>(PConst, Opts, PGeom, PSync, int); \
     template __global__ void f_mpersist<nx, nu, md, true>(PConst, Opts, PGeom, PSync, int);)
 MSTAGE_TABLE(X)
 #undef X
